@@ -1,0 +1,679 @@
+"""CPU oracle for the DuPL per-step hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch-CPU fp32 *restatement* of the reference algorithm for the path
+named by BASELINE.json:north_star.  It is the checker that the
+HIP kernels are compared with; nothing under ``dupl_amd/`` may import it.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` use it.
+
+Parity status: PINNED.  ``oracle/gen_golden.py`` imports the real reference from /root/reference
+(with a timm shim) in the authoring container, loads identical hash-generated weights into both and
+checks every function below against it; it then writes the fixtures in ``tests/golden/`` which
+``tests/test_oracle_golden.py`` replays on any machine.
+
+All citations are relative to /root/reference.  The code is written functionally over a flat
+``{state_dict key: tensor}`` parameter dict (the reference's own key names) so that the
+same parameter dict drives the reference modules, this oracle and the HIP engine.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------
+# Deterministic, platform-independent tensor generator (not torch.manual_seed: version dependent)
+# ----------------------------------------------------------------------------------------------
+def _mix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays (wraps mod 2**64)."""
+    x = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def _name_seed(name: str, seed: int) -> np.uint64:
+    h = np.uint64(1469598103934665603)
+    with np.errstate(over="ignore"):
+        for ch in name.encode():
+            h = (h ^ np.uint64(ch)) * np.uint64(1099511628211)
+        h = h ^ (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15))
+    return h
+
+
+def hash_uniform(name: str, n: int, seed: int = 0, stream: int = 0) -> np.ndarray:
+    """n float64 uniforms in (0,1) from a counter-based hash keyed on (name, seed, stream)."""
+    base = _name_seed(name, seed)
+    with np.errstate(over="ignore"):
+        ctr = np.arange(n, dtype=np.uint64) * np.uint64(2) + np.uint64(stream) + base
+    bits = _mix64(_mix64(ctr) + np.uint64(0x9E3779B97F4A7C15))
+    return ((bits >> np.uint64(11)).astype(np.float64) + 0.5) / float(1 << 53)
+
+
+def hash_normal(name: str, shape: Sequence[int], std: float = 1.0, seed: int = 0) -> Tensor:
+    """float32 N(0,std) tensor: Box-Muller in float64 over hash_uniform streams 0/1."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    u1 = hash_uniform(name, n, seed, 0)
+    u2 = hash_uniform(name, n, seed, 1)
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return torch.from_numpy((z * std).astype(np.float32).reshape(tuple(shape)))
+
+
+def hash_randint(name: str, shape: Sequence[int], lo: int, hi: int, seed: int = 0) -> np.ndarray:
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = hash_uniform(name, n, seed, 0)
+    return (lo + np.floor(u * (hi - lo))).astype(np.int64).reshape(tuple(shape))
+
+
+# ----------------------------------------------------------------------------------------------
+# Model configuration and parameter dictionary
+# ----------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ViTConfig:
+    """Hyper-parameters of the only backbone shape on the path (deit.py:97-100, vit.py:1092-1096)."""
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    mlp_ratio: int = 4
+    patch: int = 16
+    img_size: int = 224          # -> 14x14 pos-embed grid (vit.py:245)
+    aux_layer: int = -3          # train_final_voc.py:56
+    ln_eps: float = 1e-6
+    head_classes: int = 1000     # unused `head` Linear kept for state_dict parity (vit.py:263)
+
+    @property
+    def grid(self) -> int:
+        return self.img_size // self.patch
+
+
+VIT_BASE = ViTConfig()
+VIT_TINY = ViTConfig(embed_dim=96, depth=4, num_heads=3, head_classes=10)  # golden-vector model
+
+
+def student_param_shapes(cfg: ViTConfig, num_classes: int) -> Dict[str, Tuple[int, ...]]:
+    """state_dict keys/shapes of one `network` (model_dupl.py:9-41; SURVEY 8b: 157 tensors)."""
+    D, Hd = cfg.embed_dim, cfg.embed_dim * cfg.mlp_ratio
+    s: Dict[str, Tuple[int, ...]] = {}
+    s["encoder.cls_token"] = (1, 1, D)
+    s["encoder.pos_embed"] = (1, cfg.grid * cfg.grid + 1, D)
+    s["encoder.patch_embed.proj.weight"] = (D, 3, cfg.patch, cfg.patch)
+    s["encoder.patch_embed.proj.bias"] = (D,)
+    for i in range(cfg.depth):
+        p = f"encoder.blocks.{i}."
+        s[p + "norm1.weight"] = (D,)
+        s[p + "norm1.bias"] = (D,)
+        s[p + "attn.qkv.weight"] = (3 * D, D)
+        s[p + "attn.qkv.bias"] = (3 * D,)
+        s[p + "attn.proj.weight"] = (D, D)
+        s[p + "attn.proj.bias"] = (D,)
+        s[p + "norm2.weight"] = (D,)
+        s[p + "norm2.bias"] = (D,)
+        s[p + "mlp.fc1.weight"] = (Hd, D)
+        s[p + "mlp.fc1.bias"] = (Hd,)
+        s[p + "mlp.fc2.weight"] = (D, Hd)
+        s[p + "mlp.fc2.bias"] = (D,)
+    s["encoder.norm.weight"] = (D,)
+    s["encoder.norm.bias"] = (D,)
+    s["encoder.head.weight"] = (cfg.head_classes, D)
+    s["encoder.head.bias"] = (cfg.head_classes,)
+    s["decoder.conv6.weight"] = (512, D, 3, 3)
+    s["decoder.conv7.weight"] = (512, 512, 3, 3)
+    s["decoder.conv8.weight"] = (num_classes, 512, 1, 1)
+    s["classifier.weight"] = (num_classes - 1, D, 1, 1)
+    s["aux_classifier.weight"] = (num_classes - 1, D, 1, 1)
+    return s
+
+
+def make_student_params(cfg: ViTConfig, num_classes: int, seed: int = 0, prefix: str = "",
+                        std: float = 0.02, randomize_affine: bool = True) -> Dict[str, Tensor]:
+    """Hash-generated weights.  Unlike the reference init (biases 0, LN (1,0)) every
+    tensor is randomised when `randomize_affine` so that bias / LN-affine paths are exercised."""
+    out: Dict[str, Tensor] = {}
+    for k, shp in student_param_shapes(cfg, num_classes).items():
+        name = prefix + k
+        is_norm_w = k.endswith("weight") and ("norm" in k)
+        if k.startswith("decoder") or "classifier" in k:
+            fan_in = int(np.prod(shp[1:]))
+            t = hash_normal(name, shp, std=1.0 / math.sqrt(fan_in), seed=seed)
+        elif is_norm_w:
+            t = 1.0 + hash_normal(name, shp, std=0.1 if randomize_affine else 0.0, seed=seed)
+        elif k.endswith("bias"):
+            t = hash_normal(name, shp, std=std if randomize_affine else 0.0, seed=seed)
+        else:
+            t = hash_normal(name, shp, std=std, seed=seed)
+        out[k] = t
+    return out
+
+
+def make_siamese_params(cfg: ViTConfig, num_classes: int, seed: int = 0, **kw) -> Dict[str, Tensor]:
+    out: Dict[str, Tensor] = {}
+    for br in ("branch1.", "branch2."):
+        for k, v in make_student_params(cfg, num_classes, seed, prefix=br, **kw).items():
+            out[br + k] = v
+    return out
+
+
+def sub_params(params: Dict[str, Tensor], prefix: str) -> Dict[str, Tensor]:
+    n = len(prefix)
+    return {k[n:]: v for k, v in params.items() if k.startswith(prefix)}
+
+
+# ----------------------------------------------------------------------------------------------
+# a1-a6: ViT backbone
+# ----------------------------------------------------------------------------------------------
+def patch_embed(p: Dict[str, Tensor], x: Tensor, cfg: ViTConfig) -> Tensor:
+    """PatchEmbed.forward, vit.py:178-184: 16x16/s16 conv -> (B, n, D), patches row-major."""
+    y = F.conv2d(x, p["encoder.patch_embed.proj.weight"], p["encoder.patch_embed.proj.bias"],
+                 stride=cfg.patch)
+    return y.flatten(2).transpose(1, 2)
+
+
+def resized_pos_embed(p: Dict[str, Tensor], h: int, w: int, cfg: ViTConfig) -> Tensor:
+    """prepare_tokens, vit.py:294-297: bicubic(align_corners=False) 14x14 -> hxw, cls pos first."""
+    pe = p["encoder.pos_embed"]
+    g = cfg.grid
+    grid = pe[:, 1:, :].reshape(1, g, g, -1).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=(h, w), mode="bicubic", align_corners=False)
+    grid = grid.reshape(1, -1, h * w).permute(0, 2, 1)
+    return torch.cat((pe[:, :1, :], grid), dim=1)
+
+
+def prepare_tokens(p: Dict[str, Tensor], x: Tensor, cfg: ViTConfig) -> Tensor:
+    """vit.py:289-306."""
+    B, _, H, W = x.shape
+    h, w = H // cfg.patch, W // cfg.patch
+    tok = patch_embed(p, x, cfg)
+    cls = p["encoder.cls_token"].expand(B, -1, -1)
+    return torch.cat((cls, tok), dim=1) + resized_pos_embed(p, h, w, cfg)
+
+
+def attention(p: Dict[str, Tensor], pre: str, x: Tensor, cfg: ViTConfig) -> Tensor:
+    """Attention.forward, vit.py:120-138 (probabilities are not returned: vit.py:320 drops them)."""
+    B, N, C = x.shape
+    H = cfg.num_heads
+    qkv = F.linear(x, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    scale = (C // H) ** -0.5
+    att = (q @ k.transpose(-2, -1)) * scale
+    att = att.softmax(dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(B, N, C)
+    return F.linear(o, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"])
+
+
+def mlp(p: Dict[str, Tensor], pre: str, x: Tensor) -> Tensor:
+    """Mlp.forward, vit.py:97-103: fc1 -> exact-erf GELU -> fc2 (dropout p=0)."""
+    h = F.linear(x, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"])
+    h = F.gelu(h)
+    return F.linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+
+
+def block(p: Dict[str, Tensor], i: int, x: Tensor, cfg: ViTConfig) -> Tensor:
+    """Block.forward, vit.py:156-160 (drop_path = Identity)."""
+    pre = f"encoder.blocks.{i}."
+    D = cfg.embed_dim
+    y = F.layer_norm(x, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.ln_eps)
+    x = x + attention(p, pre, y, cfg)
+    y = F.layer_norm(x, (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps)
+    return x + mlp(p, pre, y)
+
+
+def forward_features(p: Dict[str, Tensor], x: Tensor, cfg: ViTConfig) -> Tuple[Tensor, Tensor, Tensor]:
+    """VisionTransformer.forward_features, vit.py:308-326 -> (cls, patch tokens, aux tokens).
+    aux = output of block `aux_layer` (un-normed unless it is the last), embeds[-1] = final LN."""
+    t = prepare_tokens(p, x, cfg)
+    embeds = []
+    for i in range(cfg.depth):
+        t = block(p, i, t, cfg)
+        embeds.append(t)
+    t = F.layer_norm(t, (cfg.embed_dim,), p["encoder.norm.weight"], p["encoder.norm.bias"], cfg.ln_eps)
+    embeds[-1] = t
+    return t[:, 0], t[:, 1:], embeds[cfg.aux_layer][:, 1:]
+
+
+# ----------------------------------------------------------------------------------------------
+# a7-a9: heads
+# ----------------------------------------------------------------------------------------------
+def to_2d(x: Tensor, h: int, w: int) -> Tensor:
+    """network.to_2D, model_dupl.py:64-67."""
+    n, hw, c = x.shape
+    return x.transpose(1, 2).reshape(n, c, h, w)
+
+
+def large_fov(p: Dict[str, Tensor], x: Tensor, dilation: int = 5) -> Tensor:
+    """LargeFOV.forward, conv_head.py:32-41 (all bias-free)."""
+    x = F.relu(F.conv2d(x, p["decoder.conv6.weight"], padding=dilation, dilation=dilation))
+    x = F.relu(F.conv2d(x, p["decoder.conv7.weight"], padding=dilation, dilation=dilation))
+    return F.conv2d(x, p["decoder.conv8.weight"])
+
+
+def network_forward(p: Dict[str, Tensor], x: Tensor, cfg: ViTConfig, cam_only: bool = False):
+    """network.forward, model_dupl.py:69-106.
+    cam_only -> (cam_aux, cam) detached, aux FIRST; else (cls_x4, seg, x4, cls_aux)."""
+    _, tok, tok_aux = forward_features(p, x, cfg)
+    h, w = x.shape[-2] // cfg.patch, x.shape[-1] // cfg.patch
+    x4 = to_2d(tok, h, w)
+    xa = to_2d(tok_aux, h, w)
+    if cam_only:
+        cam = F.conv2d(x4, p["classifier.weight"]).detach()
+        cam_aux = F.conv2d(xa, p["aux_classifier.weight"]).detach()
+        return cam_aux, cam
+    seg = large_fov(p, x4)
+    C = p["classifier.weight"].shape[0]
+    cls_aux = F.conv2d(F.adaptive_max_pool2d(xa, (1, 1)), p["aux_classifier.weight"]).view(-1, C)
+    cls_x4 = F.conv2d(F.adaptive_max_pool2d(x4, (1, 1)), p["classifier.weight"]).view(-1, C)
+    return cls_x4, seg, x4, cls_aux
+
+
+# ----------------------------------------------------------------------------------------------
+# a10: multi-scale CAM
+# ----------------------------------------------------------------------------------------------
+def multi_scale_cam(p: Dict[str, Tensor], inputs: Tensor, cfg: ViTConfig,
+                    scales: Sequence[float] = (1.0, 0.5, 1.5)) -> Tuple[Tensor, Tensor]:
+    """multi_scale_cam2[_siamese], cam_helper.py:164-204 / camutils.py:87-127 -> (cam, cam_aux)."""
+    b, _, h, w = inputs.shape
+
+    def one(x):
+        cat = torch.cat([x, x.flip(-1)], dim=0)
+        ca, c = network_forward(p, cat, cfg, cam_only=True)
+        outs = []
+        for m in (c, ca):
+            m = F.interpolate(m, size=(h, w), mode="bilinear", align_corners=False)
+            m = torch.max(m[:b], m[b:].flip(-1))
+            outs.append(F.relu(m))
+        return outs
+
+    with torch.no_grad():
+        cams, auxs = [], []
+        c, a = one(inputs)
+        cams.append(c), auxs.append(a)
+        for s in scales:
+            if s != 1.0:
+                xi = F.interpolate(inputs, size=(int(s * h), int(s * w)), mode="bilinear",
+                                   align_corners=False)
+                c, a = one(xi)
+                cams.append(c), auxs.append(a)
+        res = []
+        for lst in (cams, auxs):
+            m = torch.sum(torch.stack(lst, dim=0), dim=0)
+            m = m + F.adaptive_max_pool2d(-m, (1, 1))
+            m = m / (F.adaptive_max_pool2d(m, (1, 1)) + 1e-5)
+            res.append(m)
+    return res[0], res[1]
+
+
+# ----------------------------------------------------------------------------------------------
+# a11: CAM -> label
+# ----------------------------------------------------------------------------------------------
+def cam_to_label(cam: Tensor, cls_label: Tensor, img_box=None, bkg_thre=None, high_thre=None,
+                 low_thre=None, ignore_mid: bool = False, ignore_index=None):
+    """cam_to_label / cam_to_label_dynamic_cls, cam_helper.py:8-55.
+    `high_thre` may be a python scalar or a (b,) tensor (dynamic variant)."""
+    b, c, h, w = cam.shape
+    valid = cls_label[:, :, None, None] * cam
+    val, lab = valid.max(dim=1)
+    lab = lab + 1
+    lab[val <= bkg_thre] = 0
+    if img_box is None:
+        return lab
+    if ignore_mid:
+        ht = high_thre
+        if torch.is_tensor(ht):
+            ht = ht.reshape(-1, 1, 1)
+        lab[val <= ht] = ignore_index
+        lab[val <= low_thre] = 0
+    out = torch.full_like(lab, ignore_index)
+    for i, bx in enumerate(img_box):
+        y0, y1, x0, x1 = (int(v) for v in bx)
+        out[i, y0:y1, x0:x1] = lab[i, y0:y1, x0:x1]
+    return valid, out
+
+
+# ----------------------------------------------------------------------------------------------
+# a12: affinity mask + PTC loss
+# ----------------------------------------------------------------------------------------------
+def label_to_aff_mask(cam_label: Tensor, ignore_index: int = 255) -> Tensor:
+    """cam_helper.py:323-335 -> (b, hw, hw) int64 in {0,1,255}."""
+    b, h, w = cam_label.shape
+    l = cam_label.reshape(b, -1)
+    aff = (l[:, :, None] == l[:, None, :]).long()
+    ign = l == ignore_index
+    aff[ign[:, :, None].expand_as(aff)] = ignore_index
+    aff[ign[:, None, :].expand_as(aff)] = ignore_index
+    idx = torch.arange(h * w)
+    aff[:, idx, idx] = ignore_index
+    return aff
+
+
+def masked_ptc_loss(fmap: Tensor, mask: Tensor) -> Tensor:
+    """get_masked_ptc_loss, losses.py:6-21."""
+    b, c, h, w = fmap.shape
+    x = F.normalize(fmap.reshape(b, c, h * w), p=2, dim=1, eps=1e-8)
+    cs = torch.abs(torch.matmul(x.transpose(1, 2), x))
+    pos, neg = mask == 1, mask == 0
+    return 0.5 * (1 - torch.sum(pos * cs) / (pos.sum() + 1)) + 0.5 * torch.sum(neg * cs) / (neg.sum() + 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# a14: PAR
+# ----------------------------------------------------------------------------------------------
+PAR_DILATIONS = (1, 2, 4, 8, 12, 24)
+# neighbour order per dilation (PAR.py:10-24): (dy, dx) in units of d
+PAR_OFFSETS = ((-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1))
+
+
+def par_neighbors(x: Tensor, dilations=PAR_DILATIONS) -> Tensor:
+    """get_dilated_neighbors, PAR.py:39-49, restated as clamped-index gathers:
+    (b,c,h,w) -> (b,c,8*len(dil),h,w); replicate padding == index clamp."""
+    b, c, h, w = x.shape
+    ys = torch.arange(h)
+    xs = torch.arange(w)
+    outs = []
+    for d in dilations:
+        for dy, dx in PAR_OFFSETS:
+            yy = (ys + dy * d).clamp(0, h - 1)
+            xx = (xs + dx * d).clamp(0, w - 1)
+            outs.append(x[:, :, yy][:, :, :, xx])
+    return torch.stack(outs, dim=2)
+
+
+def par_pos_affinity(dilations=PAR_DILATIONS, w1: float = 0.3) -> Tensor:
+    """get_pos + the position term of PAR.forward (PAR.py:51-62,78,83): softmax over the 48
+    neighbours of -(pos/(std(pos)+1e-8)/w1)^2, pos = d or d*sqrt(2).  Returns (48,) float32."""
+    ker = torch.ones(8)
+    ker[[0, 2, 5, 7]] = float(np.sqrt(2))
+    pos = torch.cat([ker * d for d in dilations])
+    std = torch.std(pos)
+    aff = -((pos / (std + 1e-8) / w1) ** 2)
+    return F.softmax(aff, dim=0)
+
+
+def par_affinity(imgs: Tensor, dilations=PAR_DILATIONS, w1: float = 0.3, w2: float = 0.01) -> Tensor:
+    """Colour + position affinity, PAR.py:66-85 -> (b,1,48,h,w)."""
+    nb = par_neighbors(imgs, dilations)
+    ab = torch.abs(nb - imgs.unsqueeze(2))
+    sd = torch.std(nb, dim=2, keepdim=True)
+    aff = -((ab / (sd + 1e-8) / w1) ** 2)
+    aff = aff.mean(dim=1, keepdim=True)
+    pos = par_pos_affinity(dilations, w1).view(1, 1, -1, 1, 1)
+    return F.softmax(aff, dim=2) + w2 * pos
+
+
+def par_forward(imgs: Tensor, masks: Tensor, dilations=PAR_DILATIONS, num_iter: int = 10) -> Tensor:
+    """PAR.forward, PAR.py:64-91."""
+    masks = F.interpolate(masks, size=imgs.shape[-2:], mode="bilinear", align_corners=True)
+    aff = par_affinity(imgs, dilations)
+    for _ in range(num_iter):
+        masks = (par_neighbors(masks, dilations) * aff).sum(2)
+    return masks
+
+
+# ----------------------------------------------------------------------------------------------
+# a13: refinement with background thresholds
+# ----------------------------------------------------------------------------------------------
+def refine_cams(images: Tensor, cams: Tensor, cls_labels: Tensor, high_thre, low_thre: float,
+                ignore_index: int, img_box, down_scale: int = 2,
+                dilations=PAR_DILATIONS, num_iter: int = 10) -> Tensor:
+    """refine_cams_with_bkg_v2 (scalar high_thre) / refine_cams_with_dynamic_thres (high_thre a
+    (b,1,h,w) map), cam_helper.py:338-440 -> (b,h,w) float32 labels in {0..C, 255}."""
+    b, _, h, w = images.shape
+    hs, ws = h // down_scale, w // down_scale
+    _images = F.interpolate(images, size=[hs, ws], mode="bilinear", align_corners=False)
+    if torch.is_tensor(high_thre) and high_thre.dim() == 4:
+        bkg_h = high_thre.to(cams.dtype)
+    else:
+        bkg_h = torch.ones(b, 1, h, w) * high_thre
+    bkg_l = torch.ones(b, 1, h, w) * low_thre
+    cl = torch.cat((torch.ones(b, 1), cls_labels), dim=1)
+    lab_h = torch.ones(b, h, w) * ignore_index
+    lab_l = lab_h.clone()
+    ch = F.interpolate(torch.cat((bkg_h, cams), dim=1), size=[hs, ws], mode="bilinear", align_corners=False)
+    cl_ = F.interpolate(torch.cat((bkg_l, cams), dim=1), size=[hs, ws], mode="bilinear", align_corners=False)
+
+    def one(img, m, keys):
+        r = par_forward(img, m, dilations, num_iter)
+        r = F.interpolate(r, size=(h, w), mode="bilinear", align_corners=False)
+        return keys[r.argmax(dim=1)]
+
+    for i, bx in enumerate(img_box):
+        y0, y1, x0, x1 = (int(v) for v in bx)
+        keys = torch.nonzero(cl[i])[:, 0]
+        vh = ch[i, keys].unsqueeze(0).softmax(dim=1)
+        vl = cl_[i, keys].unsqueeze(0).softmax(dim=1)
+        rh = one(_images[[i]], vh, keys)
+        rl = one(_images[[i]], vl, keys)
+        lab_h[i, y0:y1, x0:x1] = rh[0, y0:y1, x0:x1].float()
+        lab_l[i, y0:y1, x0:x1] = rl[0, y0:y1, x0:x1].float()
+    out = lab_h.clone()
+    out[lab_h == 0] = ignore_index
+    out[(lab_h + lab_l) == 0] = 0
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# a15-a17: losses, de-normalisation
+# ----------------------------------------------------------------------------------------------
+def seg_loss(pred: Tensor, label: Tensor, ignore_index: int = 255) -> Tensor:
+    """get_seg_loss, losses.py:24-39: 0.5*(CE_bg/(n_bg+1e-6) + CE_fg/(n_fg+1e-6))."""
+    label = label.long()
+    ce = F.cross_entropy(pred, torch.where(label == ignore_index, torch.zeros_like(label), label),
+                         reduction="none")
+    bg = label == 0
+    fg = (label != 0) & (label != ignore_index)
+    bg_loss = (ce * bg).sum() / (bg.long().sum() + 1e-6)
+    fg_loss = (ce * fg).sum() / (fg.long().sum() + 1e-6)
+    return (bg_loss + fg_loss) * 0.5
+
+
+def sim_loss(f1: Tensor, f2: Tensor) -> Tensor:
+    """Discrepancy loss, train_final_voc.py:247-254: cosine over the SPATIAL axis (dim=-1)."""
+    a = f1.reshape(f1.shape[0], f1.shape[1], -1)
+    b = f2.reshape(f2.shape[0], f2.shape[1], -1)
+    s1 = 1 + F.cosine_similarity(a.detach(), b, dim=-1, eps=1e-6).mean()
+    s2 = 1 + F.cosine_similarity(b.detach(), a, dim=-1, eps=1e-6).mean()
+    return s1 + s2
+
+
+IMG_MEAN = (123.675, 116.28, 103.53)
+IMG_STD = (58.395, 57.12, 57.375)
+
+
+def denormalize_img2(imgs: Tensor) -> Tensor:
+    """imutils.py:17-31: (x*std+mean) -> uint8 TRUNCATION -> /255."""
+    std = torch.tensor(IMG_STD).view(1, 3, 1, 1)
+    mean = torch.tensor(IMG_MEAN).view(1, 3, 1, 1)
+    return (imgs * std + mean).type(torch.uint8) / 255.0
+
+
+def cosine_descent(max_thres, min_thres, step: int, num_steps: int):
+    """train_helper.py:340-349."""
+    if step < 0:
+        return max_thres
+    if step >= num_steps:
+        return min_thres
+    f = step / (num_steps - 1)
+    return max_thres + (min_thres - max_thres) * (1 - np.cos(np.pi * f)) / 2
+
+
+# ----------------------------------------------------------------------------------------------
+# a18: optimiser schedule + AdamW update
+# ----------------------------------------------------------------------------------------------
+def poly_warmup_lr_mult(step: int, warmup_iter: int = 1500, max_iter: int = 20000,
+                        warmup_ratio: float = 1e-6, power: float = 0.9) -> Optional[float]:
+    """PolyWarmupAdamW.step schedule, optimizer.py:51-63.  None == leave lr untouched."""
+    if step < warmup_iter:
+        return 1 - (1 - step / warmup_iter) * (1 - warmup_ratio)
+    if step < max_iter:
+        return (1 - step / max_iter) ** power
+    return None
+
+
+def adamw_update(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, wd: float = 0.01):
+    """torch.optim.AdamW single-tensor update (what optimizer.py:66 dispatches to); `step` is the
+    1-based count after increment.  In place on p, m, v."""
+    p.mul_(1 - lr * wd)
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def param_group_index(key: str) -> int:
+    """siamese_network.get_param_groups, model_dupl.py:119-154: 0 backbone, 1 backbone-norm
+    ("norm" in name), 2 cls heads, 3 decoders.  `key` is a siamese state_dict key."""
+    k = key.split(".", 1)[1]
+    if k.startswith("encoder."):
+        return 1 if "norm" in k[len("encoder."):] else 0
+    if k.startswith("decoder."):
+        return 3
+    return 2
+
+
+# ----------------------------------------------------------------------------------------------
+# Training step (phase A / B), train_final_voc.py:194-456
+# ----------------------------------------------------------------------------------------------
+VOC_HIGH_TARGET = (0.70, 0.70, 0.70, 0.70, 0.55, 0.55, 0.55, 0.55, 0.70, 0.55,
+                   0.55, 0.55, 0.55, 0.55, 0.55, 0.55, 0.55, 0.55, 0.70, 0.55)
+
+
+@dataclass
+class StepArgs:
+    cam_iters: int = 2000
+    gmm_iters: int = 8000
+    max_iters: int = 20000
+    bkg_thre: float = 0.5
+    high_thre: float = 0.7
+    low_thre: float = 0.25
+    ignore_index: int = 255
+    w_ptc: float = 0.2
+    w_seg: float = 0.2
+    cam_scales: Tuple[float, ...] = (1.0, 0.5, 1.5)
+    high_target: Tuple[float, ...] = VOC_HIGH_TARGET
+
+
+def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tensor, img_box,
+                      n_iter: int, cfg: ViTConfig, args: StepArgs = StepArgs()):
+    """One iteration's loss assembly for phases A and B (train_final_voc.py:194-352,440-456).
+    Returns (loss, dict of detached pieces).  `params` leaves may require grad."""
+    p1, p2 = sub_params(params, "branch1."), sub_params(params, "branch2.")
+    d1 = {k: v.detach() for k, v in p1.items()}
+    d2 = {k: v.detach() for k, v in p2.items()}
+    inputs_denorm = denormalize_img2(inputs.clone())
+    cams_1, cams_aux_1 = multi_scale_cam(d1, inputs, cfg, args.cam_scales)
+    cams_2, cams_aux_2 = multi_scale_cam(d2, inputs, cfg, args.cam_scales)
+    cls_1, segs_1, fmap_1, cls_aux_1 = network_forward(p1, inputs, cfg)
+    cls_2, segs_2, fmap_2, cls_aux_2 = network_forward(p2, inputs, cfg)
+    msm = F.multilabel_soft_margin_loss
+    cls_loss = msm(cls_1, cls_label) + msm(cls_aux_1, cls_label) + msm(cls_2, cls_label) + msm(cls_aux_2, cls_label)
+
+    phase_a = n_iter < args.cam_iters
+    b, _, h, w = inputs.shape
+    if phase_a:
+        high = args.high_thre
+    else:
+        C = cls_label.shape[1]
+        thr = cosine_descent(torch.ones(C) * args.high_thre, torch.tensor(args.high_target[:C]),
+                             n_iter - args.cam_iters, args.max_iters - args.cam_iters)
+        high = torch.stack([torch.max(thr[torch.nonzero(cls_label[i]).squeeze(-1)]) for i in range(b)])
+    fh, fw = fmap_1.shape[2:]
+    labels = []
+    for ca in (cams_aux_1, cams_aux_2):
+        r = F.interpolate(ca, size=(fh, fw), mode="bilinear", align_corners=False)
+        _, pl = cam_to_label(r, cls_label, img_box=img_box, ignore_mid=True, bkg_thre=args.bkg_thre,
+                             high_thre=high, low_thre=args.low_thre, ignore_index=args.ignore_index)
+        labels.append(pl)
+    ptc = masked_ptc_loss(fmap_1, label_to_aff_mask(labels[0])) + \
+        masked_ptc_loss(fmap_2, label_to_aff_mask(labels[1]))
+    pieces = {"pseudo_label_aux_1": labels[0], "pseudo_label_aux_2": labels[1],
+              "cams_1": cams_1, "cams_2": cams_2, "cams_aux_1": cams_aux_1, "cams_aux_2": cams_aux_2}
+    if phase_a:
+        seg = torch.ones(1)
+    else:
+        hmap = high.view(b, 1, 1, 1) * torch.ones(b, 1, h, w)
+        rep = cls_label[:, :, None, None]
+        r1 = refine_cams(inputs_denorm, cams_1 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box)
+        r2 = refine_cams(inputs_denorm, cams_2 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box)
+        s1 = F.interpolate(segs_1, size=(h, w), mode="bilinear", align_corners=False)
+        s2 = F.interpolate(segs_2, size=(h, w), mode="bilinear", align_corners=False)
+        seg = seg_loss(s1, r2.long(), args.ignore_index) + seg_loss(s2, r1.long(), args.ignore_index)
+        pieces["refined_1"], pieces["refined_2"] = r1, r2
+    sim = sim_loss(fmap_1, fmap_2)
+    if n_iter <= args.cam_iters:
+        loss = 1.0 * cls_loss + args.w_ptc * ptc + 0.0 * seg + 0.1 * sim
+    else:
+        loss = 1.0 * cls_loss + args.w_ptc * ptc + args.w_seg * seg + 0.1 * sim
+    pieces.update(cls_loss=cls_loss.detach(), ptc_loss=ptc.detach(), seg_loss=seg.detach(),
+                  sim_loss=sim.detach(), loss=loss.detach(), cls_1=cls_1.detach(), segs_1=segs_1.detach(),
+                  fmap_1=fmap_1.detach(), cls_aux_1=cls_aux_1.detach(), cls_2=cls_2.detach(),
+                  segs_2=segs_2.detach(), fmap_2=fmap_2.detach(), cls_aux_2=cls_aux_2.detach())
+    return loss, pieces
+
+
+# ----------------------------------------------------------------------------------------------
+# Synthetic batch
+# ----------------------------------------------------------------------------------------------
+def synthetic_batch(b: int, num_fg: int = 20, size: int = 448, seed: int = 0, smooth: bool = True):
+    """(inputs fp32 normalised from a uint8 image, cls_label multi-hot 1-3 positives, img_box i16).
+    `smooth`: blocky low-frequency content (so PAR affinities are non-degenerate) + uint8 noise.
+    Pure numpy float64 element-wise arithmetic -> bit-identical on every platform."""
+    u = hash_uniform(f"img{b}x{size}", b * 3 * size * size, seed).reshape(b, 3, size, size)
+    if smooth:
+        cell = 28 if size % 28 == 0 else 16
+        g = -(-size // cell)
+        lo = hash_uniform(f"imglo{b}x{size}", b * 3 * g * g, seed).reshape(b, 3, g, g)
+        lo = np.repeat(np.repeat(lo, cell, axis=2), cell, axis=3)[:, :, :size, :size]
+        yy = (np.arange(size, dtype=np.float64) / size).reshape(1, 1, size, 1)
+        xx = (np.arange(size, dtype=np.float64) / size).reshape(1, 1, 1, size)
+        ramp = 0.5 * yy + 0.5 * xx
+        u = 0.55 * lo + 0.25 * ramp + 0.2 * u
+    img_u8 = np.clip(np.floor(u * 256.0), 0, 255).astype(np.float32)
+    mean = np.array(IMG_MEAN, dtype=np.float32).reshape(1, 3, 1, 1)
+    std = np.array(IMG_STD, dtype=np.float32).reshape(1, 3, 1, 1)
+    inputs = torch.from_numpy(((img_u8 - mean) / std).astype(np.float32))
+    cls = np.zeros((b, num_fg), dtype=np.float32)
+    npos = hash_uniform(f"npos{b}", b, seed)
+    picks = hash_randint(f"pick{b}", (b, 3), 0, num_fg, seed)
+    for i in range(b):
+        k = 1 if npos[i] < 0.6 else (2 if npos[i] < 0.9 else 3)
+        for j in range(k):
+            cls[i, picks[i, j]] = 1.0
+    box = np.zeros((b, 4), dtype=np.int16)
+    r = hash_randint(f"box{b}", (b, 4), 0, size // 2, seed)
+    for i in range(b):
+        if i % 2 == 0:
+            box[i] = [0, size, 0, size]
+        else:
+            y0, x0 = int(r[i, 0]) // 2, int(r[i, 1]) // 2
+            y1 = min(size, y0 + size // 2 + int(r[i, 2]) // 2)
+            x1 = min(size, x0 + size // 2 + int(r[i, 3]) // 2)
+            box[i] = [y0, y1, x0, x1]
+    return inputs, torch.from_numpy(cls), torch.from_numpy(box)
+
+
+def synthetic_cams(b: int, C: int, h: int, w: int, seed: int = 0) -> Tensor:
+    """Smooth synthetic CAMs in [0,1]: a sum of 4 hash-placed Gaussian bumps per (image, class),
+    min-max normalised like a10.  numpy float64 -> float32 (platform independent up to libm exp)."""
+    prm = hash_uniform(f"cams{b}x{C}x{h}", b * C * 4 * 4, seed).reshape(b, C, 4, 4)
+    yy = (np.arange(h, dtype=np.float64) / h).reshape(1, 1, h, 1)
+    xx = (np.arange(w, dtype=np.float64) / w).reshape(1, 1, 1, w)
+    cam = np.zeros((b, C, h, w), dtype=np.float64)
+    for k in range(4):
+        cy = prm[:, :, k, 0].reshape(b, C, 1, 1)
+        cx = prm[:, :, k, 1].reshape(b, C, 1, 1)
+        sg = 0.05 + 0.25 * prm[:, :, k, 2].reshape(b, C, 1, 1)
+        am = 0.3 + prm[:, :, k, 3].reshape(b, C, 1, 1)
+        cam += am * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sg * sg))
+    cam = cam - cam.min(axis=(2, 3), keepdims=True)
+    cam = cam / (cam.max(axis=(2, 3), keepdims=True) + 1e-5)
+    return torch.from_numpy(cam.astype(np.float32))
