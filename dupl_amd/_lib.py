@@ -1,0 +1,101 @@
+"""ctypes binding of libdupl_hip.so -- the reference-side stub INTEGRATION.md describes.
+
+The prototypes are read from include/dupl_hip.h (single source of truth) and turned into ctypes
+signatures; every exported function is wrapped so that a non-zero status raises.  There is NO
+fallback: if the shared library is missing or a symbol is absent, importing the product path fails.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "dupl_hip.h")
+LIB_PATH = os.path.join(HERE, "libdupl_hip.so")
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of `dupl_gemm_desc` (include/dupl_hip.h)."""
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p), ("aux", ctypes.c_void_p),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32),
+        ("ldr", ctypes.c_int32), ("ldaux", ctypes.c_int32),
+        ("batch", ctypes.c_int32), ("zdiv", ctypes.c_int32),
+        ("sA0", ctypes.c_int64), ("sA1", ctypes.c_int64), ("sB0", ctypes.c_int64), ("sB1", ctypes.c_int64),
+        ("sC0", ctypes.c_int64), ("sC1", ctypes.c_int64), ("sR0", ctypes.c_int64), ("sR1", ctypes.c_int64),
+        ("sX0", ctypes.c_int64), ("sX1", ctypes.c_int64), ("sBias0", ctypes.c_int64), ("sBias1", ctypes.c_int64),
+        ("alpha", ctypes.c_float), ("flags", ctypes.c_int32),
+    ]
+
+
+GEMM_A_MCONTIG, GEMM_B_NCONTIG, GEMM_GELU, GEMM_ACCUM = 1, 2, 4, 8
+GEMM_MUL_DGELU, GEMM_RELU, GEMM_MUL_RELUMASK, GEMM_ABS, GEMM_STORE_PRE = 16, 32, 64, 128, 256
+
+_PROTO = re.compile(r"^\s*int\s+(dupl_\w+)\s*\(([^;{]*)\)\s*;", re.M | re.S)
+
+
+def _ctype(decl: str):
+    d = decl.strip()
+    if d == "void" or not d:
+        return None
+    if "dupl_gemm_desc" in d:
+        return ctypes.POINTER(GemmDesc)
+    if "*" in d or d.startswith("dupl_stream_t"):
+        return ctypes.c_void_p
+    base = d.replace("const", "").split()
+    ty = base[0]
+    return {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+            "int": ctypes.c_int, "double": ctypes.c_double}[ty]
+
+
+def parse_header(path: str = HEADER) -> Dict[str, List]:
+    """{function name: [ctypes argtypes]} for every `int dupl_*(...)` prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    out: Dict[str, List] = {}
+    for m in _PROTO.finditer(src):
+        name, args = m.group(1), m.group(2)
+        tys = [_ctype(a) for a in args.split(",")]
+        out[name] = [t for t in tys if t is not None]
+    return out
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  dupl_amd has no CPU / eager fallback by design.")
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, argtypes in self.protos.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the .so does not export a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+            setattr(self, name, fn if name == "dupl_abi_version" else self._checked(name, fn))
+
+    @staticmethod
+    def _checked(name, fn):
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise RuntimeError(f"{name} failed with status {rc} (-1 bad argument, -2 launch failure)")
+            return rc
+        call.__name__ = name
+        call.raw = fn
+        return call
+
+
+_LIB = None
+
+
+def lib() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB

@@ -1,0 +1,402 @@
+// Fused multi-head attention (flash style) on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Layout trick (CDNA4-specific): the 32x32 MFMA leaves D[i][j] with j = lane & 31 and i spread
+// over the 16 accumulator registers ( i = (e&3) + 8*(e>>2) + 4*(lane>>5) ).  We compute the
+// TRANSPOSED score tile S^T[key][q] = K . Q^T, so a lane owns ONE query column: the row softmax
+// is lane-local (+ one lane^32 exchange), and the probability registers are *already* in the
+// B-operand layout of the next MFMA ( O^T[d][q] += V^T[d][key] . P^T[key][q] ) because the k-index
+// of an f32 MFMA step is just (lane>>5): step e pairs key(e,0) with key(e,1)=key(e,0)+4.  No LDS
+// round trip, no permutes.  The same trick gives dQ / dK / dV in the backward kernels.
+// The reduction index may be permuted freely, so a lane half hf reads d = hf*HD/2 + step: each
+// lane's Q fragment is a contiguous 128-byte run.
+//
+// qkv is the raw nn.Linear(dim, 3*dim) output [B*N][3*H*HD] (vit.py:122); out is [B*N][H*HD].
+#include "common.h"
+#include "../../include/dupl_hip.h"
+
+namespace {
+
+constexpr int KT = 64;    // keys (fwd, dQ) or queries (dKV) staged per iteration
+constexpr int ANT = 256;  // threads: 4 waves x 32 rows
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int acc_row(int e, int hf) { return (e & 3) + 8 * (e >> 2) + 4 * hf; }
+
+// Stage a (KT x HD) tile (rows r0.., row stride ld floats) into registers; rows >= R are zero.
+template <int HD>
+struct Stage { float4 v[HD / 16]; };
+
+template <int HD>
+__device__ __forceinline__ void stage_load(Stage<HD>& s, const float* __restrict__ base, int ld, int r0, int R, int tid) {
+#pragma unroll
+    for (int i = 0; i < HD / 16; ++i) {
+        const int c = tid + ANT * i;
+        const int r = c / (HD / 4), dc = (c % (HD / 4)) * 4;
+        s.v[i] = (r0 + r < R) ? *reinterpret_cast<const float4*>(base + (size_t)(r0 + r) * ld + dc)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+// scatter into LDS with an odd row stride S (conflict-free for both fragment read patterns)
+template <int HD, int S>
+__device__ __forceinline__ void stage_store(const Stage<HD>& s, float* __restrict__ lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < HD / 16; ++i) {
+        const int c = tid + ANT * i;
+        const int r = c / (HD / 4), dc = (c % (HD / 4)) * 4;
+        float* p = lds + r * S + dc;
+        p[0] = s.v[i].x; p[1] = s.v[i].y; p[2] = s.v[i].z; p[3] = s.v[i].w;
+    }
+}
+
+// A lane's 128/64-byte fragment of its own row: elements [hf*HD/2, hf*HD/2 + HD/2)
+template <int HD>
+__device__ __forceinline__ void load_rowfrag(float (&f)[HD / 2], const float* __restrict__ rowp, bool valid, float mul) {
+#pragma unroll
+    for (int i = 0; i < HD / 8; ++i) {
+        float4 v = valid ? *reinterpret_cast<const float4*>(rowp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f[4 * i + 0] = v.x * mul; f[4 * i + 1] = v.y * mul; f[4 * i + 2] = v.z * mul; f[4 * i + 3] = v.w * mul;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int HD>
+__global__ __launch_bounds__(ANT) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int H, float scale) {
+    constexpr int SK = HD + 1, SV = HD + 1, HH = HD / 2, ND = HD / 32;
+    __shared__ __attribute__((aligned(16))) float smem[KT * SK + KT * SV];
+    float* Ks = smem;
+    float* Vs = smem + KT * SK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    const int D = H * HD, ld = 3 * D;
+    const float* base = qkv + (size_t)b * N * ld + h * HD;
+    const int qrow = q0 + l31;
+    const bool wave_active = q0 < N;
+
+    float qf[HH];
+    load_rowfrag<HD>(qf, base + (size_t)qrow * ld + hf * HH, qrow < N, scale);
+
+    f32x16 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (N + KT - 1) / KT;
+    Stage<HD> rk, rv;
+    stage_load<HD>(rk, base + D, ld, 0, N, tid);
+    stage_load<HD>(rv, base + 2 * D, ld, 0, N, tid);
+
+    for (int t = 0; t < nkt; ++t) {
+        __syncthreads();
+        stage_store<HD, SK>(rk, Ks, tid);
+        stage_store<HD, SV>(rv, Vs, tid);
+        __syncthreads();
+        if (t + 1 < nkt) {
+            stage_load<HD>(rk, base + D, ld, (t + 1) * KT, N, tid);
+            stage_load<HD>(rv, base + 2 * D, ld, (t + 1) * KT, N, tid);
+        }
+        if (!wave_active) continue;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kt2][e] = 0.f;
+            const float* kp = Ks + (kt2 * 32 + l31) * SK + hf * HH;
+#pragma unroll
+            for (int st = 0; st < HH; ++st) s[kt2] = MFMA32(kp[st], qf[st], s[kt2]);
+        }
+        const int kbase = t * KT;
+        if (kbase + KT > N) {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kbase + kt2 * 32 + acc_row(e, hf) >= N) s[kt2][e] = -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt2][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = expf(s[kt2][e] - m_new);
+                s[kt2][e] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float* vp = Vs + (kt2 * 32 + acc_row(e, hf)) * SV + l31;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) o[d] = MFMA32(vp[d * 32], s[kt2][e], o[d]);
+            }
+    }
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow < N) {
+        float* op = out + ((size_t)b * N + qrow) * D + h * HD;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = o[d][4 * g + 0] * inv; v.y = o[d][4 * g + 1] * inv;
+                v.z = o[d][4 * g + 2] * inv; v.w = o[d][4 * g + 3] * inv;
+                *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hf) = v;
+            }
+        if (lse && hf == 0) lse[((size_t)b * H + h) * N + qrow] = m_run + logf(l_tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int N, int H, int HD) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*N*H
+    const long total = (long)B * N * H;
+    if (idx >= total) return;
+    const int h = (int)(idx % H);
+    const long bn = idx / H;
+    const int n = (int)(bn % N), b = (int)(bn / N);
+    const float4* o = reinterpret_cast<const float4*>(out + bn * (long)(H * HD) + h * HD);
+    const float4* d = reinterpret_cast<const float4*>(dout + bn * (long)(H * HD) + h * HD);
+    float s = 0.f;
+    for (int i = 0; i < HD / 4; ++i) {
+        const float4 a = o[i], c = d[i];
+        s += (a.x * c.x + a.y * c.y) + (a.z * c.z + a.w * c.w);
+    }
+    delta[((long)b * H + h) * N + n] = s;
+}
+
+// dQ: block = 128 query rows (wave = 32), loops over key tiles.
+template <int HD>
+__global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          float* __restrict__ dqkv, int N, int H, float scale) {
+    constexpr int SK = HD + 1, HH = HD / 2, ND = HD / 32;
+    __shared__ __attribute__((aligned(16))) float smem[2 * KT * SK];
+    float* Ks = smem;
+    float* Vs = smem + KT * SK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    const int D = H * HD, ld = 3 * D;
+    const float* base = qkv + (size_t)b * N * ld + h * HD;
+    const int qrow = q0 + l31;
+    const bool wave_active = q0 < N, qv = qrow < N;
+
+    float qf[HH], dof[HH];
+    load_rowfrag<HD>(qf, base + (size_t)qrow * ld + hf * HH, qv, scale);
+    load_rowfrag<HD>(dof, dout + ((size_t)b * N + qrow) * D + h * HD + hf * HH, qv, 1.f);
+    const float my_lse = qv ? lse[((size_t)b * H + h) * N + qrow] : 0.f;
+    const float my_delta = qv ? delta[((size_t)b * H + h) * N + qrow] : 0.f;
+
+    f32x16 dq[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
+
+    const int nkt = (N + KT - 1) / KT;
+    Stage<HD> rk, rv;
+    stage_load<HD>(rk, base + D, ld, 0, N, tid);
+    stage_load<HD>(rv, base + 2 * D, ld, 0, N, tid);
+    for (int t = 0; t < nkt; ++t) {
+        __syncthreads();
+        stage_store<HD, SK>(rk, Ks, tid);
+        stage_store<HD, SK>(rv, Vs, tid);
+        __syncthreads();
+        if (t + 1 < nkt) {
+            stage_load<HD>(rk, base + D, ld, (t + 1) * KT, N, tid);
+            stage_load<HD>(rv, base + 2 * D, ld, (t + 1) * KT, N, tid);
+        }
+        if (!wave_active) continue;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+            const float* kp = Ks + (kt2 * 32 + l31) * SK + hf * HH;
+            const float* vp = Vs + (kt2 * 32 + l31) * SK + hf * HH;
+#pragma unroll
+            for (int st = 0; st < HH; ++st) s = MFMA32(kp[st], qf[st], s);
+#pragma unroll
+            for (int st = 0; st < HH; ++st) dp = MFMA32(vp[st], dof[st], dp);
+            const int kb = t * KT + kt2 * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool kvld = kb + acc_row(e, hf) < N;
+                const float p = kvld ? expf(s[e] - my_lse) : 0.f;
+                s[e] = p * (dp[e] - my_delta);  // dS^T[key][q]
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float* kr = Ks + (kt2 * 32 + acc_row(e, hf)) * SK + l31;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) dq[d] = MFMA32(kr[d * 32], s[e], dq[d]);
+            }
+        }
+    }
+    if (!wave_active || !qv) return;
+    float* op = dqkv + ((size_t)b * N + qrow) * ld + h * HD;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = dq[d][4 * g + 0] * scale; v.y = dq[d][4 * g + 1] * scale;
+            v.z = dq[d][4 * g + 2] * scale; v.w = dq[d][4 * g + 3] * scale;
+            *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hf) = v;
+        }
+}
+
+// dK, dV: block = 128 key rows (wave = 32 keys), loops over query tiles of KT rows.
+template <int HD>
+__global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           float* __restrict__ dqkv, int N, int H, float scale) {
+    constexpr int SQ = HD + 1, HH = HD / 2, ND = HD / 32;
+    __shared__ __attribute__((aligned(16))) float smem[2 * KT * SQ + 2 * KT];
+    float* Qs = smem;
+    float* Os = smem + KT * SQ;       // dO tile
+    float* Ls = smem + 2 * KT * SQ;   // lse tile
+    float* Ds = Ls + KT;              // delta tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128 + wave * 32;
+    const int D = H * HD, ld = 3 * D;
+    const float* base = qkv + (size_t)b * N * ld + h * HD;
+    const float* dob = dout + (size_t)b * N * D + h * HD;
+    const int krow = k0 + l31;
+    const bool wave_active = k0 < N, kv = krow < N;
+
+    float kf[HH], vf[HH];
+    load_rowfrag<HD>(kf, base + D + (size_t)krow * ld + hf * HH, kv, scale);
+    load_rowfrag<HD>(vf, base + 2 * D + (size_t)krow * ld + hf * HH, kv, 1.f);
+
+    f32x16 dk[ND], dv[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+
+    const int nqt = (N + KT - 1) / KT;
+    const float* lse_b = lse + ((size_t)b * H + h) * N;
+    const float* del_b = delta + ((size_t)b * H + h) * N;
+    Stage<HD> rq, ro;
+    float r_l = 0.f, r_d = 0.f;
+    stage_load<HD>(rq, base, ld, 0, N, tid);
+    stage_load<HD>(ro, dob, D, 0, N, tid);
+    if (tid < KT) { r_l = tid < N ? lse_b[tid] : 0.f; r_d = tid < N ? del_b[tid] : 0.f; }
+    for (int t = 0; t < nqt; ++t) {
+        __syncthreads();
+        stage_store<HD, SQ>(rq, Qs, tid);
+        stage_store<HD, SQ>(ro, Os, tid);
+        if (tid < KT) { Ls[tid] = r_l; Ds[tid] = r_d; }
+        __syncthreads();
+        if (t + 1 < nqt) {
+            stage_load<HD>(rq, base, ld, (t + 1) * KT, N, tid);
+            stage_load<HD>(ro, dob, D, (t + 1) * KT, N, tid);
+            if (tid < KT) {
+                const int qi = (t + 1) * KT + tid;
+                r_l = qi < N ? lse_b[qi] : 0.f;
+                r_d = qi < N ? del_b[qi] : 0.f;
+            }
+        }
+        if (!wave_active) continue;
+#pragma unroll
+        for (int qt2 = 0; qt2 < 2; ++qt2) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+            const float* qp = Qs + (qt2 * 32 + l31) * SQ + hf * HH;
+            const float* op = Os + (qt2 * 32 + l31) * SQ + hf * HH;
+            // S[q][key]: A = Q (i = q), B = K^T (j = key)
+#pragma unroll
+            for (int st = 0; st < HH; ++st) s = MFMA32(qp[st], kf[st], s);
+#pragma unroll
+            for (int st = 0; st < HH; ++st) dp = MFMA32(op[st], vf[st], dp);
+            const int qb = t * KT + qt2 * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ql = qt2 * 32 + acc_row(e, hf);
+                const bool qvld = (qb + acc_row(e, hf) < N) && kv;
+                const float p = qvld ? expf(s[e] - Ls[ql]) : 0.f;
+                s[e] = p;                        // P[q][key]
+                dp[e] = p * (dp[e] - Ds[ql]);    // dS[q][key]
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ql = qt2 * 32 + acc_row(e, hf);
+                const float* orow = Os + ql * SQ + l31;
+                const float* qrow = Qs + ql * SQ + l31;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    dv[d] = MFMA32(orow[d * 32], s[e], dv[d]);
+                    dk[d] = MFMA32(qrow[d * 32], dp[e], dk[d]);
+                }
+            }
+        }
+    }
+    if (!wave_active || !kv) return;
+    float* kp = dqkv + ((size_t)b * N + krow) * ld + D + h * HD;
+    float* vp = kp + D;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 a, c;
+            a.x = dk[d][4 * g + 0] * scale; a.y = dk[d][4 * g + 1] * scale;
+            a.z = dk[d][4 * g + 2] * scale; a.w = dk[d][4 * g + 3] * scale;
+            c.x = dv[d][4 * g + 0]; c.y = dv[d][4 * g + 1]; c.z = dv[d][4 * g + 2]; c.w = dv[d][4 * g + 3];
+            *reinterpret_cast<float4*>(kp + d * 32 + 8 * g + 4 * hf) = a;
+            *reinterpret_cast<float4*>(vp + d * 32 + 8 * g + 4 * hf) = c;
+        }
+}
+
+}  // namespace
+
+extern "C" int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd,
+                                  float scale, dupl_stream_t s) {
+    if (!qkv || !out || B <= 0 || N <= 0 || H <= 0 || (hd != 32 && hd != 64)) return DUPL_ERR_ARG;
+    dim3 grid((N + 127) / 128, H, B), block(ANT);
+    if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale);
+    else hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta,
+                                  float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, float scale, dupl_stream_t s) {
+    if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || N <= 0 || H <= 0 || (hd != 32 && hd != 64))
+        return DUPL_ERR_ARG;
+    const long total = (long)B * N * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, out, dout,
+                       delta, B, N, H, hd);
+    dim3 grid((N + 127) / 128, H, B), block(ANT);
+    if (hd == 64) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale);
+    }
+    return dupl_launch_status();
+}

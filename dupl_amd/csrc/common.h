@@ -1,0 +1,79 @@
+// Shared device helpers for the DuPL gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DUPL_OK 0
+#define DUPL_ERR_ARG (-1)
+#define DUPL_ERR_LAUNCH (-2)
+
+#define DUPL_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int dupl_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DUPL_OK : DUPL_ERR_LAUNCH;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide reductions for <= 1024 threads (16 waves).  `red` is a 16-float LDS scratch.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float r = (l < nw) ? red[l] : 0.f;
+    r = wave_sum(r);
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float r = (l < nw) ? red[l] : -INFINITY;
+    r = wave_max(r);
+    return r;
+}
+
+// exact-erf GELU (vit.py:88,93 nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// float atomic max via CAS-free integer trick (valid for any finite floats)
+__device__ __forceinline__ void atomic_max_f(float* addr, float v) {
+    if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+    else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_min_f(float* addr, float v) {
+    if (v >= 0.f) atomicMin((int*)addr, __float_as_int(v));
+    else atomicMax((unsigned int*)addr, __float_as_uint(v));
+}

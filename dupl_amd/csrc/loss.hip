@@ -1,0 +1,383 @@
+// Loss kernels: PTC masked reductions, fused upsample + balanced cross-entropy, cosine discrepancy,
+// multilabel soft margin, row L2 normalisation.  All HBM/L2-bound; block reductions -> one atomic.
+#include "common.h"
+#include "../../include/dupl_hip.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------- PTC
+// cos (b,hw,hw) signed cosine matrix; label (b,hw) int64.  The reference's (b,hw,hw) int64 affinity mask
+// (cam_helper.py:323-335) is evaluated on the fly: pos = same label, neg = different, ignored if either is
+// `ignore` or i == j.  sums = {sum_pos |cos|, n_pos, sum_neg |cos|, n_neg}.
+// kind of pair (r,c): 1 positive, 0 negative, -1 ignored.  Either from labels or from an explicit int64 mask
+// (the reference API: get_masked_ptc_loss(inputs, mask), values 1 / 0 / anything else).
+__device__ __forceinline__ int ptc_pair(const long long* lb, const long long* mk, long i, int hw, int ignore) {
+    if (mk) { const long long m = mk[i]; return m == 1 ? 1 : (m == 0 ? 0 : -1); }
+    const int r = (int)(i / hw), c = (int)(i - (long)r * hw);
+    const long long lr = lb[r], lc = lb[c];
+    if (r == c || lr == ignore || lc == ignore) return -1;
+    return lr == lc ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void ptc_reduce_kernel(const float* __restrict__ cosm, const long long* __restrict__ label,
+                                                         const long long* __restrict__ mask, int ignore,
+                                                         float* __restrict__ sums, int hw) {
+    __shared__ float red[16];
+    const int b = blockIdx.y;
+    const long long* lb = label ? label + (long)b * hw : nullptr;
+    const long long* mk = mask ? mask + (long)b * hw * hw : nullptr;
+    const float* cb = cosm + (long)b * hw * hw;
+    float sp = 0.f, np = 0.f, sn = 0.f, nn = 0.f;
+    const long total = (long)hw * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kind = ptc_pair(lb, mk, i, hw, ignore);
+        if (kind < 0) continue;
+        const float v = fabsf(cb[i]);
+        if (kind == 1) { sp += v; np += 1.f; } else { sn += v; nn += 1.f; }
+    }
+    sp = block_sum(sp, red); np = block_sum(np, red); sn = block_sum(sn, red); nn = block_sum(nn, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], sp); atomicAdd(&sums[1], np); atomicAdd(&sums[2], sn); atomicAdd(&sums[3], nn);
+    }
+}
+
+// in place: cos_signed -> d loss / d cos_signed  (g = upstream scalar gradient gscale[0])
+__global__ __launch_bounds__(256) void ptc_bwd_mask_kernel(float* __restrict__ cosm, const long long* __restrict__ label,
+                                                           const long long* __restrict__ mask, int ignore,
+                                                           const float* __restrict__ sums,
+                                                           const float* __restrict__ gscale, int hw) {
+    const int b = blockIdx.y;
+    const long long* lb = label ? label + (long)b * hw : nullptr;
+    const long long* mk = mask ? mask + (long)b * hw * hw : nullptr;
+    float* cb = cosm + (long)b * hw * hw;
+    const float g = gscale[0];
+    const float cp = -0.5f * g / (sums[1] + 1.f), cn = 0.5f * g / (sums[3] + 1.f);
+    const long total = (long)hw * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kind = ptc_pair(lb, mk, i, hw, ignore);
+        float o = 0.f;
+        if (kind >= 0) {
+            const float v = cb[i];
+            const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+            o = sg * (kind == 1 ? cp : cn);
+        }
+        cb[i] = o;
+    }
+}
+
+// F.normalize(x, p=2, dim=channel, eps): one wave per token row
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ xh,
+                                                         float* __restrict__ norm, long rows, int c, long ldx, int rows_per_img,
+                                                         long img_stride, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long img = row / rows_per_img, r = row - img * rows_per_img;
+    const float* xr = x + img * img_stride + r * ldx;
+    float s = 0.f;
+    for (int i = lane; i < c; i += 64) { const float v = xr[i]; s += v * v; }
+    const float nrm = sqrtf(wave_sum(s));
+    const float den = fmaxf(nrm, eps);
+    for (int i = lane; i < c; i += 64) xh[row * c + i] = xr[i] / den;
+    if (lane == 0) norm[row] = nrm;
+}
+
+// dx (+)= (dxh - xh * <xh, dxh>) / max(norm, eps)   (zero where norm <= eps: clamp has zero slope there)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dxh, const float* __restrict__ xh,
+                                                         const float* __restrict__ norm, float* __restrict__ dx, long rows, int c,
+                                                         long ldx, int rows_per_img, long img_stride, float eps, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long img = row / rows_per_img, r = row - img * rows_per_img;
+    float* dr = dx + img * img_stride + r * ldx;
+    float s = 0.f;
+    for (int i = lane; i < c; i += 64) s += xh[row * c + i] * dxh[row * c + i];
+    s = wave_sum(s);
+    const float nrm = norm[row];
+    const float inv = 1.f / fmaxf(nrm, eps);
+    const float proj = nrm > eps ? s : 0.f;
+    for (int i = lane; i < c; i += 64) {
+        const float v = (dxh[row * c + i] - xh[row * c + i] * proj) * inv;
+        dr[i] = accumulate ? dr[i] + v : v;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- seg loss
+// logits token-major [b][h*w][C1]; output pixel (Y,X) of the bilinear (align_corners False) upsample to HxW.
+// One thread per output pixel; a 16x16 pixel block offset by 8 touches a 2x2 group of low-res cells.
+template <bool BWD>
+__global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__ logits, const void* __restrict__ label,
+                                                       int is_i64, int ignore, float* __restrict__ sums,
+                                                       const float* __restrict__ gscale, float* __restrict__ dlogits, int C1,
+                                                       int h, int w, int H, int W) {
+    __shared__ float red[16];
+    const int b = blockIdx.z;
+    const int fy = H / h, fx = W / w;  // integer factors (16)
+    // tile origin shifted by half a cell so that a tile maps onto exactly 2x2 low-res cells
+    const int Y = (int)blockIdx.y * 16 - fy / 2 + (threadIdx.x >> 4);
+    const int X = (int)blockIdx.x * 16 - fx / 2 + (threadIdx.x & 15);
+    const bool inb = Y >= 0 && Y < H && X >= 0 && X < W;
+    float ce_bg = 0.f, n_bg = 0.f, ce_fg = 0.f, n_fg = 0.f;
+    int y0 = 0, y1 = 0, x0 = 0, x1 = 0;
+    float ly = 0.f, lx = 0.f;
+    long lab = ignore;
+    if (inb) {
+        const float ry = fmaxf(((float)h / (float)H) * (Y + 0.5f) - 0.5f, 0.f);
+        const float rx = fmaxf(((float)w / (float)W) * (X + 0.5f) - 0.5f, 0.f);
+        y0 = (int)ry; x0 = (int)rx;
+        y1 = y0 + (y0 < h - 1 ? 1 : 0); x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        ly = ry - y0; lx = rx - x0;
+        const long li = ((long)b * H + Y) * W + X;
+        lab = is_i64 ? (long)reinterpret_cast<const long long*>(label)[li] : (long)reinterpret_cast<const float*>(label)[li];
+    }
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* L = logits + (long)b * h * w * C1;
+    const float* p00 = L + (long)(y0 * w + x0) * C1;
+    const float* p01 = L + (long)(y0 * w + x1) * C1;
+    const float* p10 = L + (long)(y1 * w + x0) * C1;
+    const float* p11 = L + (long)(y1 * w + x1) * C1;
+    const bool active = inb && lab != ignore;
+    float mx = -INFINITY, se = 0.f, zl = 0.f;
+    if (active) {
+        for (int c = 0; c < C1; ++c) {
+            const float z = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+            if (c == lab) zl = z;
+            if (z > mx) { se = se * expf(mx - z) + 1.f; mx = z; } else se += expf(z - mx);
+        }
+        const float ce = (mx + logf(se)) - zl;
+        if (lab == 0) { ce_bg = ce; n_bg = 1.f; } else { ce_fg = ce; n_fg = 1.f; }
+    }
+    if (!BWD) {
+        ce_bg = block_sum(ce_bg, red); n_bg = block_sum(n_bg, red); ce_fg = block_sum(ce_fg, red); n_fg = block_sum(n_fg, red);
+        if (threadIdx.x == 0 && (n_bg + n_fg) > 0.f) {
+            atomicAdd(&sums[0], ce_bg); atomicAdd(&sums[1], n_bg); atomicAdd(&sums[2], ce_fg); atomicAdd(&sums[3], n_fg);
+        }
+    } else {
+        // d loss/d z_c = coef * (softmax_c - [c==lab]); scatter to the 4 low-res cells.  All lanes of a wave (4 rows x 16
+        // px of the shifted tile) share the same 2x2 cells, so reduce over the wave first: 4*C1 atomics per wave.
+        const float g = gscale[0];
+        float coef = 0.f;
+        if (active) coef = lab == 0 ? 0.5f * g / (sums[1] + 1e-6f) : 0.5f * g / (sums[3] + 1e-6f);
+        float* Dl = dlogits + (long)b * h * w * C1;
+        if ((fy & 15) || (fx & 15)) {
+            // generic factors: cells are not wave-uniform -> per-lane atomics (compat path, e.g. full-res logits)
+            if (!active) return;
+            const float lse_ = mx + logf(se);
+            for (int c = 0; c < C1; ++c) {
+                const float z = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+                const float gz = coef * (expf(z - lse_) - (c == lab ? 1.f : 0.f));
+                atomicAdd(&Dl[(long)(y0 * w + x0) * C1 + c], gz * hy * hx);
+                if (x1 != x0) atomicAdd(&Dl[(long)(y0 * w + x1) * C1 + c], gz * hy * lx);
+                if (y1 != y0) atomicAdd(&Dl[(long)(y1 * w + x0) * C1 + c], gz * ly * hx);
+                if (y1 != y0 && x1 != x0) atomicAdd(&Dl[(long)(y1 * w + x1) * C1 + c], gz * ly * lx);
+            }
+            return;
+        }
+        const int lane = threadIdx.x & 63;
+        // wave-uniform cell ids: take them from any in-bounds lane (all in-bounds lanes agree); lanes out of bounds add 0
+        const unsigned long long m = __ballot(inb);
+        if (m == 0ull) return;
+        const int src = __ffsll((long long)m) - 1;
+        const int cy0 = __shfl(y0, src, 64), cy1 = __shfl(y1, src, 64), cx0 = __shfl(x0, src, 64), cx1 = __shfl(x1, src, 64);
+        // a lane whose own (y0,x0) differs from the wave's reference cell can only happen at the clamped borders, where
+        // y0==y1 or x0==x1 collapse; handle generally by re-deriving weights relative to the reference cells:
+        float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+        if (active) {
+            const float wy0 = (y0 == cy0 ? hy : 0.f) + (y1 == cy0 ? ly : 0.f);
+            const float wy1 = (cy1 != cy0) ? ((y0 == cy1 ? hy : 0.f) + (y1 == cy1 ? ly : 0.f)) : 0.f;
+            const float wx0 = (x0 == cx0 ? hx : 0.f) + (x1 == cx0 ? lx : 0.f);
+            const float wx1 = (cx1 != cx0) ? ((x0 == cx1 ? hx : 0.f) + (x1 == cx1 ? lx : 0.f)) : 0.f;
+            w00 = wy0 * wx0; w01 = wy0 * wx1; w10 = wy1 * wx0; w11 = wy1 * wx1;
+        }
+        float* D = dlogits + (long)b * h * w * C1;
+        const float lse = mx + logf(se);
+        for (int c = 0; c < C1; ++c) {
+            float gz = 0.f;
+            if (active) {
+                const float z = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+                gz = coef * (expf(z - lse) - (c == lab ? 1.f : 0.f));
+            }
+            const float a00 = wave_sum(gz * w00), a01 = wave_sum(gz * w01), a10 = wave_sum(gz * w10), a11 = wave_sum(gz * w11);
+            if (lane == 0) {
+                atomicAdd(&D[(long)(cy0 * w + cx0) * C1 + c], a00);
+                if (cx1 != cx0) atomicAdd(&D[(long)(cy0 * w + cx1) * C1 + c], a01);
+                if (cy1 != cy0) atomicAdd(&D[(long)(cy1 * w + cx0) * C1 + c], a10);
+                if (cy1 != cy0 && cx1 != cx0) atomicAdd(&D[(long)(cy1 * w + cx1) * C1 + c], a11);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- cosine
+// a, b token-major [B][n][c] (row stride ld, image stride ims); reduction over the n tokens per (image, channel)
+__global__ __launch_bounds__(256) void cos_sim_fwd_kernel(const float* __restrict__ a, const float* __restrict__ bb,
+                                                          float* __restrict__ out, float* __restrict__ stats, int n, int c,
+                                                          long ld, long ims, float eps) {
+    __shared__ float r0[4][64], r1[4][64], r2[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl, img = blockIdx.y;
+    float d = 0.f, aa = 0.f, b2 = 0.f;
+    if (col < c) {
+        const float* pa = a + img * ims + col;
+        const float* pb = bb + img * ims + col;
+        for (int i = rg; i < n; i += 4) {
+            const float x = pa[(long)i * ld], y = pb[(long)i * ld];
+            d += x * y; aa += x * x; b2 += y * y;
+        }
+    }
+    r0[rg][cl] = d; r1[rg][cl] = aa; r2[rg][cl] = b2;
+    __syncthreads();
+    if (rg == 0 && col < c) {
+        d = (r0[0][cl] + r0[1][cl]) + (r0[2][cl] + r0[3][cl]);
+        aa = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
+        b2 = (r2[0][cl] + r2[1][cl]) + (r2[2][cl] + r2[3][cl]);
+        const float na = fmaxf(sqrtf(aa), eps), nb = fmaxf(sqrtf(b2), eps);
+        out[(long)img * c + col] = d / (na * nb);
+        float* st = stats + ((long)img * c + col) * 3;
+        st[0] = d; st[1] = aa; st[2] = b2;
+    }
+}
+
+// gradient wrt `bb` only: d cos / d b_i = a_i/(na*nb) - cos * b_i / nb^2  (norms above eps)
+__global__ void cos_sim_bwd_kernel(const float* __restrict__ a, const float* __restrict__ bb, const float* __restrict__ stats,
+                                   const float* __restrict__ g, float gmul, float* __restrict__ db, int B, int n, int c, long ld,
+                                   long ims, float eps, int accumulate) {
+    const long total = (long)B * n * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % c);
+        const long r = i / c;
+        const int t = (int)(r % n), img = (int)(r / n);
+        const float* st = stats + ((long)img * c + col) * 3;
+        const float na = fmaxf(sqrtf(st[1]), eps), nb = fmaxf(sqrtf(st[2]), eps);
+        const float cs = st[0] / (na * nb);
+        const long off = img * ims + (long)t * ld + col;
+        const float gv = g[0] * gmul;
+        const float v = gv * (a[off] / (na * nb) - cs * bb[off] / (nb * nb));
+        db[off] = accumulate ? db[off] + v : v;
+    }
+}
+
+// mean over (b*c) of out: loss[0] += mean
+__global__ __launch_bounds__(256) void mean_accum_kernel(const float* __restrict__ x, float* __restrict__ loss, long n, float mul) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) loss[0] += s * mul;
+}
+
+// F.multilabel_soft_margin_loss: mean_b mean_c -(y*logsig(x) + (1-y)*logsig(-x))
+__global__ __launch_bounds__(256) void msm_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ loss,
+                                                  float* __restrict__ dx, const float* __restrict__ gscale, int b, int C) {
+    __shared__ float red[16];
+    const int n = b * C;
+    float s = 0.f;
+    const float g = (dx && gscale) ? gscale[0] : 1.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = x[i], t = y[i];
+        const float sp = log1pf(expf(-fabsf(v)));          // softplus(-|v|)
+        const float ls_pos = fminf(v, 0.f) - sp;            // logsigmoid(v)
+        const float ls_neg = fminf(-v, 0.f) - sp;           // logsigmoid(-v)
+        s += -(t * ls_pos + (1.f - t) * ls_neg);
+        if (dx) {
+            const float sig = 1.f / (1.f + expf(-v));
+            dx[i] = g * (sig - t) / (float)n;
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0 && loss) loss[0] += s / (float)n;
+}
+
+inline int ew_grid(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int dupl_ptc_reduce(const float* cosm, const int64_t* label, const int64_t* mask, int32_t ignore_index, float* sums,
+                               int32_t b, int32_t hw, dupl_stream_t s) {
+    if (!cosm || (!label && !mask) || !sums || b <= 0 || hw <= 0) return DUPL_ERR_ARG;
+    int gx = (int)(((long)hw * hw + 1023) / 1024);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(ptc_reduce_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)s, cosm, (const long long*)label,
+                       (const long long*)mask, ignore_index, sums, hw);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_ptc_bwd_mask(float* cos_signed, const int64_t* label, const int64_t* mask, int32_t ignore_index,
+                                 const float* sums, const float* gscale, int32_t b, int32_t hw, dupl_stream_t s) {
+    if (!cos_signed || (!label && !mask) || !sums || !gscale || b <= 0 || hw <= 0) return DUPL_ERR_ARG;
+    int gx = (int)(((long)hw * hw + 1023) / 1024);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(ptc_bwd_mask_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)s, cos_signed, (const long long*)label,
+                       (const long long*)mask, ignore_index, sums, gscale, hw);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_l2norm_rows_fwd(const float* x, float* xhat, float* norm, int64_t rows, int32_t c, int64_t ldx,
+                                    int32_t rows_per_img, int64_t img_stride, float eps, dupl_stream_t s) {
+    if (!x || !xhat || !norm || rows <= 0 || c <= 0 || rows_per_img <= 0) return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, x, xhat, norm, (long)rows,
+                       c, (long)ldx, rows_per_img, (long)img_stride, eps);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const float* norm, float* dx, int64_t rows, int32_t c,
+                                    int64_t ldx, int32_t rows_per_img, int64_t img_stride, float eps, int32_t accumulate,
+                                    dupl_stream_t s) {
+    if (!dxhat || !xhat || !norm || !dx || rows <= 0 || c <= 0 || rows_per_img <= 0) return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, dxhat, xhat, norm, dx,
+                       (long)rows, c, (long)ldx, rows_per_img, (long)img_stride, eps, accumulate);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_seg_loss_fwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* sums,
+                                 int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, dupl_stream_t s) {
+    if (!logits || !label || !sums || b <= 0 || C1 <= 0 || h <= 0 || w <= 0 || H % h || W % w) return DUPL_ERR_ARG;
+    dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
+    hipLaunchKernelGGL(seg_loss_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index, sums,
+                       (const float*)nullptr, (float*)nullptr, C1, h, w, H, W);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, const float* sums,
+                                 const float* gscale, float* dlogits, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H,
+                                 int32_t W, dupl_stream_t s) {
+    if (!logits || !label || !sums || !gscale || !dlogits || b <= 0 || C1 <= 0 || H % h || W % w) return DUPL_ERR_ARG;
+    dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
+    hipLaunchKernelGGL(seg_loss_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index,
+                       const_cast<float*>(sums), gscale, dlogits, C1, h, w, H, W);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_cos_sim_fwd(const float* a, const float* b, float* out, float* stats, int32_t B, int32_t n, int32_t c,
+                                int64_t ld, int64_t img_stride, float eps, dupl_stream_t s) {
+    if (!a || !b || !out || !stats || B <= 0 || n <= 0 || c <= 0) return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(cos_sim_fwd_kernel, dim3((c + 63) / 64, B), dim3(256), 0, (hipStream_t)s, a, b, out, stats, n, c, (long)ld,
+                       (long)img_stride, eps);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_cos_sim_bwd(const float* a, const float* b, const float* stats, const float* g, float gmul, float* db,
+                                int32_t B, int32_t n, int32_t c, int64_t ld, int64_t img_stride, float eps, int32_t accumulate,
+                                dupl_stream_t s) {
+    if (!a || !b || !stats || !g || !db || B <= 0 || n <= 0 || c <= 0) return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(cos_sim_bwd_kernel, dim3(ew_grid((long)B * n * c)), dim3(256), 0, (hipStream_t)s, a, b, stats, g, gmul, db,
+                       B, n, c, (long)ld, (long)img_stride, eps, accumulate);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_mean_accum(const float* x, float* loss, int64_t n, float mul, dupl_stream_t s) {
+    if (!x || !loss || n <= 0) return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(mean_accum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, x, loss, (long)n, mul);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_multilabel_soft_margin(const float* logits, const float* target, float* loss, float* dlogits,
+                                           const float* gscale, int32_t b, int32_t C, dupl_stream_t s) {
+    if (!logits || !target || b <= 0 || C <= 0) return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(msm_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, logits, target, loss, dlogits, gscale, b, C);
+    return dupl_launch_status();
+}

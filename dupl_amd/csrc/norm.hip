@@ -1,0 +1,239 @@
+// LayerNorm forward / backward and column sums.  HBM-bound: one wavefront per row, the row lives in
+// registers (float4 per lane, coalesced 1 KiB per wave-instruction), reductions are wave shuffles.
+#include "common.h"
+#include "../../include/dupl_hip.h"
+
+namespace {
+
+constexpr int LN_MAXC_LIMIT = 8;  // float4 chunks per lane -> D <= 2048
+
+template <int LN_MAXC>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                            long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+    float4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nch) { v[i] = xr[c]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4* yr = reinterpret_cast<float4*>(y + row * D);
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float4 g = g4[c], b = b4[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            yr[c] = o;
+        }
+    }
+    if (lane == 0) {
+        if (mean_o) mean_o[row] = mean;
+        if (rstd_o) rstd_o[row] = rstd;
+    }
+}
+
+// Backward: each wave walks ROWS_PER_WAVE rows, keeps per-lane partial dgamma/dbeta in registers and
+// issues one atomicAdd per column per block at the end (via LDS reduction across the 4 waves).
+constexpr int LNB_ROWS = 16;  // rows per wave
+
+template <int LN_MAXC>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, long rows, int D) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = D >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    float4 gam[LN_MAXC], dg[LN_MAXC], db[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        gam[i] = c < nch ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int t = threadIdx.x; t < 2 * D; t += blockDim.x) lds[t] = 0.f;
+    __syncthreads();
+    const long row0 = ((long)blockIdx.x * 4 + wave) * LNB_ROWS;
+    for (int rr = 0; rr < LNB_ROWS; ++rr) {
+        const long row = row0 + rr;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+        const float4* dyr = reinterpret_cast<const float4*>(dy + row * D);
+        float4 xh[LN_MAXC], g[LN_MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const float4 xv = xr[c], dv = dyr[c];
+                xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+                g[i].x = dv.x * gam[i].x; g[i].y = dv.y * gam[i].y; g[i].z = dv.z * gam[i].z; g[i].w = dv.w * gam[i].w;
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                dg[i].x += dv.x * xh[i].x; dg[i].y += dv.y * xh[i].y; dg[i].z += dv.z * xh[i].z; dg[i].w += dv.w * xh[i].w;
+                db[i].x += dv.x; db[i].y += dv.y; db[i].z += dv.z; db[i].w += dv.w;
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+        float4* dxr = reinterpret_cast<float4*>(dx + row * D);
+        const float4* drr = dres ? reinterpret_cast<const float4*>(dres + row * D) : nullptr;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float4 o;
+                o.x = rs * (g[i].x - m1 - xh[i].x * m2);
+                o.y = rs * (g[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (g[i].z - m1 - xh[i].z * m2);
+                o.w = rs * (g[i].w - m1 - xh[i].w * m2);
+                if (drr) { const float4 d = drr[c]; o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
+                dxr[c] = o;
+            }
+        }
+    }
+    // block reduce of dgamma / dbeta through LDS atomics, then one global atomic per column
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            atomicAdd(&lds[4 * c + 0], dg[i].x); atomicAdd(&lds[4 * c + 1], dg[i].y);
+            atomicAdd(&lds[4 * c + 2], dg[i].z); atomicAdd(&lds[4 * c + 3], dg[i].w);
+            atomicAdd(&lds[D + 4 * c + 0], db[i].x); atomicAdd(&lds[D + 4 * c + 1], db[i].y);
+            atomicAdd(&lds[D + 4 * c + 2], db[i].z); atomicAdd(&lds[D + 4 * c + 3], db[i].w);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < D; t += blockDim.x) {
+        if (dgamma) atomicAdd(&dgamma[t], lds[t]);
+        if (dbeta) atomicAdd(&dbeta[t], lds[D + t]);
+    }
+}
+
+// out[n] (+)= sum_m x[m][n]: block = 256 threads covers 64 columns x 4 row-groups; rows strided by gridDim.y*4
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long M, int N,
+                                                     int ldx) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (col < N) {
+        for (long m = (long)blockIdx.y * 4 + rg; m < M; m += (long)gridDim.y * 4) s += x[m * ldx + col];
+    }
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < N) atomicAdd(&out[col], (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+}
+
+__global__ void fill_kernel(float* p, float v, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long st = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += st) p[i] = v;
+}
+__global__ void axpy_kernel(float* y, const float* x, float a, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long st = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += st) y[i] += a * x[i];
+}
+__global__ void scale_kernel(float* y, float a, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long st = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += st) y[i] *= a;
+}
+
+inline int ew_grid(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int dupl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                  float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s) {
+    if (!x || !gamma || !beta || !y || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256) return DUPL_ERR_ARG;
+    const int grid = (int)((rows + 3) / 4);
+#define LN_FWD(MC) hipLaunchKernelGGL(layernorm_fwd_kernel<MC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, gamma, beta, y, \
+                                      mean, rstd, (long)rows, D, eps)
+    if (D <= 256) LN_FWD(1);
+    else if (D <= 768) LN_FWD(3);
+    else if (D <= 1024) LN_FWD(4);
+    else LN_FWD(8);
+#undef LN_FWD
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                  const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                                  int64_t rows, int32_t D, dupl_stream_t s) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256)
+        return DUPL_ERR_ARG;
+    const int grid = (int)((rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS));
+#define LN_BWD(MC) hipLaunchKernelGGL(layernorm_bwd_kernel<MC>, dim3(grid), dim3(256), 2 * D * sizeof(float), (hipStream_t)s, \
+                                      dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, D)
+    if (D <= 256) LN_BWD(1);
+    else if (D <= 768) LN_BWD(3);
+    else if (D <= 1024) LN_BWD(4);
+    else LN_BWD(8);
+#undef LN_BWD
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int32_t ldx, int32_t accumulate,
+                           dupl_stream_t s) {
+    if (!x || !out || M <= 0 || N <= 0) return DUPL_ERR_ARG;
+    if (!accumulate) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, out, 0.f, (long)N);
+    long gy = (M + 255) / 256;
+    if (gy > 256) gy = 256;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (int)gy), dim3(256), 0, (hipStream_t)s, x, out, (long)M, N, ldx);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_fill(float* p, float v, int64_t n, dupl_stream_t s) {
+    if (!p || n < 0) return DUPL_ERR_ARG;
+    if (n == 0) return DUPL_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, p, v, (long)n);
+    return dupl_launch_status();
+}
+extern "C" int dupl_axpy(float* y, const float* x, float a, int64_t n, dupl_stream_t s) {
+    if (!y || !x || n < 0) return DUPL_ERR_ARG;
+    if (n == 0) return DUPL_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, y, x, a, (long)n);
+    return dupl_launch_status();
+}
+extern "C" int dupl_scale(float* y, float a, int64_t n, dupl_stream_t s) {
+    if (!y || n < 0) return DUPL_ERR_ARG;
+    if (n == 0) return DUPL_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, y, a, (long)n);
+    return dupl_launch_status();
+}

@@ -1,0 +1,397 @@
+"""Per-student forward / backward engine: the ViT-B/16 encoder, the CAM / classifier heads and the
+LargeFOV decoder, expressed as explicit sequences of libdupl_hip.so kernel launches.
+
+Python owns memory (torch tensors, flat parameter / gradient storage) and launch order; every dense
+op is a HIP kernel.  The backward pass is hand-scheduled (no autograd inside): it consumes the
+activations the forward saved and ACCUMULATES parameter gradients straight into the flat gradient
+buffer, which is what the optimiser and the gradient all-reduce operate on.
+
+Reference behaviour mirrored (paths relative to the reference):
+  forward_features  model/backbone/vit.py:289-326      Block  vit.py:156-160
+  Attention         vit.py:120-138                      Mlp    vit.py:97-103
+  network.forward   model/model_dupl.py:69-106          LargeFOV model/decoder/conv_head.py:32-41
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+@dataclass(frozen=True)
+class EncoderConfig:
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    mlp_ratio: int = 4
+    patch: int = 16
+    img_size: int = 224
+    aux_layer: int = -3
+    ln_eps: float = 1e-6
+    head_classes: int = 1000
+    decoder_dim: int = 512
+    decoder_dilation: int = 5
+
+    @property
+    def grid(self) -> int:
+        return self.img_size // self.patch
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+
+# ------------------------------------------------------------------------------------------------
+# flat parameter storage
+# ------------------------------------------------------------------------------------------------
+def student_param_shapes(cfg: EncoderConfig, num_classes: int) -> Dict[str, Tuple[int, ...]]:
+    """state_dict keys / shapes of one `network` in the reference's own order."""
+    D, Hd = cfg.embed_dim, cfg.embed_dim * cfg.mlp_ratio
+    s: Dict[str, Tuple[int, ...]] = {}
+    s["encoder.cls_token"] = (1, 1, D)
+    s["encoder.pos_embed"] = (1, cfg.grid * cfg.grid + 1, D)
+    s["encoder.patch_embed.proj.weight"] = (D, 3, cfg.patch, cfg.patch)
+    s["encoder.patch_embed.proj.bias"] = (D,)
+    for i in range(cfg.depth):
+        p = f"encoder.blocks.{i}."
+        s[p + "norm1.weight"] = (D,)
+        s[p + "norm1.bias"] = (D,)
+        s[p + "attn.qkv.weight"] = (3 * D, D)
+        s[p + "attn.qkv.bias"] = (3 * D,)
+        s[p + "attn.proj.weight"] = (D, D)
+        s[p + "attn.proj.bias"] = (D,)
+        s[p + "norm2.weight"] = (D,)
+        s[p + "norm2.bias"] = (D,)
+        s[p + "mlp.fc1.weight"] = (Hd, D)
+        s[p + "mlp.fc1.bias"] = (Hd,)
+        s[p + "mlp.fc2.weight"] = (D, Hd)
+        s[p + "mlp.fc2.bias"] = (D,)
+    s["encoder.norm.weight"] = (D,)
+    s["encoder.norm.bias"] = (D,)
+    s["encoder.head.weight"] = (cfg.head_classes, D)
+    s["encoder.head.bias"] = (cfg.head_classes,)
+    s["decoder.conv6.weight"] = (cfg.decoder_dim, D, 3, 3)
+    s["decoder.conv7.weight"] = (cfg.decoder_dim, cfg.decoder_dim, 3, 3)
+    s["decoder.conv8.weight"] = (num_classes, cfg.decoder_dim, 1, 1)
+    s["classifier.weight"] = (num_classes - 1, D, 1, 1)
+    s["aux_classifier.weight"] = (num_classes - 1, D, 1, 1)
+    return s
+
+
+# segment ids: 0 = never receives a gradient (pos_embed frozen vit.py:243; `head` unused by forward_features),
+# 1..4 = optimiser groups 0..3 of siamese_network.get_param_groups (model_dupl.py:119-154)
+SEG_FROZEN, SEG_BACKBONE, SEG_NORM, SEG_CLS, SEG_DECODER = 0, 1, 2, 3, 4
+
+
+def param_segment(key: str) -> int:
+    if key in ("encoder.pos_embed", "encoder.head.weight", "encoder.head.bias"):
+        return SEG_FROZEN
+    if key.startswith("encoder."):
+        return SEG_NORM if "norm" in key[len("encoder."):] else SEG_BACKBONE
+    if key.startswith("decoder."):
+        return SEG_DECODER
+    return SEG_CLS
+
+
+class FlatStorage:
+    """All parameters of `n_students` students in ONE fp32 buffer (+ a same-shaped gradient buffer):
+        [student 0: frozen | backbone | norm | cls | decoder][student 1: ...]
+    so that the optimiser is 4 fused launches per student, the gradient all-reduce runs over a few large
+    contiguous buckets, and student 2's copy of any tensor sits at a constant offset from student 1's."""
+
+    def __init__(self, cfg: EncoderConfig, num_classes: int, n_students: int, device="cpu"):
+        self.cfg, self.num_classes, self.n_students = cfg, num_classes, n_students
+        shapes = student_param_shapes(cfg, num_classes)
+        self.shapes = shapes
+        self.layout: Dict[str, Tuple[int, int]] = {}     # key -> (offset within a student, numel)
+        self.seg_bounds: List[Tuple[int, int]] = []      # per segment id: (start, end) within a student
+        off = 0
+        for seg in range(5):
+            start = off
+            for k, shp in shapes.items():
+                if param_segment(k) != seg:
+                    continue
+                n = 1
+                for d in shp:
+                    n *= d
+                self.layout[k] = (off, n)
+                off += (n + 3) // 4 * 4   # 16-byte alignment of every tensor
+            self.seg_bounds.append((start, off))
+        self.student_numel = off
+        self.data = torch.zeros(n_students * off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n_students * off, dtype=torch.float32, device=device)
+        # sticky "this segment has received a gradient at least once" flags == torch's `p.grad is None` skip
+        self.seg_has_grad = [[False] * 5 for _ in range(n_students)]
+
+    def view(self, student: int, key: str, grad: bool = False) -> Tensor:
+        off, n = self.layout[key]
+        base = student * self.student_numel + off
+        buf = self.grad if grad else self.data
+        return buf[base:base + n].view(self.shapes[key])
+
+    def apply(self, fn):
+        self.data = fn(self.data)
+        self.grad = fn(self.grad)
+
+    def trainable_range(self, student: int) -> Tuple[int, int]:
+        s = student * self.student_numel
+        return s + self.seg_bounds[SEG_BACKBONE][0], s + self.seg_bounds[SEG_DECODER][1]
+
+
+class StudentParams:
+    """Read-only bundle of one student's parameter / gradient views used by the engine."""
+
+    def __init__(self, store: FlatStorage, student: int):
+        self.store, self.student = store, student
+        self.cfg, self.num_classes = store.cfg, store.num_classes
+        self.w = {k: store.view(student, k) for k in store.layout}
+        self.g = {k: store.view(student, k, grad=True) for k in store.layout}
+        self._pos_cache: Dict[Tuple[int, int], Tensor] = {}
+        self._pos_version = None
+
+    def pos_embed_for(self, h: int, w: int) -> Tensor:
+        """Bicubic-resized pos-embed, cached per resolution: pos_embed is frozen (vit.py:243), so the cache
+        is only invalidated when the parameter tensor is rewritten (load_state_dict bumps _version)."""
+        pe = self.w["encoder.pos_embed"]
+        ver = (pe._version, pe.data_ptr())
+        if ver != self._pos_version:
+            self._pos_cache.clear()
+            self._pos_version = ver
+        key = (h, w)
+        if key not in self._pos_cache:
+            self._pos_cache[key] = ops.pos_embed_resize(pe, self.cfg.grid, h, w)
+        return self._pos_cache[key]
+
+    def mark_grad(self, seg: int):
+        self.store.seg_has_grad[self.student][seg] = True
+
+
+# ------------------------------------------------------------------------------------------------
+# forward
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class BlockSaved:
+    x_in: Tensor = None
+    mean1: Tensor = None
+    rstd1: Tensor = None
+    ln1: Tensor = None
+    qkv: Tensor = None
+    lse: Tensor = None
+    att: Tensor = None
+    x_mid: Tensor = None
+    mean2: Tensor = None
+    rstd2: Tensor = None
+    ln2: Tensor = None
+    pre1: Tensor = None
+    h1: Tensor = None
+
+
+@dataclass
+class EncoderSaved:
+    B: int = 0
+    h: int = 0
+    w: int = 0
+    x_img: Tensor = None
+    blocks: List[BlockSaved] = field(default_factory=list)
+    x_last: Tensor = None      # input of the final LayerNorm
+    mean_f: Tensor = None
+    rstd_f: Tensor = None
+
+
+def encoder_forward(P: StudentParams, x: Tensor, save: bool):
+    """forward_features (vit.py:308-326).  Returns (tokens_final [B*(1+n), D], tokens_aux [B*(1+n), D], saved).
+    tokens_aux = output of block `aux_layer` (un-normalised unless it is the last block)."""
+    cfg = P.cfg
+    B, _, Himg, Wimg = x.shape
+    h, w = Himg // cfg.patch, Wimg // cfg.patch
+    n, D, H, hd = h * w, cfg.embed_dim, cfg.num_heads, cfg.head_dim
+    N = n + 1
+    W = P.w
+    rows = ops.patch_im2row(x, cfg.patch)
+    patch = ops.linear(rows, W["encoder.patch_embed.proj.weight"], W["encoder.patch_embed.proj.bias"])
+    del rows
+    t = ops.assemble_tokens(patch, W["encoder.cls_token"], P.pos_embed_for(h, w), B, n, D)
+    del patch
+    sv = EncoderSaved(B=B, h=h, w=w, x_img=x if save else None) if save else None
+    aux_idx = cfg.aux_layer % cfg.depth
+    aux = None
+    scale = hd ** -0.5
+    for i in range(cfg.depth):
+        p = f"encoder.blocks.{i}."
+        ln1, m1, r1 = ops.layernorm_fwd(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, save)
+        qkv = ops.linear(ln1, W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"])
+        att, lse = ops.attention_fwd(qkv, B, N, H, hd, scale, need_lse=save)
+        x_mid = ops.linear(att, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], res=t)
+        ln2, m2, r2 = ops.layernorm_fwd(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save)
+        pre1 = torch.empty((t.shape[0], D * cfg.mlp_ratio), device=t.device, dtype=torch.float32) if save else None
+        h1 = ops.linear(ln2, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], gelu=True, store_pre=pre1)
+        x_out = ops.linear(h1, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"], res=x_mid)
+        if save:
+            sv.blocks.append(BlockSaved(x_in=t, mean1=m1, rstd1=r1, ln1=ln1, qkv=qkv, lse=lse, att=att, x_mid=x_mid,
+                                        mean2=m2, rstd2=r2, ln2=ln2, pre1=pre1, h1=h1))
+        t = x_out
+        if i == aux_idx and i != cfg.depth - 1:
+            aux = t
+    tf, mf, rf = ops.layernorm_fwd(t, W["encoder.norm.weight"], W["encoder.norm.bias"], cfg.ln_eps, save)
+    if save:
+        sv.x_last, sv.mean_f, sv.rstd_f = t, mf, rf
+    if aux is None:  # aux_layer == last block -> embeds[-1] is the final LN output (vit.py:323-324)
+        aux = tf
+    return tf, aux, sv
+
+
+def cam_logits(P: StudentParams, x: Tensor):
+    """cam_only path (model_dupl.py:81-84), token-major: returns (cam_aux_tok, cam_tok), each
+    [B*(1+n), C] (row 0 of every image is the cls token and must be skipped), plus (h, w)."""
+    tf, aux, _ = encoder_forward(P, x, save=False)
+    Wc = P.w["classifier.weight"].view(P.num_classes - 1, -1)
+    Wa = P.w["aux_classifier.weight"].view(P.num_classes - 1, -1)
+    cam = ops.linear(tf, Wc)
+    cam_aux = ops.linear(aux, Wa)
+    return cam_aux, cam
+
+
+@dataclass
+class HeadSaved:
+    enc: EncoderSaved = None
+    tf: Tensor = None
+    aux: Tensor = None
+    pooled: Tensor = None
+    pooled_idx: Tensor = None
+    pooled_aux: Tensor = None
+    pooled_aux_idx: Tensor = None
+    col6: Tensor = None
+    h6: Tensor = None
+    col7: Tensor = None
+    h7: Tensor = None
+
+
+def network_forward(P: StudentParams, x: Tensor, save: bool):
+    """network.forward (model_dupl.py:69-106), training / val branch.
+    Returns (cls_x4 (B,C), seg (B,C+1,h,w), x4 (B,D,h,w), cls_aux (B,C)), saved."""
+    cfg = P.cfg
+    tf, aux, enc = encoder_forward(P, x, save)
+    B = x.shape[0]
+    h, w = x.shape[2] // cfg.patch, x.shape[3] // cfg.patch
+    n, D, C = h * w, cfg.embed_dim, P.num_classes - 1
+    Wc = P.w["classifier.weight"].view(C, D)
+    Wa = P.w["aux_classifier.weight"].view(C, D)
+    pooled, pidx = ops.gmp_fwd(tf, B, n, D)
+    pooled_a, paidx = ops.gmp_fwd(aux, B, n, D)
+    cls_x4 = ops.linear(pooled, Wc)
+    cls_aux = ops.linear(pooled_a, Wa)
+    x4 = ops.tokens_to_nchw(tf, B, n, D, h, w, skip_cls=True)
+    # LargeFOV on the patch tokens (token-major, cls row skipped through the image stride)
+    dd, dil = cfg.decoder_dim, cfg.decoder_dilation
+    col6 = torch.empty((B * n, 9 * D), device=x.device, dtype=torch.float32)
+    ops.L().dupl_im2col_dil3(tf.data_ptr() + 4 * D, col6.data_ptr(), B, h, w, D, dil, D, (n + 1) * D, ops._stream())
+    h6 = ops.linear(col6, P.w["decoder.conv6.weight"].view(dd, -1), relu=True)
+    col7 = torch.empty((B * n, 9 * dd), device=x.device, dtype=torch.float32)
+    ops.L().dupl_im2col_dil3(h6.data_ptr(), col7.data_ptr(), B, h, w, dd, dil, dd, n * dd, ops._stream())
+    h7 = ops.linear(col7, P.w["decoder.conv7.weight"].view(dd, -1), relu=True)
+    seg_tok = ops.linear(h7, P.w["decoder.conv8.weight"].view(P.num_classes, dd))
+    seg = ops.tokens_to_nchw(seg_tok, B, n, P.num_classes, h, w, skip_cls=False)
+    sv = None
+    if save:
+        sv = HeadSaved(enc=enc, tf=tf, aux=aux, pooled=pooled, pooled_idx=pidx, pooled_aux=pooled_a, pooled_aux_idx=paidx,
+                       col6=col6, h6=h6, col7=col7, h7=h7)
+    return (cls_x4, seg, x4, cls_aux), sv
+
+
+# ------------------------------------------------------------------------------------------------
+# backward
+# ------------------------------------------------------------------------------------------------
+def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], dseg: Optional[Tensor],
+                     dx4: Optional[Tensor], dcls_aux: Optional[Tensor]):
+    """Adjoint of network_forward; accumulates into P.g[...] (the flat gradient buffer)."""
+    cfg = P.cfg
+    enc = sv.enc
+    B, h, w = enc.B, enc.h, enc.w
+    n, D, C, NC = h * w, cfg.embed_dim, P.num_classes - 1, P.num_classes
+    N = n + 1
+    dev = sv.tf.device
+    G, W = P.g, P.w
+    dtf = ops.zeros((B * N, D), dev)
+    dta = None
+    aux_is_final = sv.aux.data_ptr() == sv.tf.data_ptr()
+    # ---- heads
+    if dx4 is not None:
+        ops.nchw_to_tokens_add(dx4.contiguous(), dtf, B, n, D, skip_cls=True)
+    if dcls is not None:
+        dcls = dcls.contiguous()
+        ops.linear_wgrad(dcls, sv.pooled, G["classifier.weight"], accumulate=True)
+        dpool = ops.linear_dgrad(dcls, W["classifier.weight"].view(C, D))
+        ops.gmp_bwd(dpool, sv.pooled_idx, dtf, B, n, D)
+        P.mark_grad(SEG_CLS)
+    if dcls_aux is not None:
+        dcls_aux = dcls_aux.contiguous()
+        ops.linear_wgrad(dcls_aux, sv.pooled_aux, G["aux_classifier.weight"], accumulate=True)
+        dpool = ops.linear_dgrad(dcls_aux, W["aux_classifier.weight"].view(C, D))
+        if aux_is_final:
+            ops.gmp_bwd(dpool, sv.pooled_aux_idx, dtf, B, n, D)
+        else:
+            dta = ops.zeros((B * N, D), dev)
+            ops.gmp_bwd(dpool, sv.pooled_aux_idx, dta, B, n, D)
+        P.mark_grad(SEG_CLS)
+    # ---- decoder
+    if dseg is not None:
+        dd, dil = cfg.decoder_dim, cfg.decoder_dilation
+        dseg_tok = ops.zeros((B * n, NC), dev)
+        ops.nchw_to_tokens_add(dseg.contiguous(), dseg_tok, B, n, NC, skip_cls=False)
+        ops.linear_wgrad(dseg_tok, sv.h7, G["decoder.conv8.weight"], accumulate=True)
+        dh7 = ops.linear_dgrad(dseg_tok, W["decoder.conv8.weight"].view(NC, dd), relumask_of=sv.h7)
+        ops.linear_wgrad(dh7, sv.col7, G["decoder.conv7.weight"], accumulate=True)
+        dcol7 = ops.linear_dgrad(dh7, W["decoder.conv7.weight"].view(dd, -1))
+        dh6 = torch.empty((B * n, dd), device=dev, dtype=torch.float32)
+        ops.L().dupl_col2im_dil3(dcol7.data_ptr(), dh6.data_ptr(), B, h, w, dd, dil, dd, n * dd, 0, sv.h6.data_ptr(), ops._stream())
+        del dcol7
+        ops.linear_wgrad(dh6, sv.col6, G["decoder.conv6.weight"], accumulate=True)
+        dcol6 = ops.linear_dgrad(dh6, W["decoder.conv6.weight"].view(dd, -1))
+        ops.L().dupl_col2im_dil3(dcol6.data_ptr(), dtf.data_ptr() + 4 * D, B, h, w, D, dil, D, N * D, 1, None, ops._stream())
+        del dcol6
+        P.mark_grad(SEG_DECODER)
+    # ---- final LayerNorm
+    dx = ops.layernorm_bwd(dtf, enc.x_last, W["encoder.norm.weight"], enc.mean_f, enc.rstd_f,
+                           G["encoder.norm.weight"], G["encoder.norm.bias"])
+    aux_idx = cfg.aux_layer % cfg.depth
+    Hh, hd = cfg.num_heads, cfg.head_dim
+    scale = hd ** -0.5
+    for i in reversed(range(cfg.depth)):
+        p = f"encoder.blocks.{i}."
+        s = enc.blocks[i]
+        if dta is not None and i == aux_idx:
+            ops.axpy_(dx, dta, 1.0)
+        # MLP
+        ops.linear_wgrad(dx, s.h1, G[p + "mlp.fc2.weight"], accumulate=True)
+        ops.colsum(dx, G[p + "mlp.fc2.bias"], accumulate=True)
+        dpre1 = ops.linear_dgrad(dx, W[p + "mlp.fc2.weight"], dgelu_of=s.pre1)
+        ops.linear_wgrad(dpre1, s.ln2, G[p + "mlp.fc1.weight"], accumulate=True)
+        ops.colsum(dpre1, G[p + "mlp.fc1.bias"], accumulate=True)
+        dln2 = ops.linear_dgrad(dpre1, W[p + "mlp.fc1.weight"])
+        del dpre1
+        dx_mid = ops.layernorm_bwd(dln2, s.x_mid, W[p + "norm2.weight"], s.mean2, s.rstd2,
+                                   G[p + "norm2.weight"], G[p + "norm2.bias"], dres=dx)
+        # attention
+        ops.linear_wgrad(dx_mid, s.att, G[p + "attn.proj.weight"], accumulate=True)
+        ops.colsum(dx_mid, G[p + "attn.proj.bias"], accumulate=True)
+        datt = ops.linear_dgrad(dx_mid, W[p + "attn.proj.weight"])
+        dqkv = ops.attention_bwd(s.qkv, s.att, datt, s.lse, B, N, Hh, hd, scale)
+        ops.linear_wgrad(dqkv, s.ln1, G[p + "attn.qkv.weight"], accumulate=True)
+        ops.colsum(dqkv, G[p + "attn.qkv.bias"], accumulate=True)
+        dln1 = ops.linear_dgrad(dqkv, W[p + "attn.qkv.weight"])
+        del dqkv, datt
+        dx = ops.layernorm_bwd(dln1, s.x_in, W[p + "norm1.weight"], s.mean1, s.rstd1,
+                               G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid)
+        enc.blocks[i] = None  # release activations as we go
+    # ---- token assembly / patch embed
+    dpatch = ops.assemble_tokens_bwd(dx, G["encoder.cls_token"], B, n, D)
+    rows = ops.patch_im2row(enc.x_img, cfg.patch)
+    ops.linear_wgrad(dpatch, rows, G["encoder.patch_embed.proj.weight"], accumulate=True)
+    ops.colsum(dpatch, G["encoder.patch_embed.proj.bias"], accumulate=True)
+    P.mark_grad(SEG_BACKBONE)
+    P.mark_grad(SEG_NORM)

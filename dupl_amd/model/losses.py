@@ -1,0 +1,167 @@
+"""Losses of the DuPL step (reference: model/losses.py; train_final_voc.py:210-216,247-254) as autograd
+Functions over the HIP kernels.  `get_masked_ptc_loss` / `get_seg_loss` keep the reference signatures;
+the *_from_label / *_lowres variants are the fused forms the training loop uses (no (b,hw,hw) int64
+mask, no (b,C,448,448) up-sampled logits in HBM)."""
+import torch
+
+from .. import ops
+from ..ops import L, _p, _stream
+
+
+def _tokens_from_nchw(x):
+    """(b,c,h,w) -> token-major [b*h*w, c]"""
+    b, c, h, w = x.shape
+    t = ops.zeros((b * h * w, c), x.device)
+    ops.nchw_to_tokens_add(x.contiguous(), t, b, h * w, c, skip_cls=False)
+    return t
+
+
+class _PTC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fmap, label, mask, ignore_index):
+        b, c, h, w = fmap.shape
+        hw = h * w
+        x = _tokens_from_nchw(fmap)
+        xh = torch.empty_like(x)
+        nrm = torch.empty(b * hw, device=x.device, dtype=torch.float32)
+        L().dupl_l2norm_rows_fwd(x.data_ptr(), xh.data_ptr(), nrm.data_ptr(), b * hw, c, c, hw, hw * c, 1e-8, _stream())
+        cos = torch.empty((b, hw, hw), device=x.device, dtype=torch.float32)
+        ops.gemm_raw(xh.data_ptr(), xh.data_ptr(), cos.data_ptr(), hw, hw, c, c, c, hw, batch=b, zdiv=1,
+                     sA=(hw * c, 0), sB=(hw * c, 0), sC=(hw * hw, 0))
+        sums = ops.zeros((4,), x.device)
+        L().dupl_ptc_reduce(cos.data_ptr(), _p(label), _p(mask), ignore_index, sums.data_ptr(), b, hw, _stream())
+        loss = 0.5 * (1 - sums[0] / (sums[1] + 1)) + 0.5 * sums[2] / (sums[3] + 1)
+        ctx.save_for_backward(xh, nrm, cos, sums, label if label is not None else mask)
+        ctx.meta = (b, c, h, w, ignore_index, label is not None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        xh, nrm, cos, sums, lm = ctx.saved_tensors
+        b, c, h, w, ignore_index, is_label = ctx.meta
+        hw = h * w
+        g = g.reshape(1).contiguous().float()
+        dcos = cos.clone()
+        L().dupl_ptc_bwd_mask(dcos.data_ptr(), lm.data_ptr() if is_label else None, None if is_label else lm.data_ptr(),
+                              ignore_index, sums.data_ptr(), g.data_ptr(), b, hw, _stream())
+        # S = Xh Xh^T  ->  dXh = (dS + dS^T) Xh ; two GEMMs keep this correct for a non-symmetric explicit mask
+        dxh = torch.empty_like(xh)
+        ops.gemm_raw(dcos.data_ptr(), xh.data_ptr(), dxh.data_ptr(), hw, c, hw, hw, c, c, flags=ops._lib.GEMM_B_NCONTIG,
+                     batch=b, sA=(hw * hw, 0), sB=(hw * c, 0), sC=(hw * c, 0))
+        ops.gemm_raw(dcos.data_ptr(), xh.data_ptr(), dxh.data_ptr(), hw, c, hw, hw, c, c,
+                     flags=ops._lib.GEMM_A_MCONTIG | ops._lib.GEMM_B_NCONTIG | ops._lib.GEMM_ACCUM,
+                     batch=b, sA=(hw * hw, 0), sB=(hw * c, 0), sC=(hw * c, 0))
+        dx = torch.empty_like(xh)
+        L().dupl_l2norm_rows_bwd(dxh.data_ptr(), xh.data_ptr(), nrm.data_ptr(), dx.data_ptr(), b * hw, c, c, hw, hw * c, 1e-8, 0,
+                                 _stream())
+        dfmap = ops.tokens_to_nchw(dx, b, hw, c, h, w, skip_cls=False)
+        return dfmap, None, None, None
+
+
+def get_masked_ptc_loss(inputs, mask):
+    """losses.py:6-21 with the explicit (b,hw,hw) int64 mask of cam_helper.label_to_aff_mask."""
+    return _PTC.apply(inputs, None, mask.contiguous(), 255)
+
+
+def get_masked_ptc_loss_from_label(inputs, label, ignore_index=255):
+    """Same value as get_masked_ptc_loss(inputs, label_to_aff_mask(label)); the mask is evaluated on the fly."""
+    b = label.shape[0]
+    return _PTC.apply(inputs, label.reshape(b, -1).contiguous().long(), None, ignore_index)
+
+
+class _SegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, label, H, W, ignore_index):
+        b, C1, h, w = seg.shape
+        logits = _tokens_from_nchw(seg)
+        is_i64 = int(label.dtype == torch.int64)
+        if not is_i64:
+            label = label.float()
+        label = label.contiguous()
+        sums = ops.zeros((4,), seg.device)
+        L().dupl_seg_loss_fwd(logits.data_ptr(), label.data_ptr(), is_i64, ignore_index, sums.data_ptr(), b, C1, h, w, H, W,
+                              _stream())
+        loss = 0.5 * (sums[0] / (sums[1] + 1e-6) + sums[2] / (sums[3] + 1e-6))
+        ctx.save_for_backward(logits, label, sums)
+        ctx.meta = (b, C1, h, w, H, W, ignore_index, is_i64)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, label, sums = ctx.saved_tensors
+        b, C1, h, w, H, W, ignore_index, is_i64 = ctx.meta
+        g = g.reshape(1).contiguous().float()
+        dl = ops.zeros(tuple(logits.shape), logits.device)
+        L().dupl_seg_loss_bwd(logits.data_ptr(), label.data_ptr(), is_i64, ignore_index, sums.data_ptr(), g.data_ptr(),
+                              dl.data_ptr(), b, C1, h, w, H, W, _stream())
+        return ops.tokens_to_nchw(dl, b, h * w, C1, h, w, skip_cls=False), None, None, None, None
+
+
+def get_seg_loss_lowres(seg, label, size, ignore_index=255):
+    """get_seg_loss(F.interpolate(seg, size, 'bilinear', align_corners=False), label) fused in one kernel
+    (train_final_voc.py:345-352 + losses.py:24-39)."""
+    return _SegLoss.apply(seg, label, int(size[0]), int(size[1]), ignore_index)
+
+
+def get_seg_loss(pred, label, ignore_index=255):
+    """losses.py:24-39 on already up-sampled logits (reference signature)."""
+    return _SegLoss.apply(pred, label, pred.shape[2], pred.shape[3], ignore_index)
+
+
+class _CosSim(torch.autograd.Function):
+    """mean over (b, channel) of cos(a.detach(), b) along the spatial axis; gradient flows to b only."""
+
+    @staticmethod
+    def forward(ctx, a, bb):
+        B, c, h, w = bb.shape
+        n = h * w
+        ta, tb = _tokens_from_nchw(a), _tokens_from_nchw(bb)
+        out = torch.empty((B, c), device=bb.device, dtype=torch.float32)
+        stats = torch.empty((B, c, 3), device=bb.device, dtype=torch.float32)
+        L().dupl_cos_sim_fwd(ta.data_ptr(), tb.data_ptr(), out.data_ptr(), stats.data_ptr(), B, n, c, c, n * c, 1e-6, _stream())
+        loss = ops.zeros((1,), bb.device)
+        L().dupl_mean_accum(out.data_ptr(), loss.data_ptr(), B * c, 1.0 / (B * c), _stream())
+        ctx.save_for_backward(ta, tb, stats)
+        ctx.meta = (B, c, h, w)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ta, tb, stats = ctx.saved_tensors
+        B, c, h, w = ctx.meta
+        n = h * w
+        g = g.reshape(1).contiguous().float()
+        db = torch.empty_like(tb)
+        L().dupl_cos_sim_bwd(ta.data_ptr(), tb.data_ptr(), stats.data_ptr(), g.data_ptr(), 1.0 / (B * c), db.data_ptr(), B, n, c,
+                             c, n * c, 1e-6, 0, _stream())
+        return None, ops.tokens_to_nchw(db, B, n, c, h, w, skip_cls=False)
+
+
+def sim_loss(fmap_1, fmap_2):
+    """Discrepancy loss (train_final_voc.py:247-254): 2 + mean cos(f1.detach(), f2) + mean cos(f2.detach(), f1)."""
+    return (1 + _CosSim.apply(fmap_1.detach(), fmap_2)) + (1 + _CosSim.apply(fmap_2.detach(), fmap_1))
+
+
+class _MSM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        b, C = logits.shape
+        logits, target = logits.contiguous().float(), target.contiguous().float()
+        loss = ops.zeros((1,), logits.device)
+        L().dupl_multilabel_soft_margin(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), None, None, b, C, _stream())
+        ctx.save_for_backward(logits, target)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        b, C = logits.shape
+        g = g.reshape(1).contiguous().float()
+        d = torch.empty_like(logits)
+        L().dupl_multilabel_soft_margin(logits.data_ptr(), target.data_ptr(), None, d.data_ptr(), g.data_ptr(), b, C, _stream())
+        return d, None
+
+
+def multilabel_soft_margin_loss(logits, target):
+    """F.multilabel_soft_margin_loss (train_final_voc.py:210-216)."""
+    return _MSM.apply(logits, target)

@@ -1,0 +1,292 @@
+"""`network` / `siamese_network` -- the reference's model API (model/model_dupl.py:9-213) on the HIP engine.
+
+Same constructor arguments, forward() modes, attributes read by callers (.encoder.patch_size,
+.encoder.embed_dim, .decoder, .classifier, .aux_classifier), get_param_groups() grouping and
+state_dict keys (157 per student) as the reference, so reference checkpoints load and the
+reference's training loop drives it unchanged.  What differs is underneath:
+
+* all parameters of all students live in ONE flat fp32 buffer (engine.FlatStorage); the nn.Parameters
+  are views into it and their .grad are views into one flat gradient buffer;
+* forward/backward are explicit HIP kernel schedules (engine.network_forward / network_backward);
+  autograd sees one node per student forward, whose backward accumulates parameter gradients
+  directly into the flat gradient buffer (they are not returned through autograd);
+* `cam_with_grad` (model_dupl.py:100-104) is not on the path (no script calls it) and raises.
+* need_sp: the reference first runs both students on the full 2b batch and discards the result
+  (model_dupl.py:191-192); that dead forward is skipped here -- outputs are identical.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import engine, ops
+from ..engine import EncoderConfig, FlatStorage, StudentParams
+from .backbone import encoder_config
+from .decoder.conv_head import LargeFOV
+
+
+class _Holder(nn.Module):
+    """Bare container used to reproduce the reference's state_dict key hierarchy."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter container: compute is scheduled by dupl_amd.engine")
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            setattr(m, p, _Holder())
+        m = getattr(m, p)
+    m.register_parameter(parts[-1], param)
+
+
+class _NetworkFn(torch.autograd.Function):
+    """One autograd node per student forward.  Parameters are NOT autograd inputs: backward writes their
+    gradients into the flat gradient buffer and returns nothing for them."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, net):
+        outs, sv = engine.network_forward(net._P, x, save=True)
+        ctx.net, ctx.sv = net, sv
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dcls, dseg, dx4, dcls_aux):
+        net = ctx.net
+        engine.network_backward(net._P, ctx.sv, dcls, dseg, dx4, dcls_aux)
+        ctx.sv = None
+        for hook in net._post_backward_hooks:
+            hook(net)
+        return None, None, None
+
+
+class network(nn.Module):
+    def __init__(self, backbone, num_classes=None, pretrained=None, aux_layer=None, add_mlp=False,
+                 _store: Optional[FlatStorage] = None, _student: int = 0):
+        super().__init__()
+        if add_mlp:
+            raise NotImplementedError("add_mlp is never enabled on the DuPL training path (model_dupl.py:112,115)")
+        self.num_classes = num_classes
+        self.add_mlp = add_mlp
+        cfg = encoder_config(backbone, aux_layer)
+        self._cfg = cfg
+        self._owns_store = _store is None
+        self._store = FlatStorage(cfg, num_classes, 1) if _store is None else _store
+        self._student = _student
+        self._post_backward_hooks: List[Callable] = []
+        self._anchor = None
+        self._build_modules()
+        if self._owns_store:
+            _reference_init(self._store, 0)
+            self._rebind()
+        self.in_channels = [cfg.embed_dim] * 4
+        if pretrained and not isinstance(pretrained, bool):
+            sd = torch.load(pretrained, map_location="cpu")
+            self.load_state_dict(sd.get("model", sd), strict=False)
+        elif pretrained:
+            raise RuntimeError("pretrained=True needs network access (torch.hub / timm URLs in the reference); pass a "
+                               "local state_dict path or pretrained=False")
+        self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
+
+    # ---- construction -------------------------------------------------------------------------
+    def _build_modules(self):
+        st, s = self._store, self._student
+        enc = _Holder()
+        enc.patch_size = self._cfg.patch
+        enc.embed_dim = enc.num_features = self._cfg.embed_dim
+        enc.aux_layer = self._cfg.aux_layer
+        self.encoder = enc
+        params: Dict[str, nn.Parameter] = {}
+        for key in engine.student_param_shapes(self._cfg, self.num_classes):
+            p = nn.Parameter(st.view(s, key), requires_grad=(key != "encoder.pos_embed"))
+            params[key] = p
+        # encoder.blocks must be an indexable ModuleList-like holder with integer names
+        blocks = nn.ModuleList([_Holder() for _ in range(self._cfg.depth)])
+        enc.blocks = blocks
+        for key, p in params.items():
+            if key.startswith("encoder.blocks."):
+                _, _, idx, rest = key.split(".", 3)
+                _attach(blocks[int(idx)], rest, p)
+            elif key.startswith("encoder."):
+                _attach(enc, key[len("encoder."):], p)
+        self.decoder = LargeFOV(params["decoder.conv6.weight"], params["decoder.conv7.weight"],
+                                params["decoder.conv8.weight"], dilation=self._cfg.decoder_dilation)
+        self.classifier = _Holder()
+        self.classifier.register_parameter("weight", params["classifier.weight"])
+        self.aux_classifier = _Holder()
+        self.aux_classifier.register_parameter("weight", params["aux_classifier.weight"])
+        self._params_by_key = params
+        self._P = StudentParams(st, s)
+
+    def _rebind(self):
+        """Point every Parameter (and its .grad) at the current flat buffers."""
+        st, s = self._store, self._student
+        for key, p in self._params_by_key.items():
+            p.data = st.view(s, key)
+            p.grad = st.view(s, key, grad=True) if p.requires_grad else None
+        self._P = StudentParams(st, s)
+        self._anchor = None
+
+    def _invalidate(self):
+        self._P._pos_cache.clear()
+        self._P._pos_version = None
+
+    def _apply(self, fn, recurse=True):
+        if self._owns_store:
+            self._store.apply(fn)
+            assert self._store.data.dtype == torch.float32, "dupl_amd is an fp32-storage engine"
+            self._rebind()
+        return self
+
+    # ---- reference API ------------------------------------------------------------------------
+    def get_param_groups(self):
+        """[backbone, backbone_norm ("norm" in name), cls heads, seg head] -- the grouping the reference intends
+        (model_dupl.py:43-62; as shipped it dereferences self.mlp_layer and raises when add_mlp=False)."""
+        groups = [[], [], [], []]
+        for name, p in self.encoder.named_parameters():
+            groups[1 if "norm" in name else 0].append(p)
+        groups[2] += [self.classifier.weight, self.aux_classifier.weight]
+        groups[3] += list(self.decoder.parameters())
+        return groups
+
+    def to_2D(self, x, h, w):
+        n, hw, c = x.shape
+        return x.transpose(1, 2).reshape(n, c, h, w)
+
+    def _anchor_for(self, device):
+        if self._anchor is None or self._anchor.device != device:
+            self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        return self._anchor
+
+    def forward(self, x, cam_only=False, val=False, cam_with_grad=False):
+        if not x.is_cuda:
+            raise RuntimeError("dupl_amd.network runs on an MI355X only (no CPU path); move the model and inputs to cuda")
+        x = x.contiguous().float()
+        if cam_only:
+            cam_aux_t, cam_t = engine.cam_logits(self._P, x)
+            B = x.shape[0]
+            h, w = x.shape[2] // self._cfg.patch, x.shape[3] // self._cfg.patch
+            C = self.num_classes - 1
+            cam = ops.tokens_to_nchw(cam_t, B, h * w, C, h, w, skip_cls=True)
+            cam_aux = ops.tokens_to_nchw(cam_aux_t, B, h * w, C, h, w, skip_cls=True)
+            return cam_aux, cam
+        if cam_with_grad:
+            raise NotImplementedError("cam_with_grad (model_dupl.py:100-104) is not used by any training script")
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in (self.classifier.weight,))
+        if need_grad:
+            return _NetworkFn.apply(self._anchor_for(x.device), x, self)
+        outs, _ = engine.network_forward(self._P, x, save=False)
+        return outs
+
+
+def _trunc_normal_(t: torch.Tensor, std: float):
+    torch.nn.init.trunc_normal_(t, std=std)
+
+
+def _reference_init(store: FlatStorage, student: int):
+    """Reference initialisation (vit.py:265-276; decoder/classifier convs keep PyTorch's default
+    kaiming_uniform(a=sqrt(5)) since LargeFOV._init_weights is never called, conv_head.py:24-30)."""
+    import math
+    for key, shp in store.shapes.items():
+        t = store.view(student, key)
+        if key.startswith("decoder.") or "classifier" in key:
+            fan_in = shp[1] * shp[2] * shp[3]
+            bound = 1.0 / math.sqrt(fan_in)   # kaiming_uniform_(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+            t.uniform_(-bound, bound)
+        elif key == "encoder.patch_embed.proj.weight":
+            fan_in = shp[1] * shp[2] * shp[3]
+            bound = 1.0 / math.sqrt(fan_in)
+            t.uniform_(-bound, bound)
+        elif key == "encoder.patch_embed.proj.bias":
+            bound = 1.0 / math.sqrt(3 * store.cfg.patch ** 2)
+            t.uniform_(-bound, bound)
+        elif "norm" in key:
+            t.fill_(1.0 if key.endswith("weight") else 0.0)
+        elif key.endswith("bias"):
+            t.zero_()
+        else:  # Linear weights, pos_embed, cls_token
+            _trunc_normal_(t, 0.02)
+
+
+class siamese_network(nn.Module):
+    def __init__(self, backbone, num_classes=None, pretrained=None, aux_layer=None):
+        super().__init__()
+        cfg = encoder_config(backbone, aux_layer)
+        self._store = FlatStorage(cfg, num_classes, 2)
+        self.branch1 = network(backbone, num_classes=num_classes, pretrained=None, aux_layer=aux_layer,
+                               _store=self._store, _student=0)
+        self.branch2 = network(backbone, num_classes=num_classes, pretrained=None, aux_layer=aux_layer,
+                               _store=self._store, _student=1)
+        for s in (0, 1):
+            _reference_init(self._store, s)
+        self._rebind()
+        if pretrained and not isinstance(pretrained, bool):
+            sd = torch.load(pretrained, map_location="cpu")
+            sd = sd.get("model", sd)
+            self.branch1.encoder.load_state_dict(sd, strict=False)
+            self.branch2.encoder.load_state_dict(sd, strict=False)
+        elif pretrained:
+            raise RuntimeError("pretrained=True needs network access; pass a local state_dict path or pretrained=False")
+
+    def _rebind(self):
+        self.branch1._rebind()
+        self.branch2._rebind()
+
+    def _apply(self, fn, recurse=True):
+        self._store.apply(fn)
+        assert self._store.data.dtype == torch.float32, "dupl_amd is an fp32-storage engine"
+        self._rebind()
+        return self
+
+    @property
+    def flat_storage(self) -> FlatStorage:
+        return self._store
+
+    def get_param_groups(self):
+        """model_dupl.py:119-154: [backbone, backbone_norm, cls heads, decoders] over both students."""
+        groups = [[], [], [], []]
+        for br in (self.branch1, self.branch2):
+            for name, p in br.encoder.named_parameters():
+                groups[1 if "norm" in name else 0].append(p)
+        for br in (self.branch1, self.branch2):
+            groups[2] += [br.classifier.weight, br.aux_classifier.weight]
+        for br in (self.branch1, self.branch2):
+            groups[3] += list(br.decoder.parameters())
+        return groups
+
+    def forward(self, x, val=False, cam_only=False, cam_with_grad=False, branch=None, need_sp=False):
+        """model_dupl.py:156-213 dispatch."""
+        res = {}
+        if val:
+            if branch is None:
+                res["branch1"] = self.branch1(x)
+                res["branch2"] = self.branch2(x)
+                return res
+            return self.branch1(x) if branch == 1 else self.branch2(x)
+        if cam_only:
+            if branch is None:
+                cam_aux_1, cam_1 = self.branch1(x, cam_only=cam_only)
+                cam_aux_2, cam_2 = self.branch2(x, cam_only=cam_only)
+                return cam_aux_1, cam_1, cam_aux_2, cam_2
+            return self.branch1(x, cam_only=cam_only) if branch == 1 else self.branch2(x, cam_only=cam_only)
+        if cam_with_grad:
+            raise NotImplementedError("cam_with_grad (model_dupl.py:171-179) is not used by any training script")
+        if branch is None:
+            if need_sp:
+                x, x_aug = x.chunk(2)
+                b, _, H, W = x_aug.shape
+                x_aug = ops.resize_bilinear(x_aug.contiguous(), int(H * 0.75), int(W * 0.75))
+                res["branch1"] = self.branch1(x)
+                res["branch2"] = self.branch2(x)
+                res["branch1_aug"] = self.branch1(x_aug)[1]
+                res["branch2_aug"] = self.branch2(x_aug)[1]
+                return res
+            res["branch1"] = self.branch1(x)
+            res["branch2"] = self.branch2(x)
+            return res
+        return self.branch1(x) if branch == 1 else self.branch2(x)

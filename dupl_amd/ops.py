@@ -1,0 +1,329 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see engine.py).
+
+Every function takes CUDA(ROCm) fp32 tensors, checks layout, and enqueues the HIP kernel on the
+current torch stream.  Outputs are freshly allocated unless an `out=` is given.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GemmDesc
+
+Tensor = torch.Tensor
+
+
+def L():
+    return _lib.lib()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: Tensor, dtype=torch.float32):
+    assert t.is_cuda, "dupl_amd ops need device tensors (no CPU fallback)"
+    assert t.dtype == dtype, f"expected {dtype}, got {t.dtype}"
+    assert t.is_contiguous(), "expected a contiguous tensor"
+    return t
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, flags: int = 0,
+             bias: Optional[int] = None, res: Optional[int] = None, ldr: int = 0, aux: Optional[int] = None,
+             ldaux: int = 0, alpha: float = 1.0, batch: int = 1, zdiv: int = 1,
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sX=(0, 0), sBias=(0, 0)):
+    """Pointer-level GEMM; strides are in elements.  z -> (z // zdiv, z % zdiv)."""
+    d = GemmDesc()
+    d.A, d.B, d.C = A, B, C
+    d.bias, d.res, d.aux = bias, res, aux
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldr, d.ldaux = lda, ldb, ldc, ldr, ldaux
+    d.batch, d.zdiv = batch, zdiv
+    d.sA0, d.sA1 = sA
+    d.sB0, d.sB1 = sB
+    d.sC0, d.sC1 = sC
+    d.sR0, d.sR1 = sR
+    d.sX0, d.sX1 = sX
+    d.sBias0, d.sBias1 = sBias
+    d.alpha, d.flags = alpha, flags
+    L().dupl_gemm_f32(ctypes.byref(d), _stream())
+
+
+def linear(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, gelu: bool = False, relu: bool = False,
+           res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None) -> Tensor:
+    """y[M,N] = act(x[M,K] @ W[N,K]^T + bias) + res     (nn.Linear / 1x1 conv forward).
+    store_pre: optional [M,N] tensor that receives the pre-activation (x W^T + bias)."""
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.numel() == N * K
+    y = out if out is not None else torch.empty((M, N), device=x.device, dtype=torch.float32)
+    fl = (_lib.GEMM_GELU if gelu else 0) | (_lib.GEMM_RELU if relu else 0)
+    if store_pre is not None:
+        fl |= _lib.GEMM_STORE_PRE
+    gemm_raw(x.data_ptr(), W.data_ptr(), y.data_ptr(), M, N, K, x.stride(0), K, y.stride(0), flags=fl,
+             bias=_p(bias), res=_p(res), ldr=(res.stride(0) if res is not None else 0),
+             aux=_p(store_pre), ldaux=(store_pre.stride(0) if store_pre is not None else 0))
+    return y
+
+
+def linear_dgrad(dy: Tensor, W: Tensor, *, dgelu_of: Optional[Tensor] = None, relumask_of: Optional[Tensor] = None,
+                 out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """dx[M,K] = dy[M,N] @ W[N,K]  (optionally * gelu'(pre) or * (post_relu > 0))."""
+    M, N = dy.shape
+    K = W.numel() // N
+    dx = out if out is not None else torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    fl = _lib.GEMM_B_NCONTIG | (_lib.GEMM_ACCUM if accumulate else 0)
+    aux = None
+    if dgelu_of is not None:
+        fl |= _lib.GEMM_MUL_DGELU
+        aux = dgelu_of
+    if relumask_of is not None:
+        fl |= _lib.GEMM_MUL_RELUMASK
+        aux = relumask_of
+    gemm_raw(dy.data_ptr(), W.data_ptr(), dx.data_ptr(), M, K, N, dy.stride(0), K, dx.stride(0), flags=fl,
+             aux=_p(aux), ldaux=(aux.stride(0) if aux is not None else 0))
+    return dx
+
+
+def linear_wgrad(dy: Tensor, x: Tensor, out: Tensor, accumulate: bool = False):
+    """dW[N,K] (+)= dy[M,N]^T @ x[M,K]; `out` is any tensor with N*K elements (e.g. a conv weight view)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert out.numel() == N * K
+    fl = _lib.GEMM_A_MCONTIG | _lib.GEMM_B_NCONTIG | (_lib.GEMM_ACCUM if accumulate else 0)
+    gemm_raw(dy.data_ptr(), x.data_ptr(), out.data_ptr(), N, K, M, dy.stride(0), x.stride(0), K, flags=fl)
+
+
+def colsum(x: Tensor, out: Tensor, accumulate: bool = False):
+    M, N = x.shape
+    L().dupl_colsum(x.data_ptr(), out.data_ptr(), M, N, x.stride(0), int(accumulate), _stream())
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bool = False):
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    mean = rstd = None
+    if save:
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    L().dupl_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _p(mean), _p(rstd), rows, D,
+                           eps, _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor,
+                  dres: Optional[Tensor] = None) -> Tensor:
+    """Returns dx = dres + LN'(dy); accumulates into dgamma / dbeta (atomics)."""
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    L().dupl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
+                           dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, _stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attention_fwd(qkv: Tensor, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool = False):
+    out = torch.empty((B * N, H * hd), device=qkv.device, dtype=torch.float32)
+    lse = torch.empty((B, H, N), device=qkv.device, dtype=torch.float32) if need_lse else None
+    L().dupl_attention_fwd(qkv.data_ptr(), out.data_ptr(), _p(lse), B, N, H, hd, scale, _stream())
+    return out, lse
+
+
+def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, hd: int, scale: float) -> Tensor:
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), device=qkv.device, dtype=torch.float32)
+    L().dupl_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                           dqkv.data_ptr(), B, N, H, hd, scale, _stream())
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------ tokens
+def patch_im2row(x: Tensor, P: int) -> Tensor:
+    B, C, H, W = x.shape
+    assert C == 3
+    rows = torch.empty((B * (H // P) * (W // P), 3 * P * P), device=x.device, dtype=torch.float32)
+    L().dupl_patch_im2row(x.data_ptr(), rows.data_ptr(), B, H, W, P, _stream())
+    return rows
+
+
+def pos_embed_resize(pos_embed: Tensor, g: int, h: int, w: int) -> Tensor:
+    D = pos_embed.shape[-1]
+    out = torch.empty((1 + h * w, D), device=pos_embed.device, dtype=torch.float32)
+    L().dupl_pos_embed_resize(pos_embed.data_ptr(), out.data_ptr(), g, h, w, D, _stream())
+    return out
+
+
+def assemble_tokens(patch: Tensor, cls: Tensor, pos: Tensor, B: int, n: int, D: int) -> Tensor:
+    tok = torch.empty((B * (n + 1), D), device=patch.device, dtype=torch.float32)
+    L().dupl_assemble_tokens(patch.data_ptr(), cls.data_ptr(), pos.data_ptr(), tok.data_ptr(), B, n, D, _stream())
+    return tok
+
+
+def assemble_tokens_bwd(dtok: Tensor, dcls: Tensor, B: int, n: int, D: int) -> Tensor:
+    dpatch = torch.empty((B * n, D), device=dtok.device, dtype=torch.float32)
+    L().dupl_assemble_tokens_bwd(dtok.data_ptr(), dpatch.data_ptr(), dcls.data_ptr(), B, n, D, _stream())
+    return dpatch
+
+
+def gmp_fwd(tokens: Tensor, B: int, n: int, D: int):
+    out = torch.empty((B, D), device=tokens.device, dtype=torch.float32)
+    idx = torch.empty((B, D), device=tokens.device, dtype=torch.int32)
+    L().dupl_gmp_fwd(tokens.data_ptr(), out.data_ptr(), idx.data_ptr(), B, n, D, _stream())
+    return out, idx
+
+
+def gmp_bwd(dout: Tensor, idx: Tensor, dtokens: Tensor, B: int, n: int, D: int):
+    L().dupl_gmp_bwd(dout.data_ptr(), idx.data_ptr(), dtokens.data_ptr(), B, n, D, _stream())
+
+
+def tokens_to_nchw(tokens: Tensor, B: int, n: int, D: int, h: int, w: int, skip_cls: bool = True) -> Tensor:
+    out = torch.empty((B, D, h, w), device=tokens.device, dtype=torch.float32)
+    L().dupl_tokens_to_nchw(tokens.data_ptr(), out.data_ptr(), B, n, D, int(skip_cls), _stream())
+    return out
+
+
+def nchw_to_tokens_add(dnchw: Tensor, dtokens: Tensor, B: int, n: int, D: int, skip_cls: bool = True):
+    L().dupl_nchw_to_tokens_add(dnchw.data_ptr(), dtokens.data_ptr(), B, n, D, int(skip_cls), _stream())
+
+
+# ------------------------------------------------------------------------------------------ CAM
+def resize_bilinear(x: Tensor, Ho: int, Wo: int, flip_cat: bool = False, align_corners: bool = False) -> Tensor:
+    B, C, Hi, Wi = x.shape
+    out = torch.empty(((2 * B) if flip_cat else B, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    L().dupl_resize_bilinear(x.data_ptr(), out.data_ptr(), B, C, Hi, Wi, Ho, Wo, int(flip_cat), int(align_corners), _stream())
+    return out
+
+
+def cam_fuse(lows: Sequence[Tensor], sizes: Sequence[tuple], B: int, C: int, H: int, W: int, row_off: int, ldc: int):
+    """lows[i]: [2B*(row_off+hs*ws), ldc] CAM logits of scale i.  Returns (cam (B,C,H,W) un-normalised, mm [B*C,2])."""
+    n = len(lows)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lows])
+    hs = (ctypes.c_int32 * n)(*[s[0] for s in sizes])
+    ws = (ctypes.c_int32 * n)(*[s[1] for s in sizes])
+    cam = torch.empty((B, C, H, W), device=lows[0].device, dtype=torch.float32)
+    mm = torch.empty((B * C, 2), device=lows[0].device, dtype=torch.float32)
+    L().dupl_cam_fuse(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(hs, ctypes.c_void_p), ctypes.cast(ws, ctypes.c_void_p),
+                      n, row_off, ldc, cam.data_ptr(), mm.data_ptr(), B, C, H, W, _stream())
+    return cam, mm
+
+
+def cam_normalise_(cam: Tensor, mm: Optional[Tensor] = None) -> Tensor:
+    planes = cam.shape[0] * cam.shape[1]
+    HW = cam.shape[2] * cam.shape[3]
+    have = mm is not None
+    if mm is None:
+        mm = torch.empty((planes, 2), device=cam.device, dtype=torch.float32)
+    L().dupl_cam_minmax_normalise(cam.data_ptr(), mm.data_ptr(), planes, HW, int(have), _stream())
+    return cam
+
+
+def cam_to_label(cam: Tensor, cls_label: Tensor, img_box: Optional[Tensor], high_thre: Optional[Tensor], bkg_thre: float,
+                 low_thre: float, ignore_mid: bool, ignore_index: int, want_valid: bool = False):
+    b, C, h, w = cam.shape
+    label = torch.empty((b, h, w), device=cam.device, dtype=torch.int64)
+    valid = torch.empty_like(cam) if want_valid else None
+    L().dupl_cam_to_label(cam.data_ptr(), cls_label.data_ptr(), _p(img_box), _p(high_thre), float(bkg_thre),
+                          float(low_thre if low_thre is not None else 0.0), int(ignore_mid),
+                          int(ignore_index if ignore_index is not None else 0), label.data_ptr(), _p(valid), b, C, h, w,
+                          _stream())
+    return valid, label
+
+
+def denormalize_img(x: Tensor) -> Tensor:
+    B, C, H, W = x.shape
+    assert C == 3
+    out = torch.empty_like(x)
+    L().dupl_denormalize_img(x.data_ptr(), out.data_ptr(), B, H * W, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ PAR
+def par_pos_term(dilations: Sequence[int], w1: float = 0.3, w2: float = 0.01) -> np.ndarray:
+    """w2 * softmax_k(-(pos_k/(std(pos)+1e-8)/w1)^2): the input-independent part of PAR.forward
+    (PAR.py:51-62,78,83-85), evaluated once on the host in float32 like the reference does."""
+    ker = np.ones(8, dtype=np.float32)
+    ker[[0, 2, 5, 7]] = np.float32(np.sqrt(2))
+    pos = np.concatenate([ker * np.float32(d) for d in dilations]).astype(np.float32)
+    std = np.float32(np.std(pos.astype(np.float64), ddof=1))
+    a = -((pos / (std + np.float32(1e-8)) / np.float32(w1)) ** 2)
+    e = np.exp(a - a.max())
+    return (np.float32(w2) * (e / e.sum())).astype(np.float32)
+
+
+def par_affinity(imgs: Tensor, dilations: Sequence[int], pos_term: Tensor) -> Tensor:
+    B, C, h, w = imgs.shape
+    assert C == 3
+    nd = len(dilations)
+    aff = torch.empty((B, 8 * nd, h, w), device=imgs.device, dtype=torch.float32)
+    dil = (ctypes.c_int32 * nd)(*dilations)
+    L().dupl_par_affinity(imgs.data_ptr(), aff.data_ptr(), ctypes.cast(dil, ctypes.c_void_p), nd, pos_term.data_ptr(), B, h, w,
+                          _stream())
+    return aff
+
+
+def par_propagate(aff: Tensor, masks: Tensor, job_img: Tensor, job_K: Tensor, dilations: Sequence[int], num_iter: int) -> Tensor:
+    """masks [njobs, Kmax, h, w]; returns the propagated masks after num_iter ping-pong iterations."""
+    njobs, Kmax, h, w = masks.shape
+    nd = len(dilations)
+    dil = (ctypes.c_int32 * nd)(*dilations)
+    a, b = masks, torch.empty_like(masks)
+    for _ in range(num_iter):
+        L().dupl_par_propagate(aff.data_ptr(), a.data_ptr(), b.data_ptr(), job_img.data_ptr(), job_K.data_ptr(),
+                               ctypes.cast(dil, ctypes.c_void_p), nd, njobs, Kmax, h, w, _stream())
+        a, b = b, a
+    return a
+
+
+def refine_pre(cams: Tensor, thr_map: Optional[Tensor], thr: Optional[Tensor], job_img: Tensor, job_K: Tensor, keys: Tensor) -> Tensor:
+    b, C, H, W = cams.shape
+    njobs, Kmax = keys.shape
+    masks = torch.zeros((njobs, Kmax, H // 2, W // 2), device=cams.device, dtype=torch.float32)
+    L().dupl_refine_pre(cams.data_ptr(), _p(thr_map), _p(thr), job_img.data_ptr(), job_K.data_ptr(), keys.data_ptr(), njobs, Kmax,
+                        masks.data_ptr(), C, H, W, _stream())
+    return masks
+
+
+def refine_post(masks: Tensor, job_img: Tensor, job_K: Tensor, keys: Tensor, box: Tensor, ignore_index: float) -> Tensor:
+    njobs, Kmax, h, w = masks.shape
+    label = torch.empty((njobs, 2 * h, 2 * w), device=masks.device, dtype=torch.float32)
+    L().dupl_refine_post(masks.data_ptr(), job_img.data_ptr(), job_K.data_ptr(), keys.data_ptr(), njobs, Kmax, box.data_ptr(),
+                         float(ignore_index), label.data_ptr(), h, w, _stream())
+    return label
+
+
+def refine_merge(lab_h: Tensor, lab_l: Tensor, ignore_index: float) -> Tensor:
+    out = torch.empty_like(lab_h)
+    L().dupl_refine_merge(lab_h.data_ptr(), lab_l.data_ptr(), out.data_ptr(), float(ignore_index), lab_h.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ misc
+def fill_(t: Tensor, v: float):
+    L().dupl_fill(t.data_ptr(), float(v), t.numel(), _stream())
+    return t
+
+
+def axpy_(y: Tensor, x: Tensor, a: float = 1.0):
+    assert y.numel() == x.numel()
+    L().dupl_axpy(y.data_ptr(), x.data_ptr(), float(a), y.numel(), _stream())
+    return y
+
+
+def scale_(y: Tensor, a: float):
+    L().dupl_scale(y.data_ptr(), float(a), y.numel(), _stream())
+    return y
+
+
+def zeros(shape, device) -> Tensor:
+    t = torch.empty(shape, device=device, dtype=torch.float32)
+    return fill_(t, 0.0)

@@ -1,0 +1,130 @@
+"""One DuPL training iteration (reference: train_final_voc.py:174-472 / train_final_coco.py:170-462).
+
+`compute_losses` is the loss assembly of phases A and B (and the GMM-free part of C) written against the
+reference's own module API (siamese_network.forward, cam_helper.*, losses.*), so it reads like the
+reference's loop; `train_step` adds zero_grad / backward / optimiser step.  The per-step host syncs of
+the reference (six .item() calls + an sklearn F1 on .cpu() tensors, train_final_voc.py:458-468) are not
+part of the step: callers log from the returned device scalars when they want to.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .model import losses as LS
+from .utils import cam_helper
+from .utils.train_helper import cosine_descent
+
+VOC_HIGH_TARGET = (0.70, 0.70, 0.70, 0.70, 0.55, 0.55, 0.55, 0.55, 0.70, 0.55,
+                   0.55, 0.55, 0.55, 0.55, 0.55, 0.55, 0.55, 0.55, 0.70, 0.55)   # train_final_voc.py:162-166
+
+
+@dataclass
+class StepArgs:
+    """The argparse fields the iteration reads (defaults = train_final_voc.py:35-90)."""
+    cam_iters: int = 2000
+    gmm_iters: int = 8000
+    max_iters: int = 20000
+    bkg_thre: float = 0.5
+    high_thre: float = 0.7
+    low_thre: float = 0.25
+    ignore_index: int = 255
+    w_ptc: float = 0.2
+    w_seg: float = 0.2
+    cam_scales: Tuple[float, ...] = (1.0, 0.5, 1.5)
+    high_target: Tuple[float, ...] = VOC_HIGH_TARGET
+    samples_per_gpu: int = 2
+
+
+def coco_step_args(**kw) -> StepArgs:
+    """train_final_coco.py:75-86,161-162: cam 8000 / gmm 32000 / max 80000, bkg 0.45, high 0.65, target 0.55 x 80."""
+    d = dict(cam_iters=8000, gmm_iters=32000, max_iters=80000, bkg_thre=0.45, high_thre=0.65, low_thre=0.25,
+             high_target=tuple([0.55] * 80))
+    d.update(kw)
+    return StepArgs(**d)
+
+
+def per_image_high_thres(cls_label: torch.Tensor, n_iter: int, args: StepArgs) -> torch.Tensor:
+    """train_final_voc.py:263-275: cosine-descended per-class thresholds, per image the max over present classes.
+    Host-side (C floats) -> (b,) device tensor."""
+    C = cls_label.shape[1]
+    thr = cosine_descent(np.ones(C, dtype=np.float32) * np.float32(args.high_thre),
+                         np.asarray(args.high_target[:C], dtype=np.float32),
+                         n_iter - args.cam_iters, args.max_iters - args.cam_iters)
+    thr = np.asarray(thr, dtype=np.float32)
+    cl = cls_label.detach().cpu().numpy() > 0
+    out = np.array([thr[cl[i]].max() if cl[i].any() else thr.max() for i in range(cl.shape[0])], dtype=np.float32)
+    return torch.from_numpy(out).to(cls_label.device)
+
+
+def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs):
+    """Phase A (n_iter < cam_iters) and phase B loss assembly; returns (loss, dict of device scalars / tensors)."""
+    b, _, h, w = inputs.shape
+    phase_a = n_iter < args.cam_iters
+    inputs_denorm = ops.denormalize_img(inputs.contiguous()) if not phase_a else None
+
+    cams_1, cams_aux_1 = cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=1)
+    cams_2, cams_aux_2 = cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=2)
+
+    res = model(inputs)
+    cls_1, segs_1, fmap_1, cls_aux_1 = res["branch1"]
+    cls_2, segs_2, fmap_2, cls_aux_2 = res["branch2"]
+
+    msm = LS.multilabel_soft_margin_loss
+    cls_loss = msm(cls_1, cls_label) + msm(cls_aux_1, cls_label) + msm(cls_2, cls_label) + msm(cls_aux_2, cls_label)
+
+    fh, fw = fmap_1.shape[2:]
+    if phase_a:
+        high = args.high_thre
+        to_label = cam_helper.cam_to_label
+    else:
+        high = per_image_high_thres(cls_label, n_iter, args)
+        to_label = cam_helper.cam_to_label_dynamic_cls
+    labels = []
+    for ca in (cams_aux_1, cams_aux_2):
+        r = ops.resize_bilinear(ca, fh, fw)
+        _, pl = to_label(r, cls_label=cls_label, img_box=img_box, ignore_mid=True, bkg_thre=args.bkg_thre, high_thre=high,
+                         low_thre=args.low_thre, ignore_index=args.ignore_index)
+        labels.append(pl)
+    ptc_loss = LS.get_masked_ptc_loss_from_label(fmap_1, labels[0], args.ignore_index) + \
+        LS.get_masked_ptc_loss_from_label(fmap_2, labels[1], args.ignore_index)
+
+    out = {"pseudo_label_aux_1": labels[0], "pseudo_label_aux_2": labels[1], "cams_1": cams_1, "cams_2": cams_2,
+           "cams_aux_1": cams_aux_1, "cams_aux_2": cams_aux_2}
+    if phase_a:
+        seg_loss = torch.ones(1, device=inputs.device)
+    else:
+        # the reference passes cams * cls_label_rep (train_final_voc.py:336); refine only reads the channels of
+        # PRESENT classes (label == 1), for which that product is the identity, so the (b,C,H,W) multiply is skipped
+        hmap = high.view(b, 1, 1, 1).expand(b, 1, h, w).contiguous()
+        r1 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_1, cls_labels=cls_label,
+                                                       high_thre_map=hmap, low_thre=args.low_thre,
+                                                       ignore_index=args.ignore_index, img_box=img_box)
+        r2 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_2, cls_labels=cls_label,
+                                                       high_thre_map=hmap, low_thre=args.low_thre,
+                                                       ignore_index=args.ignore_index, img_box=img_box)
+        # cross supervision: student 1 learns from student 2's labels and vice versa (train_final_voc.py:351-352)
+        seg_loss = LS.get_seg_loss_lowres(segs_1, r2, (h, w), args.ignore_index) + \
+            LS.get_seg_loss_lowres(segs_2, r1, (h, w), args.ignore_index)
+        out["refined_1"], out["refined_2"] = r1, r2
+    sim = LS.sim_loss(fmap_1, fmap_2)
+    if n_iter <= args.cam_iters:
+        loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + 0.0 * seg_loss + 0.1 * sim
+    else:
+        loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + args.w_seg * seg_loss + 0.1 * sim
+    out.update(loss=loss, cls_loss=cls_loss, ptc_loss=ptc_loss, seg_loss=seg_loss, sim_loss=sim, cls_1=cls_1, segs_1=segs_1,
+               fmap_1=fmap_1, cls_aux_1=cls_aux_1, cls_2=cls_2, segs_2=segs_2, fmap_2=fmap_2, cls_aux_2=cls_aux_2)
+    return loss, out
+
+
+def train_step(model, optim, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs):
+    """zero_grad -> losses -> backward -> optimiser step (train_final_voc.py:470-472)."""
+    optim.zero_grad()
+    loss, out = compute_losses(model, par, inputs, cls_label, img_box, n_iter, args)
+    loss.sum().backward()
+    optim.step()
+    return out

@@ -1,0 +1,101 @@
+"""PolyWarmupAdamW (reference: utils/optimizer.py:38-68) as a fused flat-buffer optimiser.
+
+Same constructor and schedule as the reference (linear warm-up from `warmup_ratio` over `warmup_iter`
+steps, then poly decay; lr applied BEFORE the update, global_step incremented after).  When the
+parameters are views of a dupl_amd FlatStorage (the normal case) the update is one HIP launch per
+(student, param-group) segment over the flat param / grad / moment buffers; segments that have never
+received a gradient are skipped, which is exactly torch's `if p.grad is None: continue`.
+"""
+import math
+
+import torch
+
+from .. import ops
+from ..engine import FlatStorage
+
+
+def adamw_segment(p, g, m, v, step, lr, beta1, beta2, eps, wd):
+    """One fused AdamW update of flat fp32 tensors (torch.optim.AdamW single-tensor semantics)."""
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = math.sqrt(1.0 - beta2 ** step)
+    ops.L().dupl_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
+                       float(beta2), float(eps), float(wd), float(bc1), float(bc2_sqrt), ops._stream())
+
+
+class PolyWarmupAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr, weight_decay, betas, warmup_iter=None, max_iter=None, warmup_ratio=None, power=None,
+                 **kwargs):
+        defaults = dict(lr=lr, betas=betas, eps=1e-8, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.global_step = 0
+        self.warmup_iter = warmup_iter
+        self.warmup_ratio = warmup_ratio
+        self.max_iter = max_iter
+        self.power = power
+        self.__init_lr = [group["lr"] for group in self.param_groups]
+        self._flat = None          # (FlatStorage, exp_avg, exp_avg_sq, per-segment step counts)
+        self._seg_group = None
+
+    # ---- flat storage discovery -----------------------------------------------------------------
+    def bind(self, store: FlatStorage):
+        """Attach the flat storage the parameters are views of (done automatically by `step` through
+        `store_of`, or explicitly by the training script)."""
+        dev = store.data.device
+        m = torch.empty_like(store.data)
+        v = torch.empty_like(store.data)
+        ops.fill_(m, 0.0)
+        ops.fill_(v, 0.0)
+        steps = [[0] * 5 for _ in range(store.n_students)]
+        self._flat = (store, m, v, steps)
+        # map segment id (1..4) -> optimizer param group index by locating one parameter of each group
+        ptr_to_group = {}
+        for gi, grp in enumerate(self.param_groups):
+            for p in grp["params"]:
+                ptr_to_group[p.data_ptr()] = gi
+        self._seg_group = {}
+        for seg in range(1, 5):
+            lo, hi = store.seg_bounds[seg]
+            for key, (off, n) in store.layout.items():
+                if lo <= off < hi:
+                    ptr = store.view(0, key).data_ptr()
+                    if ptr in ptr_to_group:
+                        self._seg_group[seg] = ptr_to_group[ptr]
+                        break
+        return self
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self._flat is not None:
+            ops.fill_(self._flat[0].grad, 0.0)   # keep the .grad views alive: one fused fill
+        else:
+            super().zero_grad(set_to_none=False)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        # schedule (optimizer.py:51-63)
+        if self.global_step < self.warmup_iter:
+            lr_mult = 1 - (1 - self.global_step / self.warmup_iter) * (1 - self.warmup_ratio)
+            for i in range(len(self.param_groups)):
+                self.param_groups[i]["lr"] = self.__init_lr[i] * lr_mult
+        elif self.global_step < self.max_iter:
+            lr_mult = (1 - self.global_step / self.max_iter) ** self.power
+            for i in range(len(self.param_groups)):
+                self.param_groups[i]["lr"] = self.__init_lr[i] * lr_mult
+        if self._flat is None:
+            raise RuntimeError("PolyWarmupAdamW.bind(model.flat_storage) must be called once: dupl_amd updates the flat "
+                               "parameter buffer with fused HIP launches (no per-tensor fallback)")
+        store, m, v, steps = self._flat
+        for s in range(store.n_students):
+            base = s * store.student_numel
+            for seg in range(1, 5):
+                if not store.seg_has_grad[s][seg] or seg not in self._seg_group:
+                    continue
+                grp = self.param_groups[self._seg_group[seg]]
+                lo, hi = store.seg_bounds[seg]
+                if hi <= lo:
+                    continue
+                steps[s][seg] += 1
+                b1, b2 = grp["betas"]
+                sl = slice(base + lo, base + hi)
+                adamw_segment(store.data[sl], store.grad[sl], m[sl], v[sl], steps[s][seg], grp["lr"], b1, b2, grp["eps"],
+                              grp["weight_decay"])
+        self.global_step += 1

@@ -1,0 +1,227 @@
+/* dupl_hip.h -- C ABI of libdupl_hip.so: the gfx950 (MI355X / CDNA4) kernels behind DuPL's per-step
+ * hot path (BASELINE.json:north_star).
+ *
+ * The reference (Wu0409/DuPL) has no native layer: every op below is, in the reference, a stock ATen
+ * call issued from Python.  Each entry point therefore cites the reference *Python* site it replaces
+ * (paths relative to the reference checkout).  The binding a maintainer adds is a ctypes stub
+ * (INTEGRATION.md); dupl_amd/_lib.py is exactly that stub.
+ *
+ * Conventions: raw device pointers, explicit dims / leading dimensions in ELEMENTS,
+ * fp32 contiguous data unless noted, no allocation, no hidden synchronisation, work is enqueued on
+ * `stream` (a hipStream_t passed as void*; NULL = the null stream), re-entrant per stream.
+ * Return value: 0 on success, <0 on error (-1 bad argument, -2 launch failure).
+ */
+#ifndef DUPL_HIP_H
+#define DUPL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dupl_stream_t;
+
+/* library / device info: returns the ABI version (1); fills arch name if buf != NULL */
+int dupl_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 in / fp32 accumulate / fp32 out.
+ *   C[z][m][n] = epilogue( alpha * sum_k A[z](m,k) * B[z](k,n) )
+ * Replaces: nn.Linear / F.linear (vit.py:92-102,115-122,136), q@k^T and attn@v (vit.py:129,135),
+ * F.conv2d 1x1 classifiers (model_dupl.py:82-83,89,95), the patch-embed conv as im2row GEMM
+ * (vit.py:176-183), LargeFOV convs as im2col GEMMs (conv_head.py:32-41), the PTC Gram matrix
+ * (losses.py:12) and every dgrad / wgrad autograd derives from them.
+ * flags: */
+#define DUPL_GEMM_A_MCONTIG 1   /* A stored [K][lda] (m contiguous) instead of [M][lda] (k contiguous) */
+#define DUPL_GEMM_B_NCONTIG 2   /* B stored [K][ldb] (n contiguous) instead of [N][ldb] (k contiguous) */
+#define DUPL_GEMM_GELU 4        /* v = gelu_erf(v) after bias */
+#define DUPL_GEMM_ACCUM 8       /* C += v instead of C = v */
+#define DUPL_GEMM_MUL_DGELU 16  /* v *= gelu'(aux[m][n])   (MLP backward) */
+#define DUPL_GEMM_RELU 32       /* v = max(v,0) */
+#define DUPL_GEMM_MUL_RELUMASK 64 /* v *= (aux[m][n] > 0)   (ReLU backward; aux = post-ReLU output) */
+#define DUPL_GEMM_ABS 128       /* v = |v|  (PTC cosine matrix) */
+#define DUPL_GEMM_STORE_PRE 256 /* also WRITE the pre-activation (alpha*acc+bias) to aux[m][n] (training forward of fc1) */
+typedef struct dupl_gemm_desc {
+    const float* A; const float* B; float* C;
+    const float* bias;     /* [N] or NULL, added before the activation */
+    const float* res;      /* [M][ldr] or NULL, added after the activation */
+    const float* aux;      /* [M][ldaux] or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldr, ldaux;
+    int32_t batch;         /* grid.z; z -> (z / zdiv, z % zdiv) */
+    int32_t zdiv;
+    int64_t sA0, sA1, sB0, sB1, sC0, sC1, sR0, sR1, sX0, sX1, sBias0, sBias1; /* element strides */
+    float alpha;
+    int32_t flags;
+} dupl_gemm_desc;
+int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim D (D % 4 == 0, D <= 2048), one wavefront per row.
+ * Replaces nn.LayerNorm(eps=1e-6) (vit.py:146,152,256; applied at :157,:159,:323).
+ * fwd: y = (x-mean)*rstd*gamma+beta; mean/rstd [rows] saved when non-NULL.
+ * bwd: dx = [dres +] rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;
+ *      dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (atomic accumulate: zero them first). */
+int dupl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                       float* mean, float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s);
+int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                       int64_t rows, int32_t D, dupl_stream_t s);
+
+/* column sums: out[n] (+)= sum_m x[m][n]  (bias gradients).  accumulate!=0 adds to out (atomic). */
+int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int32_t ldx, int32_t accumulate,
+                dupl_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused multi-head self-attention core (flash style, exact-fp32 MFMA, online softmax).
+ * Replaces Attention.forward's q@k^T*scale -> softmax -> @v (vit.py:123-135) without
+ * materialising the (B,H,N,N) probabilities (the reference returns them; vit.py:320 drops them).
+ * qkv: [B*N][3*H*hd] exactly as nn.Linear(dim,3*dim) writes it (q|k|v, head-major inside each);
+ * out: [B*N][H*hd] (= the (attn@v).transpose(1,2).reshape(B,N,C) layout); lse: [B][H][N] or NULL.
+ * hd in {32, 64}. */
+int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H,
+                       int32_t hd, float scale, dupl_stream_t s);
+/* backward: dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N] floats. */
+int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                       float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,
+                       float scale, dupl_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token plumbing (vit.py:176-184, 289-306; model_dupl.py:64-67, 88-95). */
+/* im2row for the 16x16/s16 patch conv: x (B,3,H,W) -> rows [B*h*w][3*P*P] (c,py,px order = conv weight layout) */
+int dupl_patch_im2row(const float* x, float* rows, int32_t B, int32_t H, int32_t W, int32_t P, dupl_stream_t s);
+/* inverse scatter is never needed (inputs get no grad). */
+/* bicubic (A=-0.75, align_corners=False) resize of the (g x g) pos-embed grid to (h x w); pos_embed (1,1+g*g,D)
+ * -> out [1+h*w][D] with the cls row copied (vit.py:294-297). */
+int dupl_pos_embed_resize(const float* pos_embed, float* out, int32_t g, int32_t h, int32_t w, int32_t D, dupl_stream_t s);
+/* tokens[b][0] = cls + pos[0]; tokens[b][1+i] = patch[b][i] + pos[1+i]  (vit.py:300-304) */
+int dupl_assemble_tokens(const float* patch, const float* cls, const float* pos, float* tokens,
+                         int32_t B, int32_t n, int32_t D, dupl_stream_t s);
+/* backward of the above wrt patch rows and cls token: dpatch[b][i] = dtok[b][1+i]; dcls += sum_b dtok[b][0] */
+int dupl_assemble_tokens_bwd(const float* dtok, float* dpatch, float* dcls, int32_t B, int32_t n, int32_t D, dupl_stream_t s);
+/* global max pool over the n patch tokens (skipping the cls row): tokens [B][1+n][D] -> out [B][D], idx [B][D] */
+int dupl_gmp_fwd(const float* tokens, float* out, int32_t* idx, int32_t B, int32_t n, int32_t D, dupl_stream_t s);
+/* dtokens[b][1+idx][d] += dout[b][d] */
+int dupl_gmp_bwd(const float* dout, const int32_t* idx, float* dtokens, int32_t B, int32_t n, int32_t D, dupl_stream_t s);
+/* tokens [B][1+n][D] (skip cls) <-> NCHW (B,D,h,w): network.to_2D (model_dupl.py:64-67) and its adjoint
+ * (adjoint ACCUMULATES into dtokens rows 1..n). */
+int dupl_tokens_to_nchw(const float* tokens, float* out, int32_t B, int32_t n, int32_t D, int32_t skip_cls, dupl_stream_t s);
+int dupl_nchw_to_tokens_add(const float* dnchw, float* dtokens, int32_t B, int32_t n, int32_t D, int32_t skip_cls, dupl_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale CAM (cam_helper.py:164-204 / camutils.py:87-127), CAM->label (cam_helper.py:8-55). */
+/* F.interpolate(mode="bilinear") (B,C,Hi,Wi)->(B,C,Ho,Wo); flip_cat!=0 writes 2B images [x ; flip_w(x)]
+ * (the torch.cat([inputs, inputs.flip(-1)]) of cam_helper.py:169,184). */
+int dupl_resize_bilinear(const float* in, float* out, int32_t B, int32_t C, int32_t Hi, int32_t Wi,
+                         int32_t Ho, int32_t Wo, int32_t flip_cat, int32_t align_corners, dupl_stream_t s);
+/* Fused ms-CAM: lows[i] = token-major CAM logits of scale i, [2B][row_off + hs*ws][ldc] (first B images = original
+ * input, last B = w-flipped input; row_off = 1 skips the cls row).
+ *   cam[b][c][y][x] = sum_i relu(max(up_i(low_i[b])(y,x), up_i(low_i[B+b])(y, W-1-x)))       (cam_helper.py:173-196)
+ * and mm[b*C+c] = {min, max} over the plane.  `lows`, `hs`, `ws` are HOST arrays of nscale (<= 4) entries. */
+int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const int32_t* ws, int32_t nscale, int32_t row_off,
+                  int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, dupl_stream_t s);
+/* per plane, in place: cam = (cam - min) / ((max - min) + 1e-5)  == `cam + maxpool(-cam); cam /= maxpool(cam) + 1e-5`
+ * (cam_helper.py:197-199).  mm [planes][2]; have_minmax = 0 recomputes it first. */
+int dupl_cam_minmax_normalise(float* cam, float* mm, int32_t planes, int32_t HW, int32_t have_minmax, dupl_stream_t s);
+/* cam_to_label / cam_to_label_dynamic_cls (cam_helper.py:8-55).  cam (b,C,h,w); cls_label (b,C); img_box (b,4) int32
+ * [y0,y1,x0,x1] or NULL (then only bkg_thre applies, no box paste); high_thre (b,) floats; label out (b,h,w) int64;
+ * valid_cam out (b,C,h,w) or NULL. */
+int dupl_cam_to_label(const float* cam, const float* cls_label, const int32_t* img_box, const float* high_thre,
+                      float bkg_thre, float low_thre, int32_t ignore_mid, int32_t ignore_index,
+                      int64_t* label, float* valid_cam, int32_t b, int32_t C, int32_t h, int32_t w, dupl_stream_t s);
+/* denormalize_img2 (imutils.py:17-31): out = float(uint8_trunc(x*std+mean))/255, IEEE mul+add (no fma) */
+int dupl_denormalize_img(const float* x, float* out, int32_t B, int32_t HW, dupl_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * PAR (model/PAR.py:26-91) and the refine wrappers (cam_helper.py:338-440).
+ * A "job" is one PAR.forward call of the reference: (image job_img[j], K = job_K[j] mask channels). */
+/* aff [B][8*ndil][h][w] = softmax_k(-mean_c((|I_k-I|/(std_k+1e-8)/0.3)^2)) + pos_term[k]   (PAR.py:66-85).
+ * imgs (B,3,h,w); dilations HOST int array; pos_term DEVICE [8*ndil] = 0.01*softmax(pos) (constant). */
+int dupl_par_affinity(const float* imgs, float* aff, const int32_t* dilations, int32_t ndil, const float* pos_term,
+                      int32_t B, int32_t h, int32_t w, dupl_stream_t s);
+/* one propagation iteration for all jobs: out[j][k] = sum_n aff[job_img[j]][n] * in[j][k][nbr_n]   (PAR.py:87-89).
+ * in/out [njobs][Kmax][h][w]; job_img, job_K DEVICE int arrays. */
+int dupl_par_propagate(const float* aff, const float* in, float* out, const int32_t* job_img, const int32_t* job_K,
+                       const int32_t* dilations, int32_t ndil, int32_t njobs, int32_t Kmax, int32_t h, int32_t w,
+                       dupl_stream_t s);
+/* refine pre (cam_helper.py:358-367,406-415): per job, channel 0 = background threshold (thr[j], or the 2x-downsampled
+ * thr_map[img] (b,1,H,W) when non-NULL), channel k>0 = cams[img][keys[j][k]-1] (cams (b,C,H,W) already multiplied by the
+ * image labels); bilinear /2; softmax over the K channels -> masks [njobs][Kmax][H/2][W/2]. keys DEVICE [njobs][Kmax]. */
+int dupl_refine_pre(const float* cams, const float* thr_map, const float* thr, const int32_t* job_img,
+                    const int32_t* job_K, const int32_t* keys, int32_t njobs, int32_t Kmax, float* masks, int32_t C,
+                    int32_t H, int32_t W, dupl_stream_t s);
+/* refine post (cam_helper.py:434-440 + box paste :376-379): bilinear x2 -> first argmax -> keys -> float label
+ * [njobs][2h][2w], ignore_index outside box[job_img[j]] (box DEVICE (b,4) int32). */
+int dupl_refine_post(const float* masks, const int32_t* job_img, const int32_t* job_K, const int32_t* keys,
+                     int32_t njobs, int32_t Kmax, const int32_t* box, float ignore_index, float* label, int32_t h,
+                     int32_t w, dupl_stream_t s);
+/* merge (cam_helper.py:381-383): out = lab_h; out[lab_h==0] = ignore; out[lab_h+lab_l==0] = 0 */
+int dupl_refine_merge(const float* lab_h, const float* lab_l, float* out, float ignore_index, int64_t n, dupl_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses (model/losses.py; train_final_voc.py:210-216,247-254,345-352). */
+/* PTC (losses.py:6-21 + cam_helper.py:323-335 fused: the int64 (b,hw,hw) mask is never built).
+ * cos (b,hw,hw) = SIGNED xhat^T xhat from dupl_gemm_f32; pairs are classified from label (b,hw) int64, or -- the
+ * reference API get_masked_ptc_loss(inputs, mask) -- from an explicit mask (b,hw,hw) int64 (1 pos / 0 neg / else ignored)
+ * when mask != NULL.
+ * sums[4] += {sum_pos |cos|, n_pos, sum_neg |cos|, n_neg} (zero first). */
+int dupl_ptc_reduce(const float* cos, const int64_t* label, const int64_t* mask, int32_t ignore_index, float* sums,
+                    int32_t b, int32_t hw, dupl_stream_t s);
+/* in place: cos_signed -> d loss/d cos_signed = sign(cos) * (pos ? -0.5*g/(n_pos+1) : neg ? 0.5*g/(n_neg+1) : 0), g = gscale[0] */
+int dupl_ptc_bwd_mask(float* cos_signed, const int64_t* label, const int64_t* mask, int32_t ignore_index,
+                      const float* sums, const float* gscale, int32_t b, int32_t hw, dupl_stream_t s);
+/* F.normalize(p=2, dim=channel, eps) on token-major rows: row r of image i at x + i*img_stride + r*ldx;
+ * xhat [rows][c] dense, norm [rows]. */
+int dupl_l2norm_rows_fwd(const float* x, float* xhat, float* norm, int64_t rows, int32_t c, int64_t ldx,
+                         int32_t rows_per_img, int64_t img_stride, float eps, dupl_stream_t s);
+int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const float* norm, float* dx, int64_t rows, int32_t c,
+                         int64_t ldx, int32_t rows_per_img, int64_t img_stride, float eps, int32_t accumulate,
+                         dupl_stream_t s);
+/* fused bilinear upsample (align_corners False) + CE, bg/fg balanced (get_seg_loss, losses.py:24-39 on
+ * F.interpolate(segs, (H,W)), train_final_voc.py:345-352).  logits token-major [b][h*w][C1]; label (b,H,W) float32
+ * or int64 (is_i64).  sums[4] += {ce_bg, n_bg, ce_fg, n_fg} (zero first). */
+int dupl_seg_loss_fwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* sums,
+                      int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, dupl_stream_t s);
+/* dlogits (token-major, zero first) += gscale[0] * d loss / d logits (wave-reduced atomics when H/h, W/w are multiples
+ * of 16; per-lane atomics otherwise) */
+int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, const float* sums,
+                      const float* gscale, float* dlogits, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W,
+                      dupl_stream_t s);
+/* nn.CosineSimilarity(dim=-1) over the n tokens of every (image, channel) (train_final_voc.py:247-254); a, b
+ * token-major (element (i, t, c) at + i*img_stride + t*ld + c).  out [B][c]; stats [B][c][3] = {dot, |a|^2, |b|^2}. */
+int dupl_cos_sim_fwd(const float* a, const float* b, float* out, float* stats, int32_t B, int32_t n, int32_t c,
+                     int64_t ld, int64_t img_stride, float eps, dupl_stream_t s);
+/* gradient wrt b only (a is detached): db (+)= g[0]*gmul * d cos / d b */
+int dupl_cos_sim_bwd(const float* a, const float* b, const float* stats, const float* g, float gmul, float* db, int32_t B,
+                     int32_t n, int32_t c, int64_t ld, int64_t img_stride, float eps, int32_t accumulate, dupl_stream_t s);
+/* loss[0] += mul * sum(x[0..n)) */
+int dupl_mean_accum(const float* x, float* loss, int64_t n, float mul, dupl_stream_t s);
+/* F.multilabel_soft_margin_loss (mean over classes then batch): loss[0] += value (if loss != NULL);
+ * dlogits (if != NULL) = gscale[0] * d loss / d logits */
+int dupl_multilabel_soft_margin(const float* logits, const float* target, float* loss, float* dlogits, const float* gscale,
+                                int32_t b, int32_t C, dupl_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * LargeFOV helpers (conv_head.py:32-41): 3x3 dilated conv (zero padding = dilation) as im2col + GEMM with
+ * token-major activations.  Column order is (c, tap) so conv weight (Cout,Cin,3,3) is the GEMM B operand in place. */
+/* x: pixel p, channel c of image b at x + b*img_stride + p*ld + c  ->  col [B*h*w][9*Cin] */
+int dupl_im2col_dil3(const float* x, float* col, int32_t B, int32_t h, int32_t w, int32_t Cin, int32_t dil, int64_t ld,
+                     int64_t img_stride, dupl_stream_t s);
+/* adjoint: dx (+)= gather of dcol, zeroed where relu_of (same layout as dx, post-ReLU activations) <= 0 if non-NULL */
+int dupl_col2im_dil3(const float* dcol, float* dx, int32_t B, int32_t h, int32_t w, int32_t Cin, int32_t dil, int64_t ld,
+                     int64_t img_stride, int32_t accumulate, const float* relu_of, dupl_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser (utils/optimizer.py:38-68 -> torch.optim.AdamW) and small element-wise helpers. */
+/* fused AdamW over one flat fp32 segment (16-byte aligned); bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t) (host, double) */
+int dupl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float wd, float bc1, float bc2_sqrt, dupl_stream_t s);
+int dupl_fill(float* p, float v, int64_t n, dupl_stream_t s);
+int dupl_axpy(float* y, const float* x, float a, int64_t n, dupl_stream_t s); /* y += a*x */
+int dupl_scale(float* y, float a, int64_t n, dupl_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUPL_HIP_H */

@@ -1,0 +1,177 @@
+"""-m gpu: the whole hot path (model API -> engine -> HIP kernels) against the golden vectors produced by
+the REAL reference (tests/golden/*.npz, written by oracle/gen_golden.py) and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD = 2e-4   # relative to the tensor's max-abs; fp32 MFMA path vs ATen CPU fp32 (different summation orders)
+
+
+def relerr(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def tiny_student(dev):
+    from dupl_amd.model.model_dupl import network
+    from oracle import dupl_oracle as O
+    net = network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    net.load_state_dict(O.make_student_params(O.VIT_TINY, 21, seed=1), strict=True)
+    return net.to(dev)
+
+
+def test_tiny_forward_matches_reference(dev, golden_dir, tiny_student):
+    g = load(golden_dir, "tiny_forward")
+    x = torch.from_numpy(g["x"]).to(dev)
+    with torch.no_grad():
+        cls, seg, x4, cls_aux = tiny_student(x)
+        cam_aux, cam = tiny_student(x, cam_only=True)
+    for name, t in (("cls", cls), ("seg", seg), ("x4", x4), ("cls_aux", cls_aux), ("cam_aux", cam_aux), ("cam", cam)):
+        e = relerr(t, g[name])
+        print(f"{name}: rel err {e:.2e}")
+        assert tuple(t.shape) == g[name].shape and e < TOL_FWD, name
+
+
+def test_tiny_ms_cam_matches_reference(dev, golden_dir, tiny_student):
+    from dupl_amd.utils import camutils
+    g = load(golden_dir, "tiny_forward")
+    xs = torch.from_numpy(g["xs"]).to(dev)
+    cam, cam_aux = camutils.multi_scale_cam2(tiny_student, xs, (1.0, 0.5, 1.5))
+    d1 = (cam[:, ::4].cpu() - torch.from_numpy(g["mscam"])).abs().max().item()
+    d2 = (cam_aux[:, ::4].cpu() - torch.from_numpy(g["mscam_aux"])).abs().max().item()
+    print(f"ms-CAM max-abs-diff: cam {d1:.2e} aux {d2:.2e}")
+    assert d1 < 1e-3 and d2 < 1e-3      # north-star bar: CAM max-abs-diff < 1e-3
+    assert d1 < 2e-5 and d2 < 2e-5      # what the exact-fp32 MFMA path actually delivers
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_tiny_train_step_matches_reference(dev, golden_dir, tag):
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd import trainer
+    from oracle import dupl_oracle as O
+    g = load(golden_dir, f"tiny_step_{tag}")
+    model = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    model.load_state_dict(O.make_siamese_params(O.VIT_TINY, 21, seed=2), strict=True)
+    model.to(dev)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    inputs, cls_label, img_box = (torch.from_numpy(g[k]) for k in ("inputs", "cls_label", "img_box"))
+    args = trainer.StepArgs()
+    model.flat_storage.grad.zero_()
+    loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, int(g["n_iter"]), args)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    for k in ("loss", "cls_loss", "ptc_loss", "seg_loss", "sim_loss"):
+        ref = float(np.asarray(g[k]).reshape(-1)[0])
+        got = float(out[k].reshape(-1)[0].item())
+        print(f"{k}: ref {ref:.6f} got {got:.6f}")
+        assert abs(got - ref) <= 2e-4 * max(1.0, abs(ref)), k
+    for k in ("pseudo_label_aux_1", "pseudo_label_aux_2"):
+        assert np.array_equal(out[k].cpu().numpy().astype(np.uint8), g[k]), k
+    for k in ("cams_1", "cams_aux_1", "cams_2", "cams_aux_2"):
+        d = np.abs(out[k][:, ::4].cpu().numpy() - g[k]).max()
+        assert d < 2e-5, (k, d)
+    if tag == "B":
+        for k in ("refined_1", "refined_2"):
+            mism = int((out[k].cpu().numpy().astype(np.uint8) != g[k]).sum())
+            print(f"{k}: {mism} label mismatches of {g[k].size}")
+            assert mism <= 2, k
+    worst, nchk = 0.0, 0
+    sd_grad = {k: model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True)
+               for k in model.state_dict().keys()}
+    for k in g.files:
+        if not k.startswith("grad."):
+            continue
+        name = k[len("grad."):]
+        ref = g[k]
+        got = sd_grad[name].detach().cpu().numpy()
+        if ref.shape != got.shape:
+            got = got.reshape(-1)[::7]
+        e = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+        if e > worst:
+            worst, wname = e, name
+        nchk += 1
+    print(f"phase {tag}: {nchk} gradient tensors checked, worst rel err {worst:.2e} ({wname})")
+    assert worst < 2e-3
+    # parameters the reference leaves without a gradient must stay untouched (pos_embed frozen, head unused,
+    # decoder in phase A)
+    for name, t in sd_grad.items():
+        if ("grad." + name) not in g.files:
+            assert float(t.abs().max().item()) == 0.0, name
+
+
+def test_vitb_forward_matches_reference(dev, golden_dir):
+    from dupl_amd.model.model_dupl import network
+    from oracle import dupl_oracle as O
+    g = load(golden_dir, "vitb_224")
+    net = network("deit_base_patch16_224", num_classes=21, pretrained=False, aux_layer=-3)
+    net.load_state_dict(O.make_student_params(O.VIT_BASE, 21, seed=11), strict=True)
+    net.to(dev)
+    xb, _, _ = O.synthetic_batch(2, 20, 224, seed=12)
+    with torch.no_grad():
+        cls, seg, x4, cls_aux = net(xb.to(dev))
+        cam_aux, cam = net(xb.to(dev), cam_only=True)
+    got = dict(cls=cls, seg=seg, x4_sub=x4[:, ::16], cls_aux=cls_aux, cam_aux=cam_aux, cam=cam)
+    for k, t in got.items():
+        e = relerr(t, g[k])
+        print(f"ViT-B {k}: rel err {e:.2e}")
+        assert e < TOL_FWD, k
+
+
+def test_optimizer_step_matches_oracle(dev):
+    """PolyWarmupAdamW over the flat buffer vs the oracle's per-tensor AdamW on the same gradients."""
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.utils.optimizer import PolyWarmupAdamW
+    from oracle import dupl_oracle as O
+    pp = O.make_siamese_params(O.VIT_TINY, 21, seed=2)
+    model = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    model.load_state_dict(pp, strict=True)
+    model.to(dev)
+    groups = model.get_param_groups()
+    opt = PolyWarmupAdamW(params=[{"params": groups[0], "lr": 6e-5, "weight_decay": 0.01},
+                                  {"params": groups[1], "lr": 6e-5, "weight_decay": 0.01},
+                                  {"params": groups[2], "lr": 6e-4, "weight_decay": 0.01},
+                                  {"params": groups[3], "lr": 6e-4, "weight_decay": 0.01}],
+                          lr=6e-5, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=2, max_iter=20, warmup_ratio=1e-6,
+                          power=0.9).bind(model.flat_storage)
+    st = model.flat_storage
+    ref = {k: v.clone() for k, v in pp.items()}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in pp.items()}
+    for t in range(3):
+        opt.zero_grad()
+        grads = {k: O.hash_normal(f"g{t}{k}", v.shape, std=0.01, seed=5) for k, v in pp.items()}
+        for k, gk in grads.items():
+            s, key = (0 if k.startswith("branch1.") else 1), k.split(".", 1)[1]
+            if key in ("encoder.pos_embed", "encoder.head.weight", "encoder.head.bias"):
+                continue
+            if t == 0 and key.startswith("decoder."):
+                continue   # decoder gets its first gradient at step 1 (phase A -> B)
+            st.view(s, key, grad=True).copy_(gk.to(dev))
+        for s in (0, 1):
+            st.seg_has_grad[s] = [False, True, True, True, t >= 1]
+        opt.step()
+        mult = O.poly_warmup_lr_mult(t, 2, 20, 1e-6, 0.9)
+        for k, gk in grads.items():
+            key = k.split(".", 1)[1]
+            if key in ("encoder.pos_embed", "encoder.head.weight", "encoder.head.bias"):
+                continue
+            if key.startswith("decoder.") and t == 0:
+                continue
+            lr = (6e-5 if O.param_group_index(k) < 2 else 6e-4) * mult
+            stepno = t + 1 - (1 if key.startswith("decoder.") else 0)
+            O.adamw_update(ref[k], gk, mom[k][0], mom[k][1], stepno, lr)
+    worst = 0.0
+    for k, v in model.state_dict().items():
+        worst = max(worst, (v.cpu() - ref[k]).abs().max().item())
+    print("optimizer: worst abs param diff after 3 steps", worst)
+    assert worst < 1e-7
