@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- DuPL training-step throughput on MI355X (BASELINE.json metric: training img/s at 448^2).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
+
+A "step" is one full phase-B iteration of the reference loop (train_final_voc.py:174-472) on a synthetic
+batch that is already resident in HBM: ms-CAM for both students (3 scales x flip), dual-student
+forward/backward, CAM->label, PTC, PAR refinement (high+low) for both students, cross seg loss,
+discrepancy loss, gradient all-reduce (N > 1) and the PolyWarmupAdamW update.  Nothing is skipped or cached
+across steps.  Workload = BASELINE.json configs[1]: VOC 448^2, dual-student ViT-B/16, 4 images per GPU
+(weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMG_PHASE_AB = 3.44e12       # BASELINE.md section 2 (algorithmic, both students, fwd+bwd = 3x fwd)
+PEAK_F32_MFMA = 157.3e12              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (f32 in / f32 acc)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (VOC config: 4)")
+    ap.add_argument("--size", type=int, default=448)
+    ap.add_argument("--dataset", default="voc", choices=["voc", "coco"])
+    ap.add_argument("--backbone", default="deit_base_patch16_224")
+    ap.add_argument("--n-iter", type=int, default=5000, help="iteration index the step pretends to be (5000 = phase B)")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
+    ap.add_argument("--cpu-size", type=int, default=448)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_world(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl")
+    else:
+        torch.cuda.set_device(0)
+    return world, rank, local
+
+
+def make_batch(args, rank, dev, C):
+    from dupl_amd.synthetic import synthetic_batch
+    inputs, cls_label, img_box = synthetic_batch(args.batch, C, args.size, seed=100 + rank)
+    return inputs.to(dev), cls_label.to(dev), img_box
+
+
+def cpu_baseline(args, C):
+    """The oracle (torch-CPU restatement of the reference, kind 'port') timed on this box's host cores on a BOUNDED
+    sample: one phase-B step at b=1 (same 448^2 dual-student workload, 1/`batch` of a GPU step)."""
+    from oracle import dupl_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.VIT_BASE
+    NC = C + 1
+    pp = O.make_siamese_params(cfg, NC, seed=3, randomize_affine=False)
+    leaf = {k: v.clone().requires_grad_(k.split(".", 1)[1] not in ("encoder.pos_embed",)) for k, v in pp.items()}
+    inputs, cls_label, img_box = O.synthetic_batch(1, C, args.cpu_size, seed=100)
+    sargs = O.StepArgs() if args.dataset == "voc" else O.StepArgs(cam_iters=8000, gmm_iters=32000, max_iters=80000,
+                                                                   bkg_thre=0.45, high_thre=0.65,
+                                                                   high_target=tuple([0.55] * 80))
+    t0 = time.perf_counter()
+    loss, _ = O.train_step_losses(leaf, inputs, cls_label, img_box, args.n_iter, cfg, sargs)
+    loss.backward()
+    mom = {}
+    for k, p in leaf.items():
+        if p.grad is None:
+            continue
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        with torch.no_grad():
+            O.adamw_update(p, p.grad, m, v, 1, 6e-5 if O.param_group_index(k) < 2 else 6e-4)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"1 phase-B step of oracle/dupl_oracle.py (dual ViT-B/16, {args.cpu_size}^2, b=1, fp32, "
+                      f"torch {torch.__version__} CPU, {cores} threads): {dt:.1f} s"}
+
+
+class GemmTimer:
+    """Event-pairs around every launch of the dominant kernel (the k-contiguous x k-contiguous 'NT' GEMM that every
+    forward Linear maps to) on the stream it is launched on, plus its algorithmic FLOPs (2*M*N*K per launch)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.flops = 0.0
+        self.n = 0
+
+    def install(self):
+        from dupl_amd import ops
+        self._orig = ops.gemm_raw
+        timer = self
+
+        def timed(A, B, C, M, N, K, lda, ldb, ldc, **kw):
+            fl = kw.get("flags", 0)
+            if fl & 3:    # other operand layouts = other kernel instantiations
+                return timer._orig(A, B, C, M, N, K, lda, ldb, ldc, **kw)
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            r = timer._orig(A, B, C, M, N, K, lda, ldb, ldc, **kw)
+            e1.record(s)
+            timer.pairs.append((e0, e1))
+            timer.flops += 2.0 * M * N * K * kw.get("batch", 1)
+            timer.n += 1
+            return r
+
+        ops.gemm_raw = timed
+
+    def remove(self):
+        from dupl_amd import ops
+        ops.gemm_raw = self._orig
+
+    def result(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        return ms, self.flops, self.n
+
+
+def main():
+    args = parse()
+    world, rank, local = build_world(args)
+    dev = torch.device("cuda", local)
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd.utils.optimizer import PolyWarmupAdamW
+    from dupl_amd.ddp import DistributedDataParallel
+    from dupl_amd import trainer
+
+    C = 20 if args.dataset == "voc" else 80
+    sargs = trainer.StepArgs() if args.dataset == "voc" else trainer.coco_step_args()
+    torch.manual_seed(0)
+    model = siamese_network(args.backbone, num_classes=C + 1, pretrained=False, aux_layer=-3)
+    groups = model.get_param_groups()
+    model.to(dev)
+    ddp = DistributedDataParallel(model) if world > 1 else model
+    optim = PolyWarmupAdamW(params=[{"params": groups[i], "lr": 6e-5 * (1 if i < 2 else 10), "weight_decay": 1e-2}
+                                    for i in range(4)], lr=6e-5, weight_decay=1e-2, betas=(0.9, 0.999),
+                            warmup_iter=1500, max_iter=sargs.max_iters, warmup_ratio=1e-6, power=0.9).bind(model.flat_storage)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    inputs, cls_label, img_box = make_batch(args, rank, dev, C)
+
+    def step(i):
+        return trainer.train_step(ddp, optim, par, inputs, cls_label, img_box, args.n_iter + i, sargs)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(out["loss"].sum().item())
+    ms = dt / args.steps * 1e3
+    imgs_per_s = world * args.batch * args.steps / dt
+
+    roof = None
+    if not args.no_roofline:
+        timer = GemmTimer()
+        timer.install()
+        step(args.warmup + args.steps)
+        gms, gflops, gn = timer.result()
+        timer.remove()
+        ach = gflops / (gms * 1e-3)
+        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<false,false> (v_mfma_f32_32x32x2_f32)", "achieved": round(ach / 1e12, 2),
+                "peak": round(PEAK_F32_MFMA / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4),
+                "traffic": None, "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
+                "kernel_share_of_step": round(gms / ms, 3),
+                "step_frac_of_peak": round(imgs_per_s / world * FLOP_PER_IMG_PHASE_AB / PEAK_F32_MFMA, 4),
+                "note": "HIP event pairs around every launch of the kernel during one extra step run right after the timed "
+                        "region (same stream, same workload); algorithmic flops = 2*M*N*K per launch"}
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_baseline == "auto":
+        cpu = cpu_baseline(args, C)
+    if rank == 0:
+        rec = {"metric": f"training img/s at 448^2, {'VOC' if args.dataset == 'voc' else 'COCO'} dual-student ViT-B/16, phase B step",
+               "value": round(imgs_per_s, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{'VOC2012' if args.dataset == 'voc' else 'MSCOCO2014'} {args.size}^2 dual-student "
+                                      f"{args.backbone} + ms-CAM(1.0,0.5,1.5) + PAR + cross seg loss, phase B, "
+                                      f"{args.batch} img/GPU, DDP world_size={world}",
+                          "global_batch": world * args.batch, "img_per_gpu": args.batch, "num_classes": C + 1,
+                          "n_iter": args.n_iter, "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(rec))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

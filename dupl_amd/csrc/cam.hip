@@ -160,7 +160,12 @@ __global__ void denormalize_kernel(const float* __restrict__ x, float* __restric
     const long total = (long)B * 3 * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i / HW) % 3);
-        const float v = __fadd_rn(__fmul_rn(x[i], stdv[c]), mean[c]);
+        float v;
+        {
+#pragma clang fp contract(off)
+            const float prod = x[i] * stdv[c];   // rounded product, THEN rounded sum -- exactly what ATen's CPU mul / add do
+            v = prod + mean[c];
+        }
         const int iv = (int)v;                       // truncation toward zero
         const unsigned char u = (unsigned char)(iv & 0xff);  // wraps like the x86 float->uint8 conversion
         out[i] = __fdiv_rn((float)u, 255.0f);

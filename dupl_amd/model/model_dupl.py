@@ -53,6 +53,7 @@ class _NetworkFn(torch.autograd.Function):
         outs, sv = engine.network_forward(net._P, x, save=True)
         ctx.net, ctx.sv = net, sv
         ctx.set_materialize_grads(False)
+        net._live_graphs += 1     # forwards of this student whose backward has not run yet (phase C has two)
         return outs
 
     @staticmethod
@@ -60,6 +61,7 @@ class _NetworkFn(torch.autograd.Function):
         net = ctx.net
         engine.network_backward(net._P, ctx.sv, dcls, dseg, dx4, dcls_aux)
         ctx.sv = None
+        net._live_graphs = max(0, net._live_graphs - 1)
         for hook in net._post_backward_hooks:
             hook(net)
         return None, None, None
@@ -79,6 +81,7 @@ class network(nn.Module):
         self._store = FlatStorage(cfg, num_classes, 1) if _store is None else _store
         self._student = _student
         self._post_backward_hooks: List[Callable] = []
+        self._live_graphs = 0
         self._anchor = None
         self._build_modules()
         if self._owns_store:

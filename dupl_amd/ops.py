@@ -199,6 +199,7 @@ def nchw_to_tokens_add(dnchw: Tensor, dtokens: Tensor, B: int, n: int, D: int, s
 # ------------------------------------------------------------------------------------------ CAM
 def resize_bilinear(x: Tensor, Ho: int, Wo: int, flip_cat: bool = False, align_corners: bool = False) -> Tensor:
     B, C, Hi, Wi = x.shape
+    x = _chk(x.contiguous())
     out = torch.empty(((2 * B) if flip_cat else B, C, Ho, Wo), device=x.device, dtype=torch.float32)
     L().dupl_resize_bilinear(x.data_ptr(), out.data_ptr(), B, C, Hi, Wi, Ho, Wo, int(flip_cat), int(align_corners), _stream())
     return out
@@ -218,6 +219,7 @@ def cam_fuse(lows: Sequence[Tensor], sizes: Sequence[tuple], B: int, C: int, H: 
 
 
 def cam_normalise_(cam: Tensor, mm: Optional[Tensor] = None) -> Tensor:
+    _chk(cam)
     planes = cam.shape[0] * cam.shape[1]
     HW = cam.shape[2] * cam.shape[3]
     have = mm is not None
@@ -230,6 +232,7 @@ def cam_normalise_(cam: Tensor, mm: Optional[Tensor] = None) -> Tensor:
 def cam_to_label(cam: Tensor, cls_label: Tensor, img_box: Optional[Tensor], high_thre: Optional[Tensor], bkg_thre: float,
                  low_thre: float, ignore_mid: bool, ignore_index: int, want_valid: bool = False):
     b, C, h, w = cam.shape
+    _chk(cam), _chk(cls_label)
     label = torch.empty((b, h, w), device=cam.device, dtype=torch.int64)
     valid = torch.empty_like(cam) if want_valid else None
     L().dupl_cam_to_label(cam.data_ptr(), cls_label.data_ptr(), _p(img_box), _p(high_thre), float(bkg_thre),
@@ -242,6 +245,7 @@ def cam_to_label(cam: Tensor, cls_label: Tensor, img_box: Optional[Tensor], high
 def denormalize_img(x: Tensor) -> Tensor:
     B, C, H, W = x.shape
     assert C == 3
+    x = _chk(x.contiguous())
     out = torch.empty_like(x)
     L().dupl_denormalize_img(x.data_ptr(), out.data_ptr(), B, H * W, _stream())
     return out
@@ -286,8 +290,9 @@ def par_propagate(aff: Tensor, masks: Tensor, job_img: Tensor, job_K: Tensor, di
 
 def refine_pre(cams: Tensor, thr_map: Optional[Tensor], thr: Optional[Tensor], job_img: Tensor, job_K: Tensor, keys: Tensor) -> Tensor:
     b, C, H, W = cams.shape
+    _chk(cams)
     njobs, Kmax = keys.shape
-    masks = torch.zeros((njobs, Kmax, H // 2, W // 2), device=cams.device, dtype=torch.float32)
+    masks = zeros((njobs, Kmax, H // 2, W // 2), cams.device)
     L().dupl_refine_pre(cams.data_ptr(), _p(thr_map), _p(thr), job_img.data_ptr(), job_K.data_ptr(), keys.data_ptr(), njobs, Kmax,
                         masks.data_ptr(), C, H, W, _stream())
     return masks

@@ -174,4 +174,4 @@ def test_optimizer_step_matches_oracle(dev):
     for k, v in model.state_dict().items():
         worst = max(worst, (v.cpu() - ref[k]).abs().max().item())
     print("optimizer: worst abs param diff after 3 steps", worst)
-    assert worst < 1e-7
+    assert worst < 1e-6   # fp32 round-off (fma contraction on the GPU vs separate mul/add in ATen's CPU AdamW)

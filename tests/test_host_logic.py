@@ -1,0 +1,109 @@
+"""CPU: the C-ABI library loads and exports every declared symbol; host-side logic (flat storage layout, module
+tree / state_dict parity, param groups, schedules) behaves like the reference.  No kernels are launched."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dupl_oracle as O
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from dupl_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(cdll, name), f"{name} declared in include/dupl_hip.h but not exported"
+    assert _lib.lib().dupl_abi_version() == 1
+    # struct mirror has the same size as the C struct would (6 ptrs, 10 int32, 12 int64, float, int32)
+    assert ctypes.sizeof(_lib.GemmDesc) == 6 * 8 + 10 * 4 + 12 * 8 + 8
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from dupl_amd.model.model_dupl import network
+    net = network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        net(torch.zeros(1, 3, 32, 32))
+    from dupl_amd.model.PAR import PAR
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        PAR([1, 2], 2)(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+
+
+def test_state_dict_parity_and_groups():
+    from dupl_amd.model.model_dupl import siamese_network, network
+    m = siamese_network("deit_base_patch16_224", num_classes=21, pretrained=False, aux_layer=-3)
+    sd = m.state_dict()
+    ref_keys = set(O.make_siamese_params.__globals__["student_param_shapes"](O.VIT_BASE, 21).keys())
+    assert {k.split(".", 1)[1] for k in sd} == ref_keys and len(sd) == 314
+    assert sum(p.numel() for p in m.parameters()) == 185014736          # SURVEY appendix B probe
+    assert [len(gp) for gp in m.get_param_groups()] == [204, 100, 4, 6]
+    frozen = [k for k, p in m.named_parameters() if not p.requires_grad]
+    assert sorted(frozen) == ["branch1.encoder.pos_embed", "branch2.encoder.pos_embed"]
+    # parameters are views of one flat buffer and survive load_state_dict
+    t = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    pp = O.make_siamese_params(O.VIT_TINY, 21, seed=2)
+    t.load_state_dict(pp, strict=True)
+    st = t.flat_storage
+    for k, v in pp.items():
+        s, key = (0 if k.startswith("branch1.") else 1), k.split(".", 1)[1]
+        assert torch.equal(st.view(s, key), v)
+        assert dict(t.named_parameters())[k].data_ptr() == st.view(s, key).data_ptr()
+    # student 2 sits at a constant offset from student 1
+    off = st.view(1, "encoder.norm.weight").data_ptr() - st.view(0, "encoder.norm.weight").data_ptr()
+    assert off == st.student_numel * 4
+    # single network has working param groups (the reference's raises, model_dupl.py:56)
+    n = network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    assert [len(x) for x in n.get_param_groups()] == [38, 18, 2, 3]
+    # reference init: LN (1,0), zero biases
+    assert float(n.encoder.blocks[0].norm1.weight.min()) == 1.0 and float(n.encoder.blocks[0].attn.qkv.bias.abs().max()) == 0.0
+
+
+def test_schedules_match_reference_formulas():
+    from dupl_amd.utils.train_helper import cosine_descent
+    from dupl_amd import trainer
+    a, b = np.float32(0.7), np.float32(0.55)
+    assert cosine_descent(a, b, -1, 100) == a and cosine_descent(a, b, 100, 100) == b
+    assert abs(cosine_descent(a, b, 50, 101) - (0.7 + (0.55 - 0.7) * (1 - math.cos(math.pi * 0.5)) / 2)) < 1e-7
+    cls = torch.zeros(2, 20)
+    cls[0, 0] = 1
+    cls[1, 4] = 1
+    cls[1, 8] = 1
+    args = trainer.StepArgs()
+    hi = trainer.per_image_high_thres(cls, 5000, args)
+    thr = O.cosine_descent(torch.ones(20) * 0.7, torch.tensor(args.high_target), 3000, 18000)
+    assert torch.allclose(hi, torch.stack([thr[0], torch.max(thr[[4, 8]])]).float(), atol=1e-7)
+    assert abs(O.poly_warmup_lr_mult(0) - 1e-6) < 1e-12 and abs(O.poly_warmup_lr_mult(1500) - (1 - 1500 / 20000) ** 0.9) < 1e-12
+
+
+def test_optimizer_schedule_and_flat_binding():
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.utils.optimizer import PolyWarmupAdamW
+    m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    gps = m.get_param_groups()
+    opt = PolyWarmupAdamW(params=[{"params": gps[i], "lr": 6e-5 * (1 if i < 2 else 10), "weight_decay": 0.01} for i in range(4)],
+                          lr=6e-5, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=1500, max_iter=20000, warmup_ratio=1e-6,
+                          power=0.9)
+    with pytest.raises(RuntimeError, match="bind"):
+        opt.step()
+    assert opt.param_groups[2]["lr"] == pytest.approx(6e-4 * 1e-6)   # schedule applied before the (refused) update
+    # segment -> param-group mapping
+    opt._seg_group = None
+    st = m.flat_storage
+    ptr_to_group = {p.data_ptr(): gi for gi, grp in enumerate(opt.param_groups) for p in grp["params"]}
+    for seg, want in ((1, 0), (2, 1), (3, 2), (4, 3)):
+        lo, hi = st.seg_bounds[seg]
+        keys = [k for k, (off, n) in st.layout.items() if lo <= off < hi]
+        assert keys and all(ptr_to_group[st.view(0, k).data_ptr()] == want for k in keys)
+
+
+def test_par_pos_term_matches_reference_formula():
+    from dupl_amd import ops
+    got = ops.par_pos_term([1, 2, 4, 8, 12, 24])
+    ref = 0.01 * O.par_pos_affinity().numpy()
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-10)

@@ -1,0 +1,110 @@
+"""CPU: the oracle (oracle/dupl_oracle.py) replayed against the golden vectors written from the REAL reference
+(oracle/gen_golden.py).  This is what keeps the checker honest on machines without /root/reference."""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import dupl_oracle as O
+
+
+def g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def close(a, b, tol=2e-5):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() < tol
+
+
+def test_tiny_forward(golden_dir):
+    d = g(golden_dir, "tiny_forward")
+    sp = O.make_student_params(O.VIT_TINY, 21, seed=1)
+    x = torch.from_numpy(d["x"])
+    with torch.no_grad():
+        cls, seg, x4, cls_aux = O.network_forward(sp, x, O.VIT_TINY)
+        cam_aux, cam = O.network_forward(sp, x, O.VIT_TINY, cam_only=True)
+    for k, t in dict(cls=cls, seg=seg, x4=x4, cls_aux=cls_aux, cam_aux=cam_aux, cam=cam).items():
+        assert close(t, d[k]), k
+    cam, cam_aux = O.multi_scale_cam(sp, torch.from_numpy(d["xs"]), O.VIT_TINY)
+    assert close(cam[:, ::4], d["mscam"]) and close(cam_aux[:, ::4], d["mscam_aux"])
+
+
+def test_tiny_step_losses_and_grads(golden_dir):
+    for tag in ("A", "B"):
+        d = g(golden_dir, f"tiny_step_{tag}")
+        pp = O.make_siamese_params(O.VIT_TINY, 21, seed=2)
+        leaf = {k: v.clone().requires_grad_(k.split(".", 1)[1] != "encoder.pos_embed") for k, v in pp.items()}
+        inputs, cls_label, img_box = (torch.from_numpy(d[k]) for k in ("inputs", "cls_label", "img_box"))
+        loss, pc = O.train_step_losses(leaf, inputs, cls_label, img_box, int(d["n_iter"]), O.VIT_TINY)
+        loss.backward()
+        assert abs(loss.item() - float(d["loss"].reshape(-1)[0])) < 1e-5
+        assert np.array_equal(pc["pseudo_label_aux_1"].numpy().astype(np.uint8), d["pseudo_label_aux_1"])
+        if tag == "B":
+            assert (pc["refined_1"].numpy().astype(np.uint8) != d["refined_1"]).sum() <= 2
+        n = 0
+        for k in d.files:
+            if k.startswith("grad."):
+                got = leaf[k[5:]].grad
+                ref = d[k]
+                got = got.numpy() if got.shape == ref.shape else got.reshape(-1)[::7].numpy()
+                assert np.abs(got - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-12), k
+                n += 1
+        assert n >= 100
+
+
+def test_labels_par_refine_losses(golden_dir):
+    d = g(golden_dir, "labels_448")
+    b, C, S = 2, 20, 448
+    inputs, cls_label, img_box = O.synthetic_batch(b, C, S, seed=7)
+    assert torch.equal(cls_label, torch.from_numpy(d["cls_label"])) and torch.equal(img_box, torch.from_numpy(d["img_box"]))
+    img_dn = O.denormalize_img2(inputs.clone())
+    assert int((img_dn * 255).round().long().sum()) == int(d["img_u8_checksum"])
+    cams = O.synthetic_cams(b, C, S, S, seed=8)
+    assert abs(cams.double().sum().item() - float(d["cams_checksum"])) < 1e-3
+    rep = cls_label[:, :, None, None]
+    c28 = F.interpolate(cams, size=(28, 28), mode="bilinear", align_corners=False)
+    _, l28 = O.cam_to_label(c28.clone(), cls_label, img_box=img_box, ignore_mid=True, bkg_thre=0.5, high_thre=0.7,
+                            low_thre=0.25, ignore_index=255)
+    assert np.array_equal(l28.numpy().astype(np.uint8), d["label28"])
+    _, l28d = O.cam_to_label(c28.clone(), cls_label, img_box=torch.from_numpy(d["box_small"]), ignore_mid=True, bkg_thre=0.5,
+                             high_thre=torch.from_numpy(d["high_dyn"]), low_thre=0.25, ignore_index=255)
+    assert np.array_equal(l28d.numpy().astype(np.uint8), d["label28_dyn"])
+    lf = O.cam_to_label(cams.clone(), cls_label, bkg_thre=0.45)
+    assert np.array_equal(lf.numpy().astype(np.uint8), d["label_full"])
+    fmap = torch.from_numpy(d["fmap"])
+    assert abs(O.masked_ptc_loss(fmap, O.label_to_aff_mask(l28d)).item() - float(d["ptc"])) < 1e-6
+    r_dyn = torch.from_numpy(d["refine_dyn"]).long()
+    seg = torch.from_numpy(d["seg_logits"])
+    sl = O.seg_loss(F.interpolate(seg, size=(S, S), mode="bilinear", align_corners=False), r_dyn)
+    assert abs(sl.item() - float(d["seg_loss"])) < 1e-5
+    # refine (the heavy part: two PAR runs per image at 224^2) -- only the scalar-threshold variant to keep CPU time low
+    o_v2 = O.refine_cams(img_dn, cams * rep, cls_label, 0.65, 0.25, 255, img_box)
+    assert (o_v2.numpy().astype(np.uint8) != d["refine_v2"]).sum() <= 4
+
+
+def test_par_and_adamw(golden_dir):
+    d = g(golden_dir, "par_224")
+    inputs, _, _ = O.synthetic_batch(2, 20, 448, seed=7)
+    img_half = F.interpolate(O.denormalize_img2(inputs.clone())[:1], size=[224, 224], mode="bilinear", align_corners=False)
+    m0 = O.synthetic_cams(1, 3, 224, 224, seed=9).softmax(dim=1)
+    out = O.par_forward(img_half, m0)
+    assert np.abs(out[:, :, ::2, ::2].numpy() - d["out_sub"]).max() < 1e-5
+    a = g(golden_dir, "adamw")
+    p = torch.from_numpy(a["w0"]).clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for t in range(3):
+        O.adamw_update(p, torch.from_numpy(a[f"gw{t}"]), m, v, t + 1, 6e-5 * O.poly_warmup_lr_mult(t, 2, 20, 1e-6, 0.9))
+        assert np.abs(p.numpy() - a[f"pa{t}"]).max() < 1e-7
+
+
+def test_vitb_forward(golden_dir):
+    d = g(golden_dir, "vitb_224")
+    sp = O.make_student_params(O.VIT_BASE, 21, seed=11)
+    xb, _, _ = O.synthetic_batch(2, 20, 224, seed=12)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        cam_aux, cam = O.network_forward(sp, xb, O.VIT_BASE, cam_only=True)
+    assert close(cam, d["cam"]) and close(cam_aux, d["cam_aux"])
