@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--n-iter", type=int, default=5000, help="iteration index the step pretends to be (5000 = phase B)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--cpu-size", type=int, default=448)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline (0 = all logical CPUs)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -68,7 +69,7 @@ def cpu_baseline(args, C):
     """The oracle (torch-CPU restatement of the reference, kind 'port') timed on this box's host cores on a BOUNDED
     sample: one phase-B step at b=1 (same 448^2 dual-student workload, 1/`batch` of a GPU step)."""
     from oracle import dupl_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, args.cpu_threads) if args.cpu_threads > 0 else (os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cfg = O.VIT_BASE
     NC = C + 1
@@ -134,6 +135,10 @@ class GemmTimer:
         return ms, self.flops, self.n
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     world, rank, local = build_world(args)
@@ -166,8 +171,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"model on {dev}; starting {args.warmup} warm-up step(s)")
     for i in range(args.warmup):
+        tw = time.perf_counter()
         step(i)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {time.perf_counter() - tw:.3f} s")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -182,6 +191,7 @@ def main():
     loss_val = float(out["loss"].sum().item())
     ms = dt / args.steps * 1e3
     imgs_per_s = world * args.batch * args.steps / dt
+    log(f"timed region: {args.steps} steps in {dt:.3f} s -> {imgs_per_s:.2f} img/s")
 
     roof = None
     if not args.no_roofline:
@@ -200,7 +210,9 @@ def main():
                         "region (same stream, same workload); algorithmic flops = 2*M*N*K per launch"}
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline == "auto":
+        log("timing the CPU oracle on the host cores (bounded sample)")
         cpu = cpu_baseline(args, C)
+        log(f"cpu baseline: {cpu}")
     if rank == 0:
         rec = {"metric": f"training img/s at 448^2, {'VOC' if args.dataset == 'voc' else 'COCO'} dual-student ViT-B/16, phase B step",
                "value": round(imgs_per_s, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
