@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline (0 = all logical CPUs)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="run the two students back to back on one stream")
     return ap.parse_args()
 
 
@@ -155,6 +156,8 @@ def main():
     model = siamese_network(args.backbone, num_classes=C + 1, pretrained=False, aux_layer=-3)
     groups = model.get_param_groups()
     model.to(dev)
+    if not args.single_stream:
+        model.enable_dual_stream(True)
     ddp = DistributedDataParallel(model) if world > 1 else model
     optim = PolyWarmupAdamW(params=[{"params": groups[i], "lr": 6e-5 * (1 if i < 2 else 10), "weight_decay": 1e-2}
                                     for i in range(4)], lr=6e-5, weight_decay=1e-2, betas=(0.9, 0.999),
@@ -195,6 +198,7 @@ def main():
 
     roof = None
     if not args.no_roofline:
+        model.enable_dual_stream(False)   # per-kernel durations are only meaningful without a co-running stream
         timer = GemmTimer()
         timer.install()
         step(args.warmup + args.steps)
@@ -222,7 +226,8 @@ def main():
                                       f"{args.backbone} + ms-CAM(1.0,0.5,1.5) + PAR + cross seg loss, phase B, "
                                       f"{args.batch} img/GPU, DDP world_size={world}",
                           "global_batch": world * args.batch, "img_per_gpu": args.batch, "num_classes": C + 1,
-                          "n_iter": args.n_iter, "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
+                          "n_iter": args.n_iter, "parallelism": f"dp{world}", "student_streams": 1 if args.single_stream else 2,
+                          "loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec))
     if world > 1:

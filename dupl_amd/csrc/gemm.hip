@@ -17,18 +17,19 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int BN = 128, BK = 32, NT = 256;
 
-struct Tile4 { float4 v[4]; };
+template <int ROWS>
+struct TileR { float4 v[ROWS / 32]; };
 
 // Load a (128 x 32) operand tile into registers.
 // KC (k-contiguous): element (r, k) at base[r*ld + k]; thread chunk c -> row c>>3, k (c&7)*4.
 // MC (m-contiguous): element (r, k) at base[k*ld + r]; thread chunk c -> k c>>5, r (c&31)*4.
-template <bool MC>
-__device__ __forceinline__ void load_tile(Tile4& t, const float* __restrict__ base, int ld, int r0, int k0,
+template <bool MC, int ROWS>
+__device__ __forceinline__ void load_tile(TileR<ROWS>& t, const float* __restrict__ base, int ld, int r0, int k0,
                                           int R, int K, bool vec_ok, int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
         const int c = tid + NT * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!MC) {
@@ -44,7 +45,7 @@ __device__ __forceinline__ void load_tile(Tile4& t, const float* __restrict__ ba
                 }
             }
         } else {
-            const int k = k0 + (c >> 5), r = r0 + ((c & 31) << 2);
+            const int k = k0 + c / (ROWS / 4), r = r0 + ((c % (ROWS / 4)) << 2);
             if (k < K && r < R) {
                 const float* p = base + (size_t)k * ld + r;
                 if (vec_ok && r + 3 < R) v = *reinterpret_cast<const float4*>(p);
@@ -60,10 +61,10 @@ __device__ __forceinline__ void load_tile(Tile4& t, const float* __restrict__ ba
     }
 }
 
-template <bool MC, int S>
-__device__ __forceinline__ void store_tile(const Tile4& t, float* __restrict__ lds, int tid) {
+template <bool MC, int S, int ROWS>
+__device__ __forceinline__ void store_tile(const TileR<ROWS>& t, float* __restrict__ lds, int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
         const int c = tid + NT * i;
         if (!MC) {
             const int r = c >> 3, k = (c & 7) << 2;
@@ -72,15 +73,17 @@ __device__ __forceinline__ void store_tile(const Tile4& t, float* __restrict__ l
             lds[(k + 2) * S + r] = t.v[i].z;
             lds[(k + 3) * S + r] = t.v[i].w;
         } else {
-            const int k = c >> 5, r = (c & 31) << 2;
+            const int k = c / (ROWS / 4), r = (c % (ROWS / 4)) << 2;
             *reinterpret_cast<float4*>(&lds[k * S + r]) = t.v[i];
         }
     }
 }
 
-template <bool A_MC, bool B_NC>
+// BM = 128: wave tile 64x64 (2x2 MFMA tiles).  BM = 64: wave tile 32x64 (1x2) -- twice the blocks for small grids.
+template <bool A_MC, bool B_NC, int BM>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
-    constexpr int SA = A_MC ? 132 : 129;
+    constexpr int MI = BM / 64;                 // 32-row MFMA tiles per wave along m
+    constexpr int SA = A_MC ? (BM + 4) : (BM + 1);
     constexpr int SB = B_NC ? 132 : 129;
     __shared__ __attribute__((aligned(16))) float smem[BK * SA + BK * SB];
     float* As = smem;
@@ -110,40 +113,51 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
     const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nt = (p.K + BK - 1) / BK;
-    Tile4 ra, rb;
-    load_tile<A_MC>(ra, A, p.lda, m0, 0, p.M, p.K, a_vec, tid);
-    load_tile<B_NC>(rb, B, p.ldb, n0, 0, p.N, p.K, b_vec, tid);
+    // split-K (gridDim.z > 1): this block reduces k in [kbeg, kend) and adds its partial tile atomically
+    const int ksplit = gridDim.z;
+    int kbeg = 0, kend = p.K;
+    if (ksplit > 1) {
+        const int kchunk = ((p.K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+        kbeg = blockIdx.z * kchunk;
+        kend = min(p.K, kbeg + kchunk);
+        if (kbeg >= kend) return;
+    }
+    const int nt = (kend - kbeg + BK - 1) / BK;
+    TileR<BM> ra;
+    TileR<BN> rb;
+    load_tile<A_MC, BM>(ra, A, p.lda, m0, kbeg, p.M, kend, a_vec, tid);
+    load_tile<B_NC, BN>(rb, B, p.ldb, n0, kbeg, p.N, kend, b_vec, tid);
 
-    const float* a_rd = As + wm * 64 + l31;
+    const float* a_rd = As + wm * (BM / 2) + l31;
     const float* b_rd = Bs + wn * 64 + l31;
 
     for (int t = 0; t < nt; ++t) {
         __syncthreads();
-        store_tile<A_MC, SA>(ra, As, tid);
-        store_tile<B_NC, SB>(rb, Bs, tid);
+        store_tile<A_MC, SA, BM>(ra, As, tid);
+        store_tile<B_NC, SB, BN>(rb, Bs, tid);
         __syncthreads();
         if (t + 1 < nt) {
-            load_tile<A_MC>(ra, A, p.lda, m0, (t + 1) * BK, p.M, p.K, a_vec, tid);
-            load_tile<B_NC>(rb, B, p.ldb, n0, (t + 1) * BK, p.N, p.K, b_vec, tid);
+            load_tile<A_MC, BM>(ra, A, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, a_vec, tid);
+            load_tile<B_NC, BN>(rb, B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, b_vec, tid);
         }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int k = 2 * s + hf;
-            const float a0 = a_rd[k * SA], a1 = a_rd[k * SA + 32];
             const float b0 = b_rd[k * SB], b1 = b_rd[k * SB + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const float a = a_rd[k * SA + 32 * i];
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[i][1], 0, 0, 0);
+            }
         }
     }
 
@@ -158,10 +172,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
         if (col >= p.N) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf;
+                const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf;
                 if (row >= p.M) continue;
                 float v = p.alpha * acc[i][j][e] + bv;
                 if (fl & DUPL_GEMM_STORE_PRE) const_cast<float*>(aux)[(size_t)row * p.ldaux + col] = v;
@@ -172,6 +186,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
                 if (fl & DUPL_GEMM_MUL_RELUMASK) v = aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
                 if (res) v += res[(size_t)row * p.ldr + col];
                 float* cp = C + (size_t)row * p.ldc + col;
+                if (ksplit > 1) { unsafeAtomicAdd(cp, v); continue; }   // hardware global_atomic_add_f32
                 if (fl & DUPL_GEMM_ACCUM) v += *cp;
                 *cp = v;
             }
@@ -181,18 +196,52 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
 
 }  // namespace
 
+static int g_tile_override = 0;   // 0 = heuristic, 64 / 128 = forced (tuning knob, dupl_set_gemm_tile)
+
+extern "C" int dupl_set_gemm_tile(int32_t rows) {
+    if (rows != 0 && rows != 64 && rows != 128) return DUPL_ERR_ARG;
+    g_tile_override = rows;
+    return DUPL_OK;
+}
+
 extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     if (!d || !d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->zdiv <= 0)
         return DUPL_ERR_ARG;
     if ((d->flags & (DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK | DUPL_GEMM_STORE_PRE)) && !d->aux) return DUPL_ERR_ARG;
-    const int nbm = (d->M + BM - 1) / BM, nbn = (d->N + BN - 1) / BN;
-    dim3 grid(nbm * nbn, d->batch), block(NT);
+    const int nbn = (d->N + BN - 1) / BN;
+    const long nb128 = (long)((d->M + 127) / 128) * nbn * d->batch;
+    // 256 CUs x 2 resident blocks: below ~3 full rounds of 128-row tiles the tail round dominates -> 64-row tiles
+    // 64-row tiles (4 resident blocks / CU) measured >= 128-row tiles on every DuPL shape (profiles/r01_gemm_tiles.txt)
+    bool small = true;
+    (void)nb128;
+    if (g_tile_override) small = g_tile_override == 64;
+    const int bm = small ? 64 : 128;
+    const int nbm = (d->M + bm - 1) / bm;
+    // split-K for pure accumulate GEMMs (weight gradients: tiny M x N, K = all tokens): fill >= ~4 blocks per CU
+    int ksplit = 1;
+    const int pure = DUPL_GEMM_A_MCONTIG | DUPL_GEMM_B_NCONTIG | DUPL_GEMM_ACCUM;
+    if ((d->flags & ~pure) == 0 && (d->flags & DUPL_GEMM_ACCUM) && !d->bias && !d->res && d->alpha == 1.0f) {
+        const long blocks = (long)nbm * nbn * d->batch;
+        if (blocks < 1024) {
+            ksplit = (int)((1024 + blocks - 1) / blocks);
+            const int maxs = (d->K + 127) / 128;   // keep >= 128 k per split
+            if (ksplit > maxs) ksplit = maxs;
+            if (ksplit < 1) ksplit = 1;
+        }
+    }
+    dim3 grid(nbm * nbn, d->batch, ksplit), block(NT);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool amc = d->flags & DUPL_GEMM_A_MCONTIG, bnc = d->flags & DUPL_GEMM_B_NCONTIG;
-    if (!amc && !bnc) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, *d);
-    else if (!amc && bnc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, *d);
-    else if (amc && !bnc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, *d);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, *d);
+#define DUPL_GEMM_LAUNCH(AM, BNC)                                                               \
+    do {                                                                                        \
+        if (small) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64>), grid, block, 0, s, *d);   \
+        else hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128>), grid, block, 0, s, *d);        \
+    } while (0)
+    if (!amc && !bnc) DUPL_GEMM_LAUNCH(false, false);
+    else if (!amc && bnc) DUPL_GEMM_LAUNCH(false, true);
+    else if (amc && !bnc) DUPL_GEMM_LAUNCH(true, false);
+    else DUPL_GEMM_LAUNCH(true, true);
+#undef DUPL_GEMM_LAUNCH
     return dupl_launch_status();
 }
 

@@ -127,6 +127,14 @@ class FlatStorage:
         self.grad = torch.zeros(n_students * off, dtype=torch.float32, device=device)
         # sticky "this segment has received a gradient at least once" flags == torch's `p.grad is None` skip
         self.seg_has_grad = [[False] * 5 for _ in range(n_students)]
+        self.streams: List = []     # side streams the students run on (siamese_network.enable_dual_stream)
+
+    def wait_streams(self):
+        """Make the current stream wait for everything queued on the student streams."""
+        if self.streams:
+            cur = torch.cuda.current_stream()
+            for s in self.streams:
+                cur.wait_stream(s)
 
     def view(self, student: int, key: str, grad: bool = False) -> Tensor:
         off, n = self.layout[key]

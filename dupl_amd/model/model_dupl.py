@@ -250,6 +250,38 @@ class siamese_network(nn.Module):
     def flat_storage(self) -> FlatStorage:
         return self._store
 
+    # ---- two-student concurrency --------------------------------------------------------------
+    def enable_dual_stream(self, on: bool = True):
+        """Run the two (independent) students on two HIP streams so that their kernels share the 256 CUs:
+        a single student's N=768 GEMMs / attention grids do not fill the chip.  Autograd replays each student's
+        backward on the stream its forward ran on; the optimiser and the gradient exchange wait on both."""
+        self._dual = bool(on)
+        if on and self._store.data.is_cuda and not self._store.streams:
+            self._store.streams = [torch.cuda.Stream(device=self._store.data.device) for _ in range(2)]
+        if not on:
+            self._store.streams = []
+        return self
+
+    def per_student(self, fn1, fn2):
+        """Evaluate fn1() for student 1 and fn2() for student 2, concurrently when dual-stream is enabled."""
+        if not (getattr(self, "_dual", False) and self._store.streams):
+            return fn1(), fn2()
+        main = torch.cuda.current_stream()
+        s1, s2 = self._store.streams
+        s1.wait_stream(main)
+        s2.wait_stream(main)
+        with torch.cuda.stream(s1):
+            r1 = fn1()
+        with torch.cuda.stream(s2):
+            r2 = fn2()
+        main.wait_stream(s1)
+        main.wait_stream(s2)
+        for r in (r1, r2):
+            for t in (r if isinstance(r, (tuple, list)) else (r,)):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+        return r1, r2
+
     def get_param_groups(self):
         """model_dupl.py:119-154: [backbone, backbone_norm, cls heads, decoders] over both students."""
         groups = [[], [], [], []]
@@ -289,7 +321,6 @@ class siamese_network(nn.Module):
                 res["branch1_aug"] = self.branch1(x_aug)[1]
                 res["branch2_aug"] = self.branch2(x_aug)[1]
                 return res
-            res["branch1"] = self.branch1(x)
-            res["branch2"] = self.branch2(x)
+            res["branch1"], res["branch2"] = self.per_student(lambda: self.branch1(x), lambda: self.branch2(x))
             return res
         return self.branch1(x) if branch == 1 else self.branch2(x)

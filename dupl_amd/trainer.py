@@ -67,8 +67,10 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     phase_a = n_iter < args.cam_iters
     inputs_denorm = ops.denormalize_img(inputs.contiguous()) if not phase_a else None
 
-    cams_1, cams_aux_1 = cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=1)
-    cams_2, cams_aux_2 = cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=2)
+    core = model.module if hasattr(model, "module") else model
+    (cams_1, cams_aux_1), (cams_2, cams_aux_2) = core.per_student(
+        lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=1),
+        lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=2))
 
     res = model(inputs)
     cls_1, segs_1, fmap_1, cls_aux_1 = res["branch1"]

@@ -65,6 +65,7 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = False):
         if self._flat is not None:
+            self._flat[0].wait_streams()
             ops.fill_(self._flat[0].grad, 0.0)   # keep the .grad views alive: one fused fill
         else:
             super().zero_grad(set_to_none=False)
@@ -84,6 +85,7 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
             raise RuntimeError("PolyWarmupAdamW.bind(model.flat_storage) must be called once: dupl_amd updates the flat "
                                "parameter buffer with fused HIP launches (no per-tensor fallback)")
         store, m, v, steps = self._flat
+        store.wait_streams()     # the students' backward passes may still be running on their own streams
         for s in range(store.n_students):
             base = s * store.student_numel
             for seg in range(1, 5):

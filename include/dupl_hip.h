@@ -56,6 +56,8 @@ typedef struct dupl_gemm_desc {
     int32_t flags;
 } dupl_gemm_desc;
 int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
+/* tuning knob: force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic on the grid size) */
+int dupl_set_gemm_tile(int32_t rows);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim D (D % 4 == 0, D <= 2048), one wavefront per row.

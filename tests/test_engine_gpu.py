@@ -54,8 +54,9 @@ def test_tiny_ms_cam_matches_reference(dev, golden_dir, tiny_student):
     assert d1 < 2e-5 and d2 < 2e-5      # what the exact-fp32 MFMA path actually delivers
 
 
+@pytest.mark.parametrize("dual", [False, True], ids=["one-stream", "two-streams"])
 @pytest.mark.parametrize("tag", ["A", "B"])
-def test_tiny_train_step_matches_reference(dev, golden_dir, tag):
+def test_tiny_train_step_matches_reference(dev, golden_dir, tag, dual):
     from dupl_amd.model.model_dupl import siamese_network
     from dupl_amd.model.PAR import PAR
     from dupl_amd import trainer
@@ -64,12 +65,14 @@ def test_tiny_train_step_matches_reference(dev, golden_dir, tag):
     model = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
     model.load_state_dict(O.make_siamese_params(O.VIT_TINY, 21, seed=2), strict=True)
     model.to(dev)
+    model.enable_dual_stream(dual)
     par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
     inputs, cls_label, img_box = (torch.from_numpy(g[k]) for k in ("inputs", "cls_label", "img_box"))
     args = trainer.StepArgs()
     model.flat_storage.grad.zero_()
     loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, int(g["n_iter"]), args)
     loss.sum().backward()
+    model.flat_storage.wait_streams()
     torch.cuda.synchronize()
     for k in ("loss", "cls_loss", "ptc_loss", "seg_loss", "sim_loss"):
         ref = float(np.asarray(g[k]).reshape(-1)[0])
