@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline (0 = all logical CPUs)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--forward-precision", default="f32", choices=["f32", "h3"],
+                    help="f32: exact f32-MFMA everywhere (default); h3: split-fp16 3-pass MFMA for the Linear forwards")
     ap.add_argument("--single-stream", action="store_true", help="run the two students back to back on one stream")
     return ap.parse_args()
 
@@ -63,7 +65,7 @@ def build_world(args):
 def make_batch(args, rank, dev, C):
     from dupl_amd.synthetic import synthetic_batch
     inputs, cls_label, img_box = synthetic_batch(args.batch, C, args.size, seed=100 + rank)
-    return inputs.to(dev), cls_label.to(dev), img_box
+    return inputs.to(dev), cls_label.to(dev), img_box, cls_label
 
 
 def cpu_baseline(args, C):
@@ -150,6 +152,8 @@ def main():
     from dupl_amd.ddp import DistributedDataParallel
     from dupl_amd import trainer
 
+    from dupl_amd import ops as _ops
+    _ops.set_forward_precision(args.forward_precision)
     C = 20 if args.dataset == "voc" else 80
     sargs = trainer.StepArgs() if args.dataset == "voc" else trainer.coco_step_args()
     torch.manual_seed(0)
@@ -163,10 +167,10 @@ def main():
                                     for i in range(4)], lr=6e-5, weight_decay=1e-2, betas=(0.9, 0.999),
                             warmup_iter=1500, max_iter=sargs.max_iters, warmup_ratio=1e-6, power=0.9).bind(model.flat_storage)
     par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
-    inputs, cls_label, img_box = make_batch(args, rank, dev, C)
+    inputs, cls_label, img_box, cls_host = make_batch(args, rank, dev, C)
 
     def step(i):
-        return trainer.train_step(ddp, optim, par, inputs, cls_label, img_box, args.n_iter + i, sargs)
+        return trainer.train_step(ddp, optim, par, inputs, cls_label, img_box, args.n_iter + i, sargs, cls_label_host=cls_host)
 
     def barrier():
         if world > 1:
@@ -227,6 +231,7 @@ def main():
                                       f"{args.batch} img/GPU, DDP world_size={world}",
                           "global_batch": world * args.batch, "img_per_gpu": args.batch, "num_classes": C + 1,
                           "n_iter": args.n_iter, "parallelism": f"dp{world}", "student_streams": 1 if args.single_stream else 2,
+                          "forward_precision": args.forward_precision,
                           "loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec))

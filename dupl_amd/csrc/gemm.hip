@@ -12,6 +12,8 @@
 // write when the operand is k-contiguous in memory (row stride 129: conflict-free scatter).
 // Grid: one block per output tile, remapped so that each XCD (private L2) owns a contiguous band of
 // row-tiles; blockIdx.y = batch.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/dupl_hip.h"
 
@@ -19,68 +21,59 @@ namespace {
 
 constexpr int BN = 128, BK = 32, NT = 256;
 
-template <int ROWS>
-struct TileR { float4 v[ROWS / 32]; };
-
-// Load a (128 x 32) operand tile into registers.
-// KC (k-contiguous): element (r, k) at base[r*ld + k]; thread chunk c -> row c>>3, k (c&7)*4.
-// MC (m-contiguous): element (r, k) at base[k*ld + r]; thread chunk c -> k c>>5, r (c&31)*4.
+// One float4 chunk c of a (ROWS x 32) operand tile, fully guarded (edge tiles, unaligned rows, k tails).
+// KC (k-contiguous): element (r, k) at base[r*ld + k]; chunk c -> row c>>3, k (c&7)*4.
+// MC (m-contiguous): element (r, k) at base[k*ld + r]; chunk c -> k c/(ROWS/4), r (c%(ROWS/4))*4.
 template <bool MC, int ROWS>
-__device__ __forceinline__ void load_tile(TileR<ROWS>& t, const float* __restrict__ base, int ld, int r0, int k0,
-                                          int R, int K, bool vec_ok, int tid) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int c = tid + NT * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!MC) {
-            const int r = r0 + (c >> 3), k = k0 + ((c & 7) << 2);
-            if (r < R && k < K) {
-                const float* p = base + (size_t)r * ld + k;
-                if (vec_ok && k + 3 < K) v = *reinterpret_cast<const float4*>(p);
-                else {
-                    v.x = p[0];
-                    if (k + 1 < K) v.y = p[1];
-                    if (k + 2 < K) v.z = p[2];
-                    if (k + 3 < K) v.w = p[3];
-                }
-            }
-        } else {
-            const int k = k0 + c / (ROWS / 4), r = r0 + ((c % (ROWS / 4)) << 2);
-            if (k < K && r < R) {
-                const float* p = base + (size_t)k * ld + r;
-                if (vec_ok && r + 3 < R) v = *reinterpret_cast<const float4*>(p);
-                else {
-                    v.x = p[0];
-                    if (r + 1 < R) v.y = p[1];
-                    if (r + 2 < R) v.z = p[2];
-                    if (r + 3 < R) v.w = p[3];
-                }
+__device__ __forceinline__ float4 load_chunk(const float* __restrict__ base, int ld, int r0, int k0, int R, int K, bool vec_ok,
+                                             int c) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!MC) {
+        const int r = r0 + (c >> 3), k = k0 + ((c & 7) << 2);
+        if (r < R && k < K) {
+            const float* p = base + (size_t)r * ld + k;
+            if (vec_ok && k + 3 < K) v = *reinterpret_cast<const float4*>(p);
+            else {
+                v.x = p[0];
+                if (k + 1 < K) v.y = p[1];
+                if (k + 2 < K) v.z = p[2];
+                if (k + 3 < K) v.w = p[3];
             }
         }
-        t.v[i] = v;
+    } else {
+        const int k = k0 + c / (ROWS / 4), r = r0 + ((c % (ROWS / 4)) << 2);
+        if (k < K && r < R) {
+            const float* p = base + (size_t)k * ld + r;
+            if (vec_ok && r + 3 < R) v = *reinterpret_cast<const float4*>(p);
+            else {
+                v.x = p[0];
+                if (r + 1 < R) v.y = p[1];
+                if (r + 2 < R) v.z = p[2];
+                if (r + 3 < R) v.w = p[3];
+            }
+        }
     }
+    return v;
 }
 
+// LDS tiles are k-major ([k][row], row stride S): KC chunks are transposed on the way in (4 scalar stores, S odd ->
+// conflict free), MC chunks go in as one 16-byte store.
 template <bool MC, int S, int ROWS>
-__device__ __forceinline__ void store_tile(const TileR<ROWS>& t, float* __restrict__ lds, int tid) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int c = tid + NT * i;
-        if (!MC) {
-            const int r = c >> 3, k = (c & 7) << 2;
-            lds[(k + 0) * S + r] = t.v[i].x;
-            lds[(k + 1) * S + r] = t.v[i].y;
-            lds[(k + 2) * S + r] = t.v[i].z;
-            lds[(k + 3) * S + r] = t.v[i].w;
-        } else {
-            const int k = c / (ROWS / 4), r = (c % (ROWS / 4)) << 2;
-            *reinterpret_cast<float4*>(&lds[k * S + r]) = t.v[i];
-        }
+__device__ __forceinline__ void store_chunk(const float4 v, float* __restrict__ lds, int c) {
+    if (!MC) {
+        const int r = c >> 3, k = (c & 7) << 2;
+        lds[(k + 0) * S + r] = v.x;
+        lds[(k + 1) * S + r] = v.y;
+        lds[(k + 2) * S + r] = v.z;
+        lds[(k + 3) * S + r] = v.w;
+    } else {
+        const int k = c / (ROWS / 4), r = (c % (ROWS / 4)) << 2;
+        *reinterpret_cast<float4*>(&lds[k * S + r]) = v;
     }
 }
 
 // BM = 128: wave tile 64x64 (2x2 MFMA tiles).  BM = 64: wave tile 32x64 (1x2) -- twice the blocks for small grids.
-template <bool A_MC, bool B_NC, int BM>
+template <bool A_MC, bool B_NC, int BM, bool FAST>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
     constexpr int MI = BM / 64;                 // 32-row MFMA tiles per wave along m
     constexpr int SA = A_MC ? (BM + 4) : (BM + 1);
@@ -131,32 +124,69 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
         if (kbeg >= kend) return;
     }
     const int nt = (kend - kbeg + BK - 1) / BK;
-    TileR<BM> ra;
-    TileR<BN> rb;
-    load_tile<A_MC, BM>(ra, A, p.lda, m0, kbeg, p.M, kend, a_vec, tid);
-    load_tile<B_NC, BN>(rb, B, p.ldb, n0, kbeg, p.N, kend, b_vec, tid);
-
+    // FAST (decided on the host, dupl_gemm_f32): every k-tile full and every row 16-byte aligned -> branch-free
+    // clamped float4 loads; otherwise the fully guarded loader.
     const float* a_rd = As + wm * (BM / 2) + l31;
     const float* b_rd = Bs + wn * 64 + l31;
 
+    // ---- k-loop.  Staging registers are plain local float4 arrays filled by fully inlined code (no struct refs).
+    constexpr int NA = BM / 32, NB = BN / 32;   // float4 per thread per k-tile
+    float4 ra[NA], rb[NB];
+    auto issue_loads = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = tid + NT * i;
+            if (FAST) {
+                if (!A_MC) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + (c >> 3), p.M - 1) * p.lda + k0 + ((c & 7) << 2));
+                else ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(k0 + c / (BM / 4)) * p.lda + min(m0 + ((c % (BM / 4)) << 2), p.M - 4));
+            } else {
+                ra[i] = load_chunk<A_MC, BM>(A, p.lda, m0, k0, p.M, kend, a_vec, c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = tid + NT * i;
+            if (FAST) {
+                if (!B_NC) rb[i] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + (c >> 3), p.N - 1) * p.ldb + k0 + ((c & 7) << 2));
+                else rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(k0 + c / (BN / 4)) * p.ldb + min(n0 + ((c % (BN / 4)) << 2), p.N - 4));
+            } else {
+                rb[i] = load_chunk<B_NC, BN>(B, p.ldb, n0, k0, p.N, kend, b_vec, c);
+            }
+        }
+    };
+    issue_loads(kbeg);
     for (int t = 0; t < nt; ++t) {
         __syncthreads();
-        store_tile<A_MC, SA, BM>(ra, As, tid);
-        store_tile<B_NC, SB, BN>(rb, Bs, tid);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) store_chunk<A_MC, SA, BM>(ra[i], As, tid + NT * i);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) store_chunk<B_NC, SB, BN>(rb[i], Bs, tid + NT * i);
         __syncthreads();
-        if (t + 1 < nt) {
-            load_tile<A_MC, BM>(ra, A, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, a_vec, tid);
-            load_tile<B_NC, BN>(rb, B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, b_vec, tid);
+        if (t + 1 < nt) issue_loads(kbeg + (t + 1) * BK);
+        // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
+        float fa[2][MI], fb[2][2];
+        {
+            const int k = hf;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[0][i] = a_rd[k * SA + 32 * i];
+            fb[0][0] = b_rd[k * SB];
+            fb[0][1] = b_rd[k * SB + 32];
         }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            const int k = 2 * s + hf;
-            const float b0 = b_rd[k * SB], b1 = b_rd[k * SB + 32];
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < BK / 2) {
+                const int k = 2 * (s + 1) + hf;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[nxt][i] = a_rd[k * SA + 32 * i];
+                fb[nxt][0] = b_rd[k * SB];
+                fb[nxt][1] = b_rd[k * SB + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the next step's ds_reads ahead of this step's MFMAs
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const float a = a_rd[k * SA + 32 * i];
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[i][1], 0, 0, 0);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][1], acc[i][1], 0, 0, 0);
             }
         }
     }
@@ -211,6 +241,7 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     const int nbn = (d->N + BN - 1) / BN;
     const long nb128 = (long)((d->M + 127) / 128) * nbn * d->batch;
     // 256 CUs x 2 resident blocks: below ~3 full rounds of 128-row tiles the tail round dominates -> 64-row tiles
+    const bool amc_ = d->flags & DUPL_GEMM_A_MCONTIG, bnc_ = d->flags & DUPL_GEMM_B_NCONTIG;
     // 64-row tiles (4 resident blocks / CU) measured >= 128-row tiles on every DuPL shape (profiles/r01_gemm_tiles.txt)
     bool small = true;
     (void)nb128;
@@ -232,10 +263,19 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     dim3 grid(nbm * nbn, d->batch, ksplit), block(NT);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool amc = d->flags & DUPL_GEMM_A_MCONTIG, bnc = d->flags & DUPL_GEMM_B_NCONTIG;
-#define DUPL_GEMM_LAUNCH(AM, BNC)                                                               \
-    do {                                                                                        \
-        if (small) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64>), grid, block, 0, s, *d);   \
-        else hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128>), grid, block, 0, s, *d);        \
+    // fast-path predicate (see gemm_mainloop): 16-byte aligned operands incl. batch strides, K a multiple of the
+    // k-tile (split-K chunks are), m-/n-contiguous operands with a row count that is a multiple of 4
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool fast = al16(d->A) && al16(d->B) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) && (d->K % BK == 0) &&
+                (d->sA0 % 4 == 0) && (d->sA1 % 4 == 0) && (d->sB0 % 4 == 0) && (d->sB1 % 4 == 0);
+    if (amc_) fast = fast && (d->M % 4 == 0) && d->M >= 4;
+    if (bnc_) fast = fast && (d->N % 4 == 0) && d->N >= 4;
+#define DUPL_GEMM_LAUNCH(AM, BNC)                                                                              \
+    do {                                                                                                       \
+        if (small && fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, true>), grid, block, 0, s, *d);    \
+        else if (small) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, false>), grid, block, 0, s, *d);      \
+        else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, true>), grid, block, 0, s, *d);       \
+        else hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, false>), grid, block, 0, s, *d);                \
     } while (0)
     if (!amc && !bnc) DUPL_GEMM_LAUNCH(false, false);
     else if (!amc && bnc) DUPL_GEMM_LAUNCH(false, true);

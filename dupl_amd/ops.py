@@ -37,10 +37,26 @@ def _chk(t: Tensor, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+_FORWARD_PRECISION = "f32"
+
+
+def set_forward_precision(mode: str):
+    """"f32": every GEMM on the exact f32-input MFMA (default, the parity reference).
+    "h3": nn.Linear-style forwards on the split-fp16 3-pass MFMA kernel (dupl_gemm_h3, ~1e-6 relative error);
+    backward GEMMs always stay f32."""
+    global _FORWARD_PRECISION
+    assert mode in ("f32", "h3")
+    _FORWARD_PRECISION = mode
+
+
+def forward_precision() -> str:
+    return _FORWARD_PRECISION
+
+
 def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, flags: int = 0,
              bias: Optional[int] = None, res: Optional[int] = None, ldr: int = 0, aux: Optional[int] = None,
              ldaux: int = 0, alpha: float = 1.0, batch: int = 1, zdiv: int = 1,
-             sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sX=(0, 0), sBias=(0, 0)):
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sX=(0, 0), sBias=(0, 0), h3: bool = False):
     """Pointer-level GEMM; strides are in elements.  z -> (z // zdiv, z % zdiv)."""
     d = GemmDesc()
     d.A, d.B, d.C = A, B, C
@@ -55,7 +71,10 @@ def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int,
     d.sX0, d.sX1 = sX
     d.sBias0, d.sBias1 = sBias
     d.alpha, d.flags = alpha, flags
-    L().dupl_gemm_f32(ctypes.byref(d), _stream())
+    if h3:
+        L().dupl_gemm_h3(ctypes.byref(d), _stream())
+    else:
+        L().dupl_gemm_f32(ctypes.byref(d), _stream())
 
 
 def linear(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, gelu: bool = False, relu: bool = False,
@@ -71,7 +90,8 @@ def linear(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, gelu: bool = 
         fl |= _lib.GEMM_STORE_PRE
     gemm_raw(x.data_ptr(), W.data_ptr(), y.data_ptr(), M, N, K, x.stride(0), K, y.stride(0), flags=fl,
              bias=_p(bias), res=_p(res), ldr=(res.stride(0) if res is not None else 0),
-             aux=_p(store_pre), ldaux=(store_pre.stride(0) if store_pre is not None else 0))
+             aux=_p(store_pre), ldaux=(store_pre.stride(0) if store_pre is not None else 0),
+             h3=(_FORWARD_PRECISION == "h3"))
     return y
 
 
@@ -313,6 +333,16 @@ def refine_merge(lab_h: Tensor, lab_l: Tensor, ignore_index: float) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------ misc
+def to_device_async(host, dtype, device) -> Tensor:
+    """Small host table -> device without a stream synchronisation: staged through pinned memory and copied with
+    non_blocking=True (a plain torch.tensor(..., device=dev) copies from pageable memory and blocks the host until
+    every kernel queued before it has finished)."""
+    t = torch.as_tensor(np.asarray(host), dtype=dtype)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def fill_(t: Tensor, v: float):
     L().dupl_fill(t.data_ptr(), float(v), t.numel(), _stream())
     return t

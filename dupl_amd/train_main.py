@@ -1,0 +1,164 @@
+"""Shared body of train_final_voc.py / train_final_coco.py: the reference's launch surface (argparse flag names and
+defaults, LOCAL_RANK env, torchrun launch, DDP wrap, PolyWarmupAdamW, PAR, per-iteration loop, periodic checkpoint
+with the DDP `module.` key prefix) on the HIP engine.  Datasets / augmentation / validation are outside the hot
+path (SURVEY 2 "OUT"): batches are synthetic unless a DataLoader-like iterable is passed to `train(loader=...)`."""
+from __future__ import annotations
+
+import argparse
+import datetime
+import logging
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def build_parser(dataset: str) -> argparse.ArgumentParser:
+    voc = dataset == "voc"
+    p = argparse.ArgumentParser()
+    p.add_argument("--comment", default="_train_voc" if voc else "_train_coco", type=str, help="comment")
+    p.add_argument("--num_workers", default=10 if voc else 16, type=int, help="num_workers")
+    p.add_argument("--backend", default="nccl")
+    p.add_argument("--seed", default=0, type=int, help="fix random seed")
+    p.add_argument("--work_dir", default="work_dir_voc" if voc else "work_dir_coco_wseg", type=str)
+    if voc:
+        p.add_argument("--data_folder", default="/your_voc_dir", type=str, help="dataset folder")
+    else:
+        p.add_argument("--img_folder", default="/your_voc_dir", type=str, help="dataset folder")
+        p.add_argument("--label_folder", default="/home/wyc/Dataset/MSCOCO/SegmentationClass", type=str)
+    p.add_argument("--list_folder", default="datasets/voc" if voc else "datasets/coco", type=str)
+    p.add_argument("--train_set", default="train_aug" if voc else "train", type=str)
+    p.add_argument("--val_set", default="val" if voc else "val_part", type=str)
+    p.add_argument("--scales", default=(0.5, 2), help="random rescale in training")
+    p.add_argument("--backbone", default="deit_base_patch16_224", type=str, help="backbone")
+    p.add_argument("--pooling", default="gmp", type=str)
+    p.add_argument("--pretrained", default=False, help="path to a local ImageNet state_dict (no network here)")
+    if voc:
+        p.add_argument("--aux_layer", default=-3, type=int, help="aux_layer")
+    p.add_argument("--samples_per_gpu", default=2 if voc else 1, type=int, help="samples_per_gpu")
+    p.add_argument("--optimizer", default="PolyWarmupAdamW", type=str, help="optimizer")
+    p.add_argument("--warmup_iters", default=1500, type=int)
+    p.add_argument("--lr", default=6e-5, type=float)
+    p.add_argument("--warmup_lr", default=1e-6, type=float)
+    p.add_argument("--wt_decay", default=1e-2, type=float)
+    p.add_argument("--betas", default=(0.9, 0.999))
+    p.add_argument("--power", default=0.9, type=float)
+    p.add_argument("--save_ckpt", default=True, type=bool)
+    p.add_argument("--num_classes", default=21 if voc else 81, type=int)
+    p.add_argument("--crop_size", default=448, type=int)
+    p.add_argument("--ignore_index", default=255, type=int)
+    p.add_argument("--max_iters", default=20000 if voc else 80000, type=int)
+    p.add_argument("--log_iters", default=200, type=int)
+    p.add_argument("--eval_iters", default=2000 if voc else 4000, type=int)
+    p.add_argument("--cam_iters", default=2000 if voc else 8000, type=int)
+    p.add_argument("--high_thre", default=0.7 if voc else 0.65, type=float)
+    p.add_argument("--low_thre", default=0.25, type=float)
+    p.add_argument("--bkg_thre", default=0.5 if voc else 0.45, type=float)
+    p.add_argument("--cam_scales", default=(1.0, 0.5, 1.5))
+    if voc:
+        p.add_argument("--w_ptc", default=0.2, type=float)
+        p.add_argument("--w_seg", default=0.2, type=float)
+        p.add_argument("--w_seg_diff", default=2.0, type=float)
+    p.add_argument("--gmm_iters", default=8000 if voc else 32000, type=int)
+    p.add_argument("--gmm_valid_thre", default=1.0, type=float)
+    p.add_argument("--gamma", default=0.95, type=float)
+    # additions of this build
+    p.add_argument("--synthetic", default=True, type=bool, help="synthetic batches (the only data source in this build)")
+    p.add_argument("--start_iter", default=0, type=int, help="first n_iter (lets a short run exercise phase B)")
+    p.add_argument("--single_stream", action="store_true")
+    return p
+
+
+def setup_seed(seed):
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def train(args, dataset: str, loader=None):
+    from .ddp import DistributedDataParallel
+    from .model.model_dupl import siamese_network
+    from .model.PAR import PAR
+    from .synthetic import synthetic_batch
+    from .utils import train_helper
+    from . import trainer
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend)
+    device = torch.device("cuda", local_rank)
+    rank = dist.get_rank() if distributed else 0
+    voc = dataset == "voc"
+    aux_layer = args.aux_layer if voc else 9            # train_final_coco.py:148
+    model = siamese_network(backbone=args.backbone, num_classes=args.num_classes, pretrained=args.pretrained,
+                            aux_layer=aux_layer)
+    param_groups = model.get_param_groups()
+    model.to(device)
+    if not args.single_stream:
+        model.enable_dual_stream(True)
+    wrapped = DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True) if distributed else model
+    optim = train_helper.get_optimizer(param_groups, args).bind(model.flat_storage)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(device)
+    C = args.num_classes - 1
+    if voc:
+        sargs = trainer.StepArgs(cam_iters=args.cam_iters, gmm_iters=args.gmm_iters, max_iters=args.max_iters,
+                                 bkg_thre=args.bkg_thre, high_thre=args.high_thre, low_thre=args.low_thre,
+                                 ignore_index=args.ignore_index, w_ptc=args.w_ptc, w_seg=args.w_seg,
+                                 cam_scales=tuple(args.cam_scales), samples_per_gpu=args.samples_per_gpu)
+    else:
+        sargs = trainer.coco_step_args(cam_iters=args.cam_iters, gmm_iters=args.gmm_iters, max_iters=args.max_iters,
+                                       bkg_thre=args.bkg_thre, high_thre=args.high_thre, low_thre=args.low_thre,
+                                       ignore_index=args.ignore_index, cam_scales=tuple(args.cam_scales),
+                                       samples_per_gpu=args.samples_per_gpu)
+    it = iter(loader) if loader is not None else None
+    t0 = time.time()
+    acc = {}
+    for n_iter in range(args.start_iter, args.max_iters):
+        if it is not None:
+            _, inputs, cls_label, img_box, _ = next(it)
+            cls_host = cls_label
+            inputs, cls_label = inputs.to(device), cls_label.to(device)
+        else:
+            inputs, cls_label, img_box = synthetic_batch(args.samples_per_gpu, C, args.crop_size, seed=n_iter * 64 + rank)
+            cls_host = cls_label
+            inputs, cls_label = inputs.to(device), cls_label.to(device)
+        if n_iter >= args.gmm_iters:
+            if rank == 0:
+                logging.info("reached gmm_iters=%d: phase C is not part of this build yet (SURVEY 8f) -- stopping", args.gmm_iters)
+            break
+        out = trainer.train_step(wrapped, optim, par, inputs, cls_label, img_box, n_iter, sargs, cls_label_host=cls_host)
+        for k in ("cls_loss", "ptc_loss", "seg_loss", "sim_loss"):
+            acc[k] = acc.get(k, 0.0) + out[k].detach().reshape(-1)[0]     # device-side accumulation, no host sync
+        if (n_iter + 1) % args.log_iters == 0 and rank == 0:
+            n = args.log_iters
+            el = time.time() - t0
+            logging.info("Iter: %d; Elapsed: %.0fs; LR: %.3e; cls_loss: %.4f | ptc_loss: %.4f | seg_loss: %.4f | sim_loss: %.4f"
+                         % (n_iter + 1, el, optim.param_groups[0]["lr"], float(acc["cls_loss"]) / n, float(acc["ptc_loss"]) / n,
+                            float(acc["seg_loss"]) / n, float(acc["sim_loss"]) / n))
+            acc = {}
+        if (n_iter + 1) % args.eval_iters == 0 and rank == 0 and args.save_ckpt:
+            os.makedirs(args.ckpt_dir, exist_ok=True)
+            sd = wrapped.state_dict() if distributed else {"module." + k: v for k, v in model.state_dict().items()}
+            torch.save(sd, os.path.join(args.ckpt_dir, "checkpoint.pth"))     # keys prefixed `module.` (train_final_voc.py:519)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.destroy_process_group()
+    return True
+
+
+def main(dataset: str):
+    args = build_parser(dataset).parse_args()
+    timestamp = "{0:%Y-%m-%d-%H-%M-%S-%f}".format(datetime.datetime.now()) + args.comment
+    args.work_dir = os.path.join(args.work_dir, timestamp)
+    args.ckpt_dir = os.path.join(args.work_dir, "checkpoints")
+    args.pred_dir = os.path.join(args.work_dir, "predictions")
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
+    setup_seed(args.seed)
+    train(args, dataset)

@@ -38,31 +38,43 @@ class StepArgs:
     cam_scales: Tuple[float, ...] = (1.0, 0.5, 1.5)
     high_target: Tuple[float, ...] = VOC_HIGH_TARGET
     samples_per_gpu: int = 2
+    schedule: str = "voc"        # "voc": train_final_voc.py:194-456; "coco": train_final_coco.py:190-448
+    coco_switch_iter: int = 12000  # train_final_coco.py:241,312: bkg_v2 on aux CAMs until here, then dynamic thresholds
 
 
 def coco_step_args(**kw) -> StepArgs:
     """train_final_coco.py:75-86,161-162: cam 8000 / gmm 32000 / max 80000, bkg 0.45, high 0.65, target 0.55 x 80."""
     d = dict(cam_iters=8000, gmm_iters=32000, max_iters=80000, bkg_thre=0.45, high_thre=0.65, low_thre=0.25,
-             high_target=tuple([0.55] * 80))
+             high_target=tuple([0.55] * 80), schedule="coco")
     d.update(kw)
     return StepArgs(**d)
 
 
-def per_image_high_thres(cls_label: torch.Tensor, n_iter: int, args: StepArgs) -> torch.Tensor:
+def per_image_high_thres(cls_label: torch.Tensor, n_iter: int, args: StepArgs, device=None) -> torch.Tensor:
     """train_final_voc.py:263-275: cosine-descended per-class thresholds, per image the max over present classes.
-    Host-side (C floats) -> (b,) device tensor."""
+    Host-side (C floats) -> (b,) device tensor.  `cls_label` should be the HOST copy of the labels (no sync)."""
     C = cls_label.shape[1]
+    off = args.cam_iters if args.schedule == "voc" else args.coco_switch_iter   # train_final_coco.py:241
     thr = cosine_descent(np.ones(C, dtype=np.float32) * np.float32(args.high_thre),
                          np.asarray(args.high_target[:C], dtype=np.float32),
-                         n_iter - args.cam_iters, args.max_iters - args.cam_iters)
+                         n_iter - off, args.max_iters - off)
     thr = np.asarray(thr, dtype=np.float32)
     cl = cls_label.detach().cpu().numpy() > 0
     out = np.array([thr[cl[i]].max() if cl[i].any() else thr.max() for i in range(cl.shape[0])], dtype=np.float32)
-    return torch.from_numpy(out).to(cls_label.device)
+    device = device if device is not None else cls_label.device
+    return ops.to_device_async(out, torch.float32, device)
 
 
-def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs):
-    """Phase A (n_iter < cam_iters) and phase B loss assembly; returns (loss, dict of device scalars / tensors)."""
+def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs, cls_label_host=None):
+    """Phase A (n_iter < cam_iters) and phase B loss assembly; returns (loss, dict of device scalars / tensors).
+    `cls_label_host`: CPU copy of `cls_label` (the data loader has it anyway); with it the step contains no
+    host<->device synchronisation at all and the host can run a full step ahead of the GPU."""
+    if cls_label_host is None:
+        cls_label_host = cls_label.detach().cpu()
+    if n_iter >= args.gmm_iters:
+        raise NotImplementedError("phase C (GMM label-noise filter + consistency regularisation, train_final_voc.py:"
+                                  "358-436) is the next SURVEY 8(f) row; phases A and B are implemented")
+    coco = args.schedule == "coco"
     b, _, h, w = inputs.shape
     phase_a = n_iter < args.cam_iters
     inputs_denorm = ops.denormalize_img(inputs.contiguous()) if not phase_a else None
@@ -80,41 +92,60 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     cls_loss = msm(cls_1, cls_label) + msm(cls_aux_1, cls_label) + msm(cls_2, cls_label) + msm(cls_aux_2, cls_label)
 
     fh, fw = fmap_1.shape[2:]
-    if phase_a:
-        high = args.high_thre
-        to_label = cam_helper.cam_to_label
+    out = {"cams_1": cams_1, "cams_2": cams_2, "cams_aux_1": cams_aux_1, "cams_aux_2": cams_aux_2}
+    high = None
+    if phase_a and coco:
+        ptc_loss = torch.ones(1, device=inputs.device)     # train_final_coco.py:216: no PTC in phase A
     else:
-        high = per_image_high_thres(cls_label, n_iter, args)
-        to_label = cam_helper.cam_to_label_dynamic_cls
-    labels = []
-    for ca in (cams_aux_1, cams_aux_2):
-        r = ops.resize_bilinear(ca, fh, fw)
-        _, pl = to_label(r, cls_label=cls_label, img_box=img_box, ignore_mid=True, bkg_thre=args.bkg_thre, high_thre=high,
-                         low_thre=args.low_thre, ignore_index=args.ignore_index)
-        labels.append(pl)
-    ptc_loss = LS.get_masked_ptc_loss_from_label(fmap_1, labels[0], args.ignore_index) + \
-        LS.get_masked_ptc_loss_from_label(fmap_2, labels[1], args.ignore_index)
-
-    out = {"pseudo_label_aux_1": labels[0], "pseudo_label_aux_2": labels[1], "cams_1": cams_1, "cams_2": cams_2,
-           "cams_aux_1": cams_aux_1, "cams_aux_2": cams_aux_2}
+        if phase_a:
+            high = args.high_thre
+            to_label = cam_helper.cam_to_label
+        else:
+            high = per_image_high_thres(cls_label_host, n_iter, args, device=inputs.device)
+            to_label = cam_helper.cam_to_label_dynamic_cls
+        labels = []
+        for ca in (cams_aux_1, cams_aux_2):
+            r = ops.resize_bilinear(ca, fh, fw)
+            _, pl = to_label(r, cls_label=cls_label, img_box=img_box, ignore_mid=True, bkg_thre=args.bkg_thre,
+                             high_thre=high, low_thre=args.low_thre, ignore_index=args.ignore_index)
+            labels.append(pl)
+        ptc_loss = LS.get_masked_ptc_loss_from_label(fmap_1, labels[0], args.ignore_index) + \
+            LS.get_masked_ptc_loss_from_label(fmap_2, labels[1], args.ignore_index)
+        out["pseudo_label_aux_1"], out["pseudo_label_aux_2"] = labels
     if phase_a:
         seg_loss = torch.ones(1, device=inputs.device)
     else:
         # the reference passes cams * cls_label_rep (train_final_voc.py:336); refine only reads the channels of
         # PRESENT classes (label == 1), for which that product is the identity, so the (b,C,H,W) multiply is skipped
-        hmap = high.view(b, 1, 1, 1).expand(b, 1, h, w).contiguous()
-        r1 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_1, cls_labels=cls_label,
-                                                       high_thre_map=hmap, low_thre=args.low_thre,
-                                                       ignore_index=args.ignore_index, img_box=img_box)
-        r2 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_2, cls_labels=cls_label,
-                                                       high_thre_map=hmap, low_thre=args.low_thre,
-                                                       ignore_index=args.ignore_index, img_box=img_box)
+        if coco and n_iter <= args.coco_switch_iter:
+            # train_final_coco.py:312-322: scalar high threshold on the AUX CAMs
+            r1 = cam_helper.refine_cams_with_bkg_v2(par, inputs_denorm, cams=cams_aux_1, cls_labels=cls_label_host,
+                                                    high_thre=args.high_thre, low_thre=args.low_thre,
+                                                    ignore_index=args.ignore_index, img_box=img_box)
+            r2 = cam_helper.refine_cams_with_bkg_v2(par, inputs_denorm, cams=cams_aux_2, cls_labels=cls_label_host,
+                                                    high_thre=args.high_thre, low_thre=args.low_thre,
+                                                    ignore_index=args.ignore_index, img_box=img_box)
+        else:
+            hmap = high.view(b, 1, 1, 1).expand(b, 1, h, w).contiguous()
+            r1 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_1, cls_labels=cls_label_host,
+                                                           high_thre_map=hmap, low_thre=args.low_thre,
+                                                           ignore_index=args.ignore_index, img_box=img_box)
+            r2 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_2, cls_labels=cls_label_host,
+                                                           high_thre_map=hmap, low_thre=args.low_thre,
+                                                           ignore_index=args.ignore_index, img_box=img_box)
         # cross supervision: student 1 learns from student 2's labels and vice versa (train_final_voc.py:351-352)
         seg_loss = LS.get_seg_loss_lowres(segs_1, r2, (h, w), args.ignore_index) + \
             LS.get_seg_loss_lowres(segs_2, r1, (h, w), args.ignore_index)
         out["refined_1"], out["refined_2"] = r1, r2
     sim = LS.sim_loss(fmap_1, fmap_2)
-    if n_iter <= args.cam_iters:
+    if coco:    # hard-coded weights, train_final_coco.py:441-448
+        if n_iter <= 8000:
+            loss = 1.0 * cls_loss + 0.0 * ptc_loss + 0.0 * seg_loss + 0.0 * sim
+        elif n_iter <= args.coco_switch_iter:
+            loss = 1.0 * cls_loss + 0.0 * ptc_loss + 0.2 * seg_loss + 0.05 * sim
+        else:
+            loss = 1.0 * cls_loss + 0.2 * ptc_loss + 0.2 * seg_loss + 0.05 * sim
+    elif n_iter <= args.cam_iters:
         loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + 0.0 * seg_loss + 0.1 * sim
     else:
         loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + args.w_seg * seg_loss + 0.1 * sim
@@ -123,10 +154,10 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     return loss, out
 
 
-def train_step(model, optim, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs):
+def train_step(model, optim, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs, cls_label_host=None):
     """zero_grad -> losses -> backward -> optimiser step (train_final_voc.py:470-472)."""
     optim.zero_grad()
-    loss, out = compute_losses(model, par, inputs, cls_label, img_box, n_iter, args)
+    loss, out = compute_losses(model, par, inputs, cls_label, img_box, n_iter, args, cls_label_host)
     loss.sum().backward()
     optim.step()
     return out

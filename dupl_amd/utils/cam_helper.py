@@ -32,14 +32,30 @@ def _ms_cam(P, inputs, scales):
     patch = P.cfg.patch
     order = [1.0] + [s for s in scales if s != 1.0]   # 1.0 first, then tuple order (cam_helper.py:169-196)
     lows, lows_aux, sizes = [], [], []
+    # the scales are independent until the fusion: with scale streams enabled (siamese_network.enable_dual_stream)
+    # each scale's encoder pass runs on its own HIP stream so the small-grid 0.5x pass hides under the 1.5x pass
+    pool = P.store.scale_streams.get(P.student, []) if inputs.is_cuda else []
+    cur = torch.cuda.current_stream() if pool else None
     with torch.no_grad():
-        for s in order:
+        for i, s in enumerate(order):
             hs, ws = (h, w) if s == 1.0 else (int(s * h), int(s * w))
-            x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
-            cam_aux_t, cam_t = engine.cam_logits(P, x2)
+            st = pool[i % len(pool)] if pool else None
+            if st is not None:
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
+                    cam_aux_t, cam_t = engine.cam_logits(P, x2)
+                cam_t.record_stream(cur)
+                cam_aux_t.record_stream(cur)
+            else:
+                x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
+                cam_aux_t, cam_t = engine.cam_logits(P, x2)
             lows.append(cam_t)
             lows_aux.append(cam_aux_t)
             sizes.append((hs // patch, ws // patch))
+        if pool:
+            for st in pool:
+                cur.wait_stream(st)
         cam, mm = ops.cam_fuse(lows, sizes, b, C, h, w, row_off=1, ldc=C)
         ops.cam_normalise_(cam, mm)
         cam_aux, mm2 = ops.cam_fuse(lows_aux, sizes, b, C, h, w, row_off=1, ldc=C)
@@ -61,7 +77,9 @@ def _box_i32(img_box, device):
     if img_box is None:
         return None
     t = img_box if torch.is_tensor(img_box) else torch.as_tensor(img_box)
-    return t.to(device=device, dtype=torch.int32).contiguous()
+    if t.is_cuda:
+        return t.to(dtype=torch.int32).contiguous()
+    return ops.to_device_async(t.numpy(), torch.int32, device)
 
 
 def _cam_to_label(cam, cls_label, img_box, bkg_thre, high_thre, low_thre, ignore_mid, ignore_index):
@@ -72,7 +90,10 @@ def _cam_to_label(cam, cls_label, img_box, bkg_thre, high_thre, low_thre, ignore
     high = None
     if box is not None and ignore_mid:
         if torch.is_tensor(high_thre):
-            high = high_thre.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            if high_thre.is_cuda:
+                high = high_thre.to(dtype=torch.float32).reshape(-1).contiguous()
+            else:
+                high = ops.to_device_async(high_thre.reshape(-1).numpy(), torch.float32, dev)
             if high.numel() == 1:
                 high = high.repeat(b)
         else:
@@ -121,7 +142,7 @@ def _refine(ref_mod, images, cams, cls_labels, thr_scalar: Optional[float], thr_
     cams = cams.contiguous().float()
     dev = cams.device
     b, C, H, W = cams.shape
-    cl = cls_labels.detach().to("cpu")
+    cl = cls_labels.detach().to("cpu")   # pass a HOST copy of the labels to avoid a stream sync here
     keys_l, K_l = [], []
     for i in range(b):
         ks = [0] + [int(c) + 1 for c in torch.nonzero(cl[i])[:, 0].tolist()]
@@ -129,13 +150,16 @@ def _refine(ref_mod, images, cams, cls_labels, thr_scalar: Optional[float], thr_
         K_l.append(len(ks))
     Kmax = max(K_l)
     njobs = 2 * b   # [high jobs of images 0..b-1][low jobs of images 0..b-1]
-    keys = torch.zeros((njobs, Kmax), dtype=torch.int32)
+    import numpy as np
+    keys_h = np.zeros((njobs, Kmax), dtype=np.int32)
     for j in range(njobs):
         ks = keys_l[j % b]
-        keys[j, :len(ks)] = torch.tensor(ks, dtype=torch.int32)
-    job_img = torch.tensor([j % b for j in range(njobs)], dtype=torch.int32, device=dev)
-    job_K = torch.tensor([K_l[j % b] for j in range(njobs)], dtype=torch.int32, device=dev)
-    keys = keys.to(dev)
+        keys_h[j, :len(ks)] = ks
+    # one packed host->device transfer (pinned, non-blocking) for all job tables
+    tab = np.concatenate([np.array([j % b for j in range(njobs)], np.int32),
+                          np.array([K_l[j % b] for j in range(njobs)], np.int32), keys_h.reshape(-1)])
+    tab_d = ops.to_device_async(tab, torch.int32, dev)
+    job_img, job_K, keys = tab_d[:njobs], tab_d[njobs:2 * njobs], tab_d[2 * njobs:].view(njobs, Kmax)
     box = _box_i32(img_box, dev)
     half = ops.resize_bilinear(images, H // 2, W // 2)
     aff = ref_mod.affinity(half)

@@ -56,6 +56,10 @@ typedef struct dupl_gemm_desc {
     int32_t flags;
 } dupl_gemm_desc;
 int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
+/* Split-fp16 "3-pass" GEMM (v_mfma_f32_32x32x16_f16): same descriptor, fp32 in/out, operands split on the fly into
+ * fp16 hi + lo and accumulated in fp32 as lo*hi + hi*lo + hi*hi (~1e-6 relative error).  Forward layouts/epilogues
+ * only (no A_MCONTIG / B_NCONTIG / ACCUM / MUL_*).  Opt-in fast path for the nn.Linear forwards. */
+int dupl_gemm_h3(const dupl_gemm_desc* d, dupl_stream_t stream);
 /* tuning knob: force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic on the grid size) */
 int dupl_set_gemm_tile(int32_t rows);
 

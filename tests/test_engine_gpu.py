@@ -178,3 +178,37 @@ def test_optimizer_step_matches_oracle(dev):
         worst = max(worst, (v.cpu() - ref[k]).abs().max().item())
     print("optimizer: worst abs param diff after 3 steps", worst)
     assert worst < 1e-6   # fp32 round-off (fma contraction on the GPU vs separate mul/add in ATen's CPU AdamW)
+
+
+def test_coco_schedule_step_runs_and_matches_oracle_cls_loss(dev):
+    """81-class (COCO-shaped) tiny siamese: phase-A and phase-B COCO-schedule steps run end to end; the
+    classification loss (the only non-zero-weight term before iteration 8000) matches the oracle."""
+    import torch.nn.functional as F
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd import trainer
+    from oracle import dupl_oracle as O
+    NC = 81
+    cfg = O.ViTConfig(embed_dim=96, depth=4, num_heads=3, head_classes=10, aux_layer=9 % 4)
+    pp = O.make_siamese_params(cfg, NC, seed=4)
+    model = siamese_network("tiny_test", num_classes=NC, pretrained=False, aux_layer=9 % 4)
+    model.load_state_dict(pp, strict=True)
+    model.to(dev)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    inputs, cls_label, img_box = O.synthetic_batch(2, NC - 1, 64, seed=9)
+    sargs = trainer.coco_step_args()
+    for n_iter in (100, 9000, 20000):
+        model.flat_storage.grad.zero_()
+        loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, n_iter, sargs)
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        p1, p2 = O.sub_params(pp, "branch1."), O.sub_params(pp, "branch2.")
+        with torch.no_grad():
+            c1, _, _, a1 = O.network_forward(p1, inputs, cfg)
+            c2, _, _, a2 = O.network_forward(p2, inputs, cfg)
+        msm = F.multilabel_soft_margin_loss
+        ref = msm(c1, cls_label) + msm(a1, cls_label) + msm(c2, cls_label) + msm(a2, cls_label)
+        assert abs(float(out["cls_loss"].item()) - float(ref.item())) < 2e-5
+        assert torch.isfinite(loss).all()
+        if n_iter > 8000:
+            assert set(torch.unique(out["refined_1"]).tolist()) <= set(range(NC)) | {255}
