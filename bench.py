@@ -98,6 +98,23 @@ def cpu_baseline(args, C):
                       f"torch {torch.__version__} CPU, {cores} threads): {dt:.1f} s"}
 
 
+def pmc_traffic_per_launch(kernel_prefix="gemm_f32_kernel<false, false"):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_final_pmc_hbm.txt:
+    separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same workload, summarised by
+    tools/rocpd_pmc.py).  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md 'HBM');
+    it counts L2->fabric requests, i.e. Infinity-Cache hits are included.  None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.txt")
+    try:
+        for line in open(path):
+            if line.startswith(kernel_prefix):
+                parts = line.split()
+                calls, fetch_kib, write_kib = float(parts[-4]), float(parts[-2]), float(parts[-1])
+                return round((2.0 * fetch_kib + write_kib) * 1024.0 / calls)
+    except OSError:
+        pass
+    return None
+
+
 class GemmTimer:
     """Event-pairs around every launch of the dominant kernel (the k-contiguous x k-contiguous 'NT' GEMM that every
     forward Linear maps to) on the stream it is launched on, plus its algorithmic FLOPs (2*M*N*K per launch)."""
@@ -105,6 +122,7 @@ class GemmTimer:
     def __init__(self):
         self.pairs = []
         self.flops = 0.0
+        self.bytes = 0.0
         self.n = 0
 
     def install(self):
@@ -123,6 +141,7 @@ class GemmTimer:
             e1.record(s)
             timer.pairs.append((e0, e1))
             timer.flops += 2.0 * M * N * K * kw.get("batch", 1)
+            timer.bytes += 4.0 * (M * K + N * K + M * N) * kw.get("batch", 1)
             timer.n += 1
             return r
 
@@ -135,7 +154,7 @@ class GemmTimer:
     def result(self):
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in self.pairs)
-        return ms, self.flops, self.n
+        return ms, self.flops, self.n, self.bytes
 
 
 def log(msg):
@@ -206,12 +225,14 @@ def main():
         timer = GemmTimer()
         timer.install()
         step(args.warmup + args.steps)
-        gms, gflops, gn = timer.result()
+        gms, gflops, gn, gbytes = timer.result()
         timer.remove()
         ach = gflops / (gms * 1e-3)
         roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<false,false> (v_mfma_f32_32x32x2_f32)", "achieved": round(ach / 1e12, 2),
                 "peak": round(PEAK_F32_MFMA / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4),
-                "traffic": None, "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
+                "traffic": pmc_traffic_per_launch(), "traffic_unit": "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, "
+                "profiles/r01_final_pmc_hbm.txt)", "algorithmic_bytes_per_launch": round(gbytes / max(gn, 1)),
+                "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
                 "kernel_share_of_step": round(gms / ms, 3),
                 "step_frac_of_peak": round(imgs_per_s / world * FLOP_PER_IMG_PHASE_AB / PEAK_F32_MFMA, 4),
                 "note": "HIP event pairs around every launch of the kernel during one extra step run right after the timed "

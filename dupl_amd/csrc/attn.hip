@@ -107,8 +107,16 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[kt2][e] = 0.f;
             const float* kp = Ks + (kt2 * 32 + l31) * SK + hf * HH;
+            // K fragment reads run two k-steps ahead of the MFMAs that consume them
+            float kf0 = kp[0], kf1 = kp[1];
 #pragma unroll
-            for (int st = 0; st < HH; ++st) s[kt2] = MFMA32(kp[st], qf[st], s[kt2]);
+            for (int st = 0; st < HH; ++st) {
+                const float kc = kf0;
+                kf0 = kf1;
+                if (st + 2 < HH) kf1 = kp[st + 2];
+                __builtin_amdgcn_sched_barrier(0);
+                s[kt2] = MFMA32(kc, qf[st], s[kt2]);
+            }
         }
         const int kbase = t * KT;
         if (kbase + KT > N) {
@@ -141,14 +149,31 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(const float* __restrict__
         for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        {
+            // V fragment reads run one (key-step) ahead of the MFMAs
+            float vn[ND];
+            {
+                const float* vp = Vs + acc_row(0, hf) * SV + l31;
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float* vp = Vs + (kt2 * 32 + acc_row(e, hf)) * SV + l31;
-#pragma unroll
-                for (int d = 0; d < ND; ++d) o[d] = MFMA32(vp[d * 32], s[kt2][e], o[d]);
+                for (int d = 0; d < ND; ++d) vn[d] = vp[d * 32];
             }
+#pragma unroll
+            for (int ke = 0; ke < 32; ++ke) {
+                const int kt2 = ke >> 4, e = ke & 15;
+                float vc[ND];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) vc[d] = vn[d];
+                if (ke + 1 < 32) {
+                    const int k2 = (ke + 1) >> 4, e2 = (ke + 1) & 15;
+                    const float* vp = Vs + (k2 * 32 + acc_row(e2, hf)) * SV + l31;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) vn[d] = vp[d * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) o[d] = MFMA32(vc[d], s[kt2][e], o[d]);
+            }
+        }
     }
     if (!wave_active) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
