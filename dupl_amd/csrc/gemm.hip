@@ -73,7 +73,7 @@ __device__ __forceinline__ void store_chunk(const float4 v, float* __restrict__ 
 }
 
 // BM = 128: wave tile 64x64 (2x2 MFMA tiles).  BM = 64: wave tile 32x64 (1x2) -- twice the blocks for small grids.
-template <bool A_MC, bool B_NC, int BM, bool FAST>
+template <bool A_MC, bool B_NC, int BM, int FAST>   // FAST: 0 guarded loader, 1 branch-free, 2 branch-free + k-range mask
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
     constexpr int MI = BM / 64;                 // 32-row MFMA tiles per wave along m
     constexpr int SA = A_MC ? (BM + 4) : (BM + 1);
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
         if (kbeg >= kend) return;
     }
     const int nt = (kend - kbeg + BK - 1) / BK;
-    // FAST (decided on the host, dupl_gemm_f32): every k-tile full and every row 16-byte aligned -> branch-free
-    // clamped float4 loads; otherwise the fully guarded loader.
+    // FAST (decided on the host, dupl_gemm_f32): every row 16-byte aligned (and K % 4 == 0 for k-contiguous
+    // operands) -> branch-free clamped float4 loads with a multiplicative k-range mask; otherwise the guarded loader.
     const float* a_rd = As + wm * (BM / 2) + l31;
     const float* b_rd = Bs + wn * 64 + l31;
 
@@ -137,8 +137,14 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
         for (int i = 0; i < NA; ++i) {
             const int c = tid + NT * i;
             if (FAST) {
-                if (!A_MC) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + (c >> 3), p.M - 1) * p.lda + k0 + ((c & 7) << 2));
-                else ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(k0 + c / (BM / 4)) * p.lda + min(m0 + ((c % (BM / 4)) << 2), p.M - 4));
+                // branch-free: clamp the address into the matrix, then zero the chunk if its k lies past the range
+                const int kk = A_MC ? k0 + c / (BM / 4) : k0 + ((c & 7) << 2);
+                const int kc = min(kk, A_MC ? kend - 1 : kend - 4);
+                float4 v;
+                if (!A_MC) v = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + (c >> 3), p.M - 1) * p.lda + kc);
+                else v = *reinterpret_cast<const float4*>(A + (size_t)kc * p.lda + min(m0 + ((c % (BM / 4)) << 2), p.M - 4));
+                const bool keep = FAST == 1 || kk < kend;   // FAST == 1: K is a multiple of the k-tile, no mask needed
+                ra[i] = make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
             } else {
                 ra[i] = load_chunk<A_MC, BM>(A, p.lda, m0, k0, p.M, kend, a_vec, c);
             }
@@ -147,8 +153,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
         for (int i = 0; i < NB; ++i) {
             const int c = tid + NT * i;
             if (FAST) {
-                if (!B_NC) rb[i] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + (c >> 3), p.N - 1) * p.ldb + k0 + ((c & 7) << 2));
-                else rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(k0 + c / (BN / 4)) * p.ldb + min(n0 + ((c % (BN / 4)) << 2), p.N - 4));
+                const int kk = B_NC ? k0 + c / (BN / 4) : k0 + ((c & 7) << 2);
+                const int kc = min(kk, B_NC ? kend - 1 : kend - 4);
+                float4 v;
+                if (!B_NC) v = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + (c >> 3), p.N - 1) * p.ldb + kc);
+                else v = *reinterpret_cast<const float4*>(B + (size_t)kc * p.ldb + min(n0 + ((c % (BN / 4)) << 2), p.N - 4));
+                const bool keep = FAST == 1 || kk < kend;
+                rb[i] = make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
             } else {
                 rb[i] = load_chunk<B_NC, BN>(B, p.ldb, n0, k0, p.N, kend, b_vec, c);
             }
@@ -266,16 +277,21 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     // fast-path predicate (see gemm_mainloop): 16-byte aligned operands incl. batch strides, K a multiple of the
     // k-tile (split-K chunks are), m-/n-contiguous operands with a row count that is a multiple of 4
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    bool fast = al16(d->A) && al16(d->B) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) && (d->K % BK == 0) &&
+    bool fast = al16(d->A) && al16(d->B) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) && d->K >= 4 &&
                 (d->sA0 % 4 == 0) && (d->sA1 % 4 == 0) && (d->sB0 % 4 == 0) && (d->sB1 % 4 == 0);
     if (amc_) fast = fast && (d->M % 4 == 0) && d->M >= 4;
+    else fast = fast && (d->K % 4 == 0);          // float4 chunks run along k: whole chunks are in or out
     if (bnc_) fast = fast && (d->N % 4 == 0) && d->N >= 4;
-#define DUPL_GEMM_LAUNCH(AM, BNC)                                                                              \
-    do {                                                                                                       \
-        if (small && fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, true>), grid, block, 0, s, *d);    \
-        else if (small) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, false>), grid, block, 0, s, *d);      \
-        else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, true>), grid, block, 0, s, *d);       \
-        else hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, false>), grid, block, 0, s, *d);                \
+    else fast = fast && (d->K % 4 == 0);
+    const bool kfull = (d->K % BK) == 0;   // split-K chunks are multiples of BK, so only the global tail matters
+#define DUPL_GEMM_LAUNCH(AM, BNC)                                                                                  \
+    do {                                                                                                           \
+        if (small && fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 1>), grid, block, 0, s, *d);  \
+        else if (small && fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 2>), grid, block, 0, s, *d);      \
+        else if (small) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 0>), grid, block, 0, s, *d);              \
+        else if (fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 1>), grid, block, 0, s, *d);     \
+        else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 2>), grid, block, 0, s, *d);              \
+        else hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 0>), grid, block, 0, s, *d);                        \
     } while (0)
     if (!amc && !bnc) DUPL_GEMM_LAUNCH(false, false);
     else if (!amc && bnc) DUPL_GEMM_LAUNCH(false, true);
