@@ -48,7 +48,7 @@ def _ctype(decl: str):
         return ctypes.c_void_p
     base = d.replace("const", "").split()
     ty = base[0]
-    return {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+    return {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "uint8_t": ctypes.c_uint8,
             "int": ctypes.c_int, "double": ctypes.c_double}[ty]
 
 

@@ -106,11 +106,15 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 // ----------------------------------------------------------------------------------------------- seg loss
 // logits token-major [b][h*w][C1]; output pixel (Y,X) of the bilinear (align_corners False) upsample to HxW.
 // One thread per output pixel; a 16x16 pixel block offset by 8 touches a 2x2 group of low-res cells.
-template <bool BWD>
+// MODE 0: forward sums; 1: backward; 2: per-pixel CE map (written to `dlogits` as a (b,H,W) plane, 0 where ignored).
+// flip: the low-res logits are read w-flipped (torch.flip(segs_aug, dims=[3]) before the upsample,
+// train_final_voc.py:407-414).  balanced: 1 = get_seg_loss' 0.5*(bg mean + fg mean); 0 = plain mean over valid pixels.
+template <int MODE>
 __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__ logits, const void* __restrict__ label,
                                                        int is_i64, int ignore, float* __restrict__ sums,
                                                        const float* __restrict__ gscale, float* __restrict__ dlogits, int C1,
-                                                       int h, int w, int H, int W) {
+                                                       int h, int w, int H, int W, int flip, int balanced) {
+    constexpr bool BWD = MODE == 1;
     __shared__ float red[16];
     const int b = blockIdx.z;
     const int fy = H / h, fx = W / w;  // integer factors (16)
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
         y0 = (int)ry; x0 = (int)rx;
         y1 = y0 + (y0 < h - 1 ? 1 : 0); x1 = x0 + (x0 < w - 1 ? 1 : 0);
         ly = ry - y0; lx = rx - x0;
+        if (flip) { x0 = w - 1 - x0; x1 = w - 1 - x1; }
         const long li = ((long)b * H + Y) * W + X;
         lab = is_i64 ? (long)reinterpret_cast<const long long*>(label)[li] : (long)reinterpret_cast<const float*>(label)[li];
     }
@@ -148,6 +153,10 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
         const float ce = (mx + logf(se)) - zl;
         if (lab == 0) { ce_bg = ce; n_bg = 1.f; } else { ce_fg = ce; n_fg = 1.f; }
     }
+    if (MODE == 2) {
+        if (inb) dlogits[((long)b * H + Y) * W + X] = ce_bg + ce_fg;
+        return;
+    }
     if (!BWD) {
         ce_bg = block_sum(ce_bg, red); n_bg = block_sum(n_bg, red); ce_fg = block_sum(ce_fg, red); n_fg = block_sum(n_fg, red);
         if (threadIdx.x == 0 && (n_bg + n_fg) > 0.f) {
@@ -158,19 +167,23 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
         // px of the shifted tile) share the same 2x2 cells, so reduce over the wave first: 4*C1 atomics per wave.
         const float g = gscale[0];
         float coef = 0.f;
-        if (active) coef = lab == 0 ? 0.5f * g / (sums[1] + 1e-6f) : 0.5f * g / (sums[3] + 1e-6f);
+        if (active) {
+            if (balanced) coef = lab == 0 ? 0.5f * g / (sums[1] + 1e-6f) : 0.5f * g / (sums[3] + 1e-6f);
+            else coef = g / (sums[1] + sums[3]);
+        }
         float* Dl = dlogits + (long)b * h * w * C1;
-        if ((fy & 15) || (fx & 15)) {
+        if ((fy & 15) || (fx & 15) || (H % h) || (W % w)) {
             // generic factors: cells are not wave-uniform -> per-lane atomics (compat path, e.g. full-res logits)
             if (!active) return;
             const float lse_ = mx + logf(se);
             for (int c = 0; c < C1; ++c) {
                 const float z = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
                 const float gz = coef * (expf(z - lse_) - (c == lab ? 1.f : 0.f));
+                // all four taps, even when the border clamp makes two of them the same cell (their weights add up)
                 atomicAdd(&Dl[(long)(y0 * w + x0) * C1 + c], gz * hy * hx);
-                if (x1 != x0) atomicAdd(&Dl[(long)(y0 * w + x1) * C1 + c], gz * hy * lx);
-                if (y1 != y0) atomicAdd(&Dl[(long)(y1 * w + x0) * C1 + c], gz * ly * hx);
-                if (y1 != y0 && x1 != x0) atomicAdd(&Dl[(long)(y1 * w + x1) * C1 + c], gz * ly * lx);
+                atomicAdd(&Dl[(long)(y0 * w + x1) * C1 + c], gz * hy * lx);
+                atomicAdd(&Dl[(long)(y1 * w + x0) * C1 + c], gz * ly * hx);
+                atomicAdd(&Dl[(long)(y1 * w + x1) * C1 + c], gz * ly * lx);
             }
             return;
         }
@@ -207,6 +220,50 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
             }
         }
     }
+}
+
+// Consistency-regularisation targets (train_final_voc.py:416-426): per full-res pixel of the bilinearly up-sampled
+// logits: pseudo = argmax_c, conf = max_c softmax; keep pseudo where the OTHER student's refined label is `ignore`
+// and conf > thr, else `ignore`.  count[0] += number of kept pixels.
+__global__ __launch_bounds__(256) void seg_pseudo_label_kernel(const float* __restrict__ logits, const float* __restrict__ other,
+                                                               int ignore, float thr, long long* __restrict__ out,
+                                                               float* __restrict__ count, int C1, int h, int w, int H, int W) {
+    __shared__ float red[16];
+    const int b = blockIdx.y;
+    const int P = blockIdx.x * blockDim.x + threadIdx.x;
+    float kept = 0.f;
+    if (P < H * W) {
+        const int Y = P / W, X = P - Y * W;
+        const float ry = fmaxf(((float)h / (float)H) * (Y + 0.5f) - 0.5f, 0.f);
+        const float rx = fmaxf(((float)w / (float)W) * (X + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)ry, x0 = (int)rx;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly = ry - y0, lx = rx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float* L = logits + (long)b * h * w * C1;
+        const float* p00 = L + (long)(y0 * w + x0) * C1;
+        const float* p01 = L + (long)(y0 * w + x1) * C1;
+        const float* p10 = L + (long)(y1 * w + x0) * C1;
+        const float* p11 = L + (long)(y1 * w + x1) * C1;
+        float mx = -INFINITY, se = 0.f;
+        int arg = 0;
+        for (int c = 0; c < C1; ++c) {
+            const float z = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+            if (z > mx) { se = se * expf(mx - z) + 1.f; mx = z; arg = c; } else se += expf(z - mx);
+        }
+        const float conf = 1.f / se;   // softmax of the arg-max class
+        const long li = ((long)b * H + Y) * W + X;
+        const bool keep = ((int)other[li] == ignore) && (conf > thr);
+        out[li] = keep ? arg : ignore;
+        kept = keep ? 1.f : 0.f;
+    }
+    kept = block_sum(kept, red);
+    if (threadIdx.x == 0 && kept > 0.f) atomicAdd(count, kept);
+}
+
+// label[i] = value where mask[i] != 0   (GMM noise filter write-back, train_final_voc.py:381,393)
+__global__ void mask_fill_kernel(float* __restrict__ label, const unsigned char* __restrict__ mask, float value, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        if (mask[i]) label[i] = value;
 }
 
 // ----------------------------------------------------------------------------------------------- cosine
@@ -334,21 +391,47 @@ extern "C" int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const
 }
 
 extern "C" int dupl_seg_loss_fwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* sums,
-                                 int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, dupl_stream_t s) {
-    if (!logits || !label || !sums || b <= 0 || C1 <= 0 || h <= 0 || w <= 0 || H % h || W % w) return DUPL_ERR_ARG;
+                                 int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip,
+                                 dupl_stream_t s) {
+    if (!logits || !label || !sums || b <= 0 || C1 <= 0 || h <= 0 || w <= 0 || H < h || W < w) return DUPL_ERR_ARG;
     dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
-    hipLaunchKernelGGL(seg_loss_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index, sums,
-                       (const float*)nullptr, (float*)nullptr, C1, h, w, H, W);
+    hipLaunchKernelGGL(seg_loss_kernel<0>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index, sums,
+                       (const float*)nullptr, (float*)nullptr, C1, h, w, H, W, flip, 1);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_seg_ce_map(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* ce_map,
+                               int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip,
+                               dupl_stream_t s) {
+    if (!logits || !label || !ce_map || b <= 0 || C1 <= 0 || h <= 0 || w <= 0 || H < h || W < w) return DUPL_ERR_ARG;
+    dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
+    hipLaunchKernelGGL(seg_loss_kernel<2>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index,
+                       (float*)nullptr, (const float*)nullptr, ce_map, C1, h, w, H, W, flip, 1);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, const float* sums,
                                  const float* gscale, float* dlogits, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H,
-                                 int32_t W, dupl_stream_t s) {
-    if (!logits || !label || !sums || !gscale || !dlogits || b <= 0 || C1 <= 0 || H % h || W % w) return DUPL_ERR_ARG;
+                                 int32_t W, int32_t flip, int32_t balanced, dupl_stream_t s) {
+    if (!logits || !label || !sums || !gscale || !dlogits || b <= 0 || C1 <= 0 || H < h || W < w) return DUPL_ERR_ARG;
     dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
-    hipLaunchKernelGGL(seg_loss_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index,
-                       const_cast<float*>(sums), gscale, dlogits, C1, h, w, H, W);
+    hipLaunchKernelGGL(seg_loss_kernel<1>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index,
+                       const_cast<float*>(sums), gscale, dlogits, C1, h, w, H, W, flip, balanced);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_seg_pseudo_label(const float* logits, const float* other_label, int32_t ignore_index, float conf_thr,
+                                     int64_t* out_label, float* count, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H,
+                                     int32_t W, dupl_stream_t s) {
+    if (!logits || !other_label || !out_label || !count || b <= 0 || C1 <= 0 || h <= 0 || w <= 0) return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(seg_pseudo_label_kernel, dim3((H * W + 255) / 256, b), dim3(256), 0, (hipStream_t)s, logits, other_label,
+                       ignore_index, conf_thr, (long long*)out_label, count, C1, h, w, H, W);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_mask_fill(float* label, const uint8_t* mask, float value, int64_t n, dupl_stream_t s) {
+    if (!label || !mask || n <= 0) return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(mask_fill_kernel, dim3(ew_grid((long)n)), dim3(256), 0, (hipStream_t)s, label, mask, value, (long)n);
     return dupl_launch_status();
 }
 

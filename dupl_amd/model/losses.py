@@ -70,8 +70,11 @@ def get_masked_ptc_loss_from_label(inputs, label, ignore_index=255):
 
 
 class _SegLoss(torch.autograd.Function):
+    """balanced=True: get_seg_loss; balanced=False: sum CE / #valid (the consistency loss); flip: the low-res logits are
+    read w-flipped before the up-sampling."""
+
     @staticmethod
-    def forward(ctx, seg, label, H, W, ignore_index):
+    def forward(ctx, seg, label, H, W, ignore_index, flip=False, balanced=True):
         b, C1, h, w = seg.shape
         logits = _tokens_from_nchw(seg)
         is_i64 = int(label.dtype == torch.int64)
@@ -80,21 +83,24 @@ class _SegLoss(torch.autograd.Function):
         label = label.contiguous()
         sums = ops.zeros((4,), seg.device)
         L().dupl_seg_loss_fwd(logits.data_ptr(), label.data_ptr(), is_i64, ignore_index, sums.data_ptr(), b, C1, h, w, H, W,
-                              _stream())
-        loss = 0.5 * (sums[0] / (sums[1] + 1e-6) + sums[2] / (sums[3] + 1e-6))
+                              int(flip), _stream())
+        if balanced:
+            loss = 0.5 * (sums[0] / (sums[1] + 1e-6) + sums[2] / (sums[3] + 1e-6))
+        else:
+            loss = (sums[0] + sums[2]) / (sums[1] + sums[3]).clamp_min(1.0)   # no valid pixel -> 0 (reference: seg_loss * 0)
         ctx.save_for_backward(logits, label, sums)
-        ctx.meta = (b, C1, h, w, H, W, ignore_index, is_i64)
+        ctx.meta = (b, C1, h, w, H, W, ignore_index, is_i64, int(flip), int(balanced))
         return loss
 
     @staticmethod
     def backward(ctx, g):
         logits, label, sums = ctx.saved_tensors
-        b, C1, h, w, H, W, ignore_index, is_i64 = ctx.meta
+        b, C1, h, w, H, W, ignore_index, is_i64, flip, balanced = ctx.meta
         g = g.reshape(1).contiguous().float()
         dl = ops.zeros(tuple(logits.shape), logits.device)
         L().dupl_seg_loss_bwd(logits.data_ptr(), label.data_ptr(), is_i64, ignore_index, sums.data_ptr(), g.data_ptr(),
-                              dl.data_ptr(), b, C1, h, w, H, W, _stream())
-        return ops.tokens_to_nchw(dl, b, h * w, C1, h, w, skip_cls=False), None, None, None, None
+                              dl.data_ptr(), b, C1, h, w, H, W, flip, balanced, _stream())
+        return ops.tokens_to_nchw(dl, b, h * w, C1, h, w, skip_cls=False), None, None, None, None, None, None
 
 
 def get_seg_loss_lowres(seg, label, size, ignore_index=255):
@@ -106,6 +112,47 @@ def get_seg_loss_lowres(seg, label, size, ignore_index=255):
 def get_seg_loss(pred, label, ignore_index=255):
     """losses.py:24-39 on already up-sampled logits (reference signature)."""
     return _SegLoss.apply(pred, label, pred.shape[2], pred.shape[3], ignore_index)
+
+
+def seg_ce_map(seg, label, size, ignore_index=255, flip=False):
+    """Detached per-pixel ce_criterion(F.interpolate(seg, size), label) (train_final_voc.py:360-361) -> (b,H,W) float32,
+    fused (the (b,C1,H,W) up-sampled logits are never materialised)."""
+    b, C1, h, w = seg.shape
+    H, W = int(size[0]), int(size[1])
+    logits = _tokens_from_nchw(seg.detach())
+    is_i64 = int(label.dtype == torch.int64)
+    label = label.contiguous() if is_i64 else label.float().contiguous()
+    out = torch.empty((b, H, W), device=seg.device, dtype=torch.float32)
+    L().dupl_seg_ce_map(logits.data_ptr(), label.data_ptr(), is_i64, ignore_index, out.data_ptr(), b, C1, h, w, H, W, int(flip),
+                        _stream())
+    return out
+
+
+def seg_pseudo_label(seg, other_label, size, ignore_index=255, conf_thre=0.9):
+    """Consistency targets (train_final_voc.py:416-426): argmax of the up-sampled `seg` where `other_label` (the OTHER
+    student's refined pseudo-label, float32 (b,H,W)) is ignore_index and the max-softmax exceeds conf_thre, else
+    ignore_index.  Returns (pseudo_seg int64 (b,H,W), count 1-element float tensor)."""
+    b, C1, h, w = seg.shape
+    H, W = int(size[0]), int(size[1])
+    logits = _tokens_from_nchw(seg.detach())
+    out = torch.empty((b, H, W), device=seg.device, dtype=torch.int64)
+    count = ops.zeros((1,), seg.device)
+    L().dupl_seg_pseudo_label(logits.data_ptr(), other_label.float().contiguous().data_ptr(), ignore_index, float(conf_thre),
+                              out.data_ptr(), count.data_ptr(), b, C1, h, w, H, W, _stream())
+    return out, count
+
+
+def get_reg_loss(seg_aug, pseudo_seg, size, ignore_index=255):
+    """ce_criterion(F.interpolate(torch.flip(seg_aug, dims=[3]), size), pseudo_seg).sum() / #valid
+    (train_final_voc.py:407-434); the caller guards the #valid == 0 case like the reference."""
+    return _SegLoss.apply(seg_aug, pseudo_seg, int(size[0]), int(size[1]), ignore_index, True, False)
+
+
+def mask_fill_(label, mask, value):
+    """label[mask] = value, in place (label float32, mask uint8/bool of the same shape)."""
+    m = mask.to(torch.uint8).contiguous()
+    L().dupl_mask_fill(label.data_ptr(), m.data_ptr(), float(value), label.numel(), _stream())
+    return label
 
 
 class _CosSim(torch.autograd.Function):

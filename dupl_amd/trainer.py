@@ -38,6 +38,8 @@ class StepArgs:
     cam_scales: Tuple[float, ...] = (1.0, 0.5, 1.5)
     high_target: Tuple[float, ...] = VOC_HIGH_TARGET
     samples_per_gpu: int = 2
+    gmm_valid_thre: float = 1.0
+    gamma: float = 0.95
     schedule: str = "voc"        # "voc": train_final_voc.py:194-456; "coco": train_final_coco.py:190-448
     coco_switch_iter: int = 12000  # train_final_coco.py:241,312: bkg_v2 on aux CAMs until here, then dynamic thresholds
 
@@ -65,15 +67,19 @@ def per_image_high_thres(cls_label: torch.Tensor, n_iter: int, args: StepArgs, d
     return ops.to_device_async(out, torch.float32, device)
 
 
-def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs, cls_label_host=None):
-    """Phase A (n_iter < cam_iters) and phase B loss assembly; returns (loss, dict of device scalars / tensors).
-    `cls_label_host`: CPU copy of `cls_label` (the data loader has it anyway); with it the step contains no
-    host<->device synchronisation at all and the host can run a full step ahead of the GPU."""
+def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs, cls_label_host=None,
+                   inputs_aug=None):
+    """Loss assembly of one iteration, phases A / B / C; returns (loss, dict of device scalars / tensors).
+    `cls_label_host`: CPU copy of `cls_label` (the data loader has it anyway); with it phases A and B contain no
+    host<->device synchronisation at all and the host can run a full step ahead of the GPU.
+    Phase C (n_iter >= gmm_iters, train_final_voc.py:358-436) needs `inputs_aug`, the strongly augmented + w-flipped
+    batch from the data pipeline (train_final_voc.py:191); its GMM filter is the reference's host-side sklearn call
+    (one device->host transfer of the CE maps per step, like the reference)."""
     if cls_label_host is None:
         cls_label_host = cls_label.detach().cpu()
-    if n_iter >= args.gmm_iters:
-        raise NotImplementedError("phase C (GMM label-noise filter + consistency regularisation, train_final_voc.py:"
-                                  "358-436) is the next SURVEY 8(f) row; phases A and B are implemented")
+    phase_c = n_iter >= args.gmm_iters
+    if phase_c and inputs_aug is None:
+        raise ValueError("phase C needs inputs_aug (strongly augmented, w-flipped batch)")
     coco = args.schedule == "coco"
     b, _, h, w = inputs.shape
     phase_a = n_iter < args.cam_iters
@@ -84,7 +90,10 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
         lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=1),
         lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=2))
 
-    res = model(inputs)
+    if phase_c:
+        res = model(torch.cat([inputs, inputs_aug], dim=0), need_sp=True)     # train_final_voc.py:291-295
+    else:
+        res = model(inputs)
     cls_1, segs_1, fmap_1, cls_aux_1 = res["branch1"]
     cls_2, segs_2, fmap_2, cls_aux_2 = res["branch2"]
 
@@ -133,10 +142,28 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
             r2 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_2, cls_labels=cls_label_host,
                                                            high_thre_map=hmap, low_thre=args.low_thre,
                                                            ignore_index=args.ignore_index, img_box=img_box)
+        if phase_c:
+            # GMM label-noise filter on the detached per-pixel CE of each student w.r.t. ITS OWN labels (:360-394)
+            from .utils.gmm_filter import gmm_noise_masks
+            hits = []
+            for segs_k, r_k in ((segs_1, r1), (segs_2, r2)):
+                ce = LS.seg_ce_map(segs_k, r_k, (h, w), args.ignore_index)
+                mask, nh = gmm_noise_masks(ce.cpu().numpy(), r_k.cpu().numpy(), args.gmm_valid_thre, args.gamma)
+                hits.append(nh)
+                if nh:
+                    LS.mask_fill_(r_k, ops.to_device_async(mask, torch.uint8, inputs.device), float(args.ignore_index))
+            out["gmm_hits"] = hits
         # cross supervision: student 1 learns from student 2's labels and vice versa (train_final_voc.py:351-352)
         seg_loss = LS.get_seg_loss_lowres(segs_1, r2, (h, w), args.ignore_index) + \
             LS.get_seg_loss_lowres(segs_2, r1, (h, w), args.ignore_index)
         out["refined_1"], out["refined_2"] = r1, r2
+        if phase_c:
+            # consistency regularisation on the 0.75x strong-aug branch (:407-436)
+            ps1, n1 = LS.seg_pseudo_label(segs_1, r2, (h, w), args.ignore_index, 0.9)
+            ps2, n2 = LS.seg_pseudo_label(segs_2, r1, (h, w), args.ignore_index, 0.9)
+            reg_loss = LS.get_reg_loss(res["branch1_aug"], ps1, (h, w), args.ignore_index) + \
+                LS.get_reg_loss(res["branch2_aug"], ps2, (h, w), args.ignore_index)
+            out.update(pseudo_seg_1=ps1, pseudo_seg_2=ps2, n_uncertain=(n1, n2), reg_loss=reg_loss)
     sim = LS.sim_loss(fmap_1, fmap_2)
     if coco:    # hard-coded weights, train_final_coco.py:441-448
         if n_iter <= 8000:
@@ -145,19 +172,24 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
             loss = 1.0 * cls_loss + 0.0 * ptc_loss + 0.2 * seg_loss + 0.05 * sim
         else:
             loss = 1.0 * cls_loss + 0.2 * ptc_loss + 0.2 * seg_loss + 0.05 * sim
+            if phase_c:
+                loss = loss + 0.05 * out["reg_loss"]
     elif n_iter <= args.cam_iters:
         loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + 0.0 * seg_loss + 0.1 * sim
-    else:
+    elif n_iter <= args.gmm_iters:
         loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + args.w_seg * seg_loss + 0.1 * sim
+    else:
+        loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + args.w_seg * seg_loss + 0.1 * sim + 0.05 * out["reg_loss"]
     out.update(loss=loss, cls_loss=cls_loss, ptc_loss=ptc_loss, seg_loss=seg_loss, sim_loss=sim, cls_1=cls_1, segs_1=segs_1,
                fmap_1=fmap_1, cls_aux_1=cls_aux_1, cls_2=cls_2, segs_2=segs_2, fmap_2=fmap_2, cls_aux_2=cls_aux_2)
     return loss, out
 
 
-def train_step(model, optim, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs, cls_label_host=None):
+def train_step(model, optim, par, inputs, cls_label, img_box, n_iter: int, args: StepArgs, cls_label_host=None,
+               inputs_aug=None):
     """zero_grad -> losses -> backward -> optimiser step (train_final_voc.py:470-472)."""
     optim.zero_grad()
-    loss, out = compute_losses(model, par, inputs, cls_label, img_box, n_iter, args, cls_label_host)
+    loss, out = compute_losses(model, par, inputs, cls_label, img_box, n_iter, args, cls_label_host, inputs_aug)
     loss.sum().backward()
     optim.step()
     return out

@@ -188,12 +188,25 @@ int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const float* nor
  * F.interpolate(segs, (H,W)), train_final_voc.py:345-352).  logits token-major [b][h*w][C1]; label (b,H,W) float32
  * or int64 (is_i64).  sums[4] += {ce_bg, n_bg, ce_fg, n_fg} (zero first). */
 int dupl_seg_loss_fwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* sums,
-                      int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, dupl_stream_t s);
+                      int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip, dupl_stream_t s);
+/* same fused upsample + CE, but the per-pixel value ce_map (b,H,W) (0 where label == ignore): the detached
+ * ce_criterion(segs, refined_label) maps the GMM noise filter is fitted on (train_final_voc.py:360-361).
+ * flip != 0 reads the low-res logits w-flipped (torch.flip(segs_aug, dims=[3]), :407-408). */
+int dupl_seg_ce_map(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* ce_map,
+                    int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip, dupl_stream_t s);
+/* consistency-regularisation targets (train_final_voc.py:416-426): pseudo = argmax of the up-sampled logits where the
+ * OTHER student's refined label == ignore and max-softmax > conf_thr, else ignore; count[0] += kept pixels. */
+int dupl_seg_pseudo_label(const float* logits, const float* other_label, int32_t ignore_index, float conf_thr,
+                          int64_t* out_label, float* count, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H,
+                          int32_t W, dupl_stream_t s);
+/* label[i] = value where mask[i] != 0 (noise-mask write-back, train_final_voc.py:381,393) */
+int dupl_mask_fill(float* label, const uint8_t* mask, float value, int64_t n, dupl_stream_t s);
 /* dlogits (token-major, zero first) += gscale[0] * d loss / d logits (wave-reduced atomics when H/h, W/w are multiples
- * of 16; per-lane atomics otherwise) */
+ * of 16; per-lane atomics otherwise).  balanced = 1: get_seg_loss' 0.5*(bg mean + fg mean); 0: plain mean over the
+ * valid pixels (sum CE / count: the consistency loss, train_final_voc.py:430-434). */
 int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, const float* sums,
                       const float* gscale, float* dlogits, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W,
-                      dupl_stream_t s);
+                      int32_t flip, int32_t balanced, dupl_stream_t s);
 /* nn.CosineSimilarity(dim=-1) over the n tokens of every (image, channel) (train_final_voc.py:247-254); a, b
  * token-major (element (i, t, c) at + i*img_stride + t*ld + c).  out [B][c]; stats [B][c][3] = {dot, |a|^2, |b|^2}. */
 int dupl_cos_sim_fwd(const float* a, const float* b, float* out, float* stats, int32_t B, int32_t n, int32_t c,

@@ -516,12 +516,38 @@ class StepArgs:
     w_seg: float = 0.2
     cam_scales: Tuple[float, ...] = (1.0, 0.5, 1.5)
     high_target: Tuple[float, ...] = VOC_HIGH_TARGET
+    gmm_valid_thre: float = 1.0
+    gamma: float = 0.95
+
+
+def gmm_noise_filter_(ce_map: Tensor, refined: Tensor, gmm_valid_thre: float, gamma: float) -> int:
+    """GMM label-noise filter of one student, in place on `refined` (train_final_voc.py:363-394).
+    Third-party dependency: sklearn.mixture.GaussianMixture (reference pins scikit-learn 1.0.2; 1.7.2 here),
+    called exactly as the reference calls it.  Returns the number of images whose labels were filtered."""
+    from sklearn.mixture import GaussianMixture
+    b, h, w = refined.shape
+    roi = (refined != 0) & (refined != 255)
+    hit = 0
+    for i in range(b):
+        m = ce_map[i][roi[i]]
+        if (m > 0.1).sum().item() > 1000:
+            gmm = GaussianMixture(n_components=2, max_iter=10, tol=1e-2, reg_covar=5e-4, random_state=0)
+            gmm.fit(m[m > 0.1].unsqueeze(-1).cpu().detach().numpy())
+            means = gmm.means_
+            if abs(means[0, 0] - means[1, 0]) > gmm_valid_thre:
+                noise_idx = gmm.means_.argmax()
+                prob = gmm.predict_proba(ce_map[i].reshape(-1).unsqueeze(-1).cpu().detach().numpy())
+                noise = torch.tensor(prob[:, noise_idx] > gamma).reshape(h, w) & (refined[i] != 0)
+                refined[i][noise] = 255
+                hit += 1
+    return hit
 
 
 def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tensor, img_box,
-                      n_iter: int, cfg: ViTConfig, args: StepArgs = StepArgs()):
-    """One iteration's loss assembly for phases A and B (train_final_voc.py:194-352,440-456).
-    Returns (loss, dict of detached pieces).  `params` leaves may require grad."""
+                      n_iter: int, cfg: ViTConfig, args: StepArgs = StepArgs(), inputs_aug: Optional[Tensor] = None):
+    """One iteration's loss assembly for phases A, B and C (train_final_voc.py:194-456).
+    Returns (loss, dict of detached pieces).  `params` leaves may require grad.  Phase C (n_iter >= gmm_iters) needs
+    `inputs_aug`, the strongly augmented + w-flipped batch the data pipeline supplies (train_final_voc.py:191)."""
     p1, p2 = sub_params(params, "branch1."), sub_params(params, "branch2.")
     d1 = {k: v.detach() for k, v in p1.items()}
     d2 = {k: v.detach() for k, v in p2.items()}
@@ -553,6 +579,7 @@ def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tens
         masked_ptc_loss(fmap_2, label_to_aff_mask(labels[1]))
     pieces = {"pseudo_label_aux_1": labels[0], "pseudo_label_aux_2": labels[1],
               "cams_1": cams_1, "cams_2": cams_2, "cams_aux_1": cams_aux_1, "cams_aux_2": cams_aux_2}
+    reg = torch.zeros(1)
     if phase_a:
         seg = torch.ones(1)
     else:
@@ -562,13 +589,48 @@ def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tens
         r2 = refine_cams(inputs_denorm, cams_2 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box)
         s1 = F.interpolate(segs_1, size=(h, w), mode="bilinear", align_corners=False)
         s2 = F.interpolate(segs_2, size=(h, w), mode="bilinear", align_corners=False)
-        seg = seg_loss(s1, r2.long(), args.ignore_index) + seg_loss(s2, r1.long(), args.ignore_index)
+        if n_iter < args.gmm_iters:
+            seg_1, seg_2 = seg_loss(s1, r2.long(), args.ignore_index), seg_loss(s2, r1.long(), args.ignore_index)
+            seg = seg_1 + seg_2
+            reg = seg_1 * 0 + seg_2 * 0
+        else:
+            # ---- phase C: GMM noise filter (train_final_voc.py:358-394) ...
+            ce1 = F.cross_entropy(s1, r1.long(), ignore_index=args.ignore_index, reduction="none").detach()
+            ce2 = F.cross_entropy(s2, r2.long(), ignore_index=args.ignore_index, reduction="none").detach()
+            pieces["ce_map_1"] = ce1
+            pieces["gmm_hits"] = (gmm_noise_filter_(ce1, r1, args.gmm_valid_thre, args.gamma),
+                                  gmm_noise_filter_(ce2, r2, args.gmm_valid_thre, args.gamma))
+            seg_1, seg_2 = seg_loss(s1, r2.long(), args.ignore_index), seg_loss(s2, r1.long(), args.ignore_index)
+            seg = seg_1 + seg_2
+            # ---- ... and consistency regularisation on the 0.75x aug branch (model_dupl.py:194-205, :407-436)
+            xa = F.interpolate(inputs_aug, scale_factor=0.75, mode="bilinear", align_corners=False)
+            sa1 = network_forward(p1, xa, cfg)[1]
+            sa2 = network_forward(p2, xa, cfg)[1]
+            sa1 = F.interpolate(torch.flip(sa1, dims=[3]), size=(h, w), mode="bilinear", align_corners=False)
+            sa2 = F.interpolate(torch.flip(sa2, dims=[3]), size=(h, w), mode="bilinear", align_corners=False)
+            ps1, ps2 = s1.detach().max(1)[1], s2.detach().max(1)[1]
+            cf1, cf2 = torch.softmax(s1.detach(), dim=1).max(1)[0], torch.softmax(s2.detach(), dim=1).max(1)[0]
+            un1 = (r2 == args.ignore_index) & (cf1 > 0.9)
+            un2 = (r1 == args.ignore_index) & (cf2 > 0.9)
+            ps1[~un1] = args.ignore_index
+            ps2[~un2] = args.ignore_index
+            reg_1, reg_2 = seg_1 * 0.0, seg_2 * 0.0
+            if un1.sum() > 0:
+                reg_1 = F.cross_entropy(sa1, ps1, ignore_index=args.ignore_index, reduction="none").sum() / un1.sum()
+            if un2.sum() > 0:
+                reg_2 = F.cross_entropy(sa2, ps2, ignore_index=args.ignore_index, reduction="none").sum() / un2.sum()
+            reg = reg_1 + reg_2
+            pieces["pseudo_seg_1"], pieces["pseudo_seg_2"] = ps1, ps2
+            pieces["n_uncertain"] = (int(un1.sum()), int(un2.sum()))
         pieces["refined_1"], pieces["refined_2"] = r1, r2
     sim = sim_loss(fmap_1, fmap_2)
     if n_iter <= args.cam_iters:
         loss = 1.0 * cls_loss + args.w_ptc * ptc + 0.0 * seg + 0.1 * sim
+    elif n_iter <= args.gmm_iters:
+        loss = 1.0 * cls_loss + args.w_ptc * ptc + args.w_seg * seg + 0.1 * sim + 0.00 * reg
     else:
-        loss = 1.0 * cls_loss + args.w_ptc * ptc + args.w_seg * seg + 0.1 * sim
+        loss = 1.0 * cls_loss + args.w_ptc * ptc + args.w_seg * seg + 0.1 * sim + 0.05 * reg
+    pieces["reg_loss"] = reg.detach()
     pieces.update(cls_loss=cls_loss.detach(), ptc_loss=ptc.detach(), seg_loss=seg.detach(),
                   sim_loss=sim.detach(), loss=loss.detach(), cls_1=cls_1.detach(), segs_1=segs_1.detach(),
                   fmap_1=fmap_1.detach(), cls_aux_1=cls_aux_1.detach(), cls_2=cls_2.detach(),

@@ -160,14 +160,22 @@ def main():
     par = R["PAR"](num_iter=10, dilations=[1, 2, 4, 8, 12, 24])
     args = O.StepArgs()
 
-    def ref_step(n_iter):
+    from sklearn.mixture import GaussianMixture
+    ce_criterion = nn.CrossEntropyLoss(ignore_index=args.ignore_index, reduction="none")
+
+    def ref_step(n_iter, inputs=inputs, cls_label=cls_label, img_box=img_box, inputs_aug=None):
         sia.zero_grad()
         inputs_denorm = O.denormalize_img2(inputs.clone())   # utils.imutils not importable (torchvision)
         cams_1, cams_aux_1 = CH.multi_scale_cam2_siamese(sia, inputs=inputs, scales=args.cam_scales, branch=1)
         cams_2, cams_aux_2 = CH.multi_scale_cam2_siamese(sia, inputs=inputs, scales=args.cam_scales, branch=2)
-        res = sia(inputs)
+        if n_iter < args.gmm_iters:
+            res = sia(inputs)
+        else:
+            res = sia(torch.cat([inputs, inputs_aug], dim=0), need_sp=True)     # train_final_voc.py:291-295
+            segs_1_aug, segs_2_aug = res["branch1_aug"], res["branch2_aug"]
         cls_1, segs_1, fmap_1, cls_aux_1 = res["branch1"]
         cls_2, segs_2, fmap_2, cls_aux_2 = res["branch2"]
+        seg_lowres = (segs_1.detach().clone(), segs_2.detach().clone())
         msm = F.multilabel_soft_margin_loss
         cls_loss = msm(cls_1, cls_label) + msm(cls_aux_1, cls_label) + msm(cls_2, cls_label) + msm(cls_aux_2, cls_label)
         b, _, h, w = inputs.shape
@@ -181,6 +189,8 @@ def main():
                 lab.append(pl)
             seg_loss = torch.ones(1)
             refined = None
+            reg_loss = torch.zeros(1)
+            extra_c = {}
         else:
             thr = O.cosine_descent(torch.ones(NC - 1) * args.high_thre, torch.tensor(args.high_target),
                                    n_iter - args.cam_iters, args.max_iters - args.cam_iters)
@@ -207,7 +217,57 @@ def main():
                                                    ignore_index=args.ignore_index, img_box=img_box)
             s1 = F.interpolate(segs_1, size=r1.shape[1:], mode="bilinear", align_corners=False)
             s2 = F.interpolate(segs_2, size=r2.shape[1:], mode="bilinear", align_corners=False)
-            seg_loss = R["losses"].get_seg_loss(s1, r2.type(torch.long)) + R["losses"].get_seg_loss(s2, r1.type(torch.long))
+            reg_loss = torch.zeros(1)
+            extra_c = {}
+            if n_iter < args.gmm_iters:
+                seg_loss = R["losses"].get_seg_loss(s1, r2.type(torch.long)) + R["losses"].get_seg_loss(s2, r1.type(torch.long))
+            else:
+                # ---- phase C, composed exactly as train_final_voc.py:358-436
+                refined_pre = (r1.clone(), r2.clone())
+                sl1 = ce_criterion(s1, r1.type(torch.long)).detach()
+                sl2 = ce_criterion(s2, r2.type(torch.long)).detach()
+                roi1 = (r1 != 0).bool() & (r1 != 255).bool()
+                roi2 = (r2 != 0).bool() & (r2 != 255).bool()
+                hits = [0, 0]
+                for i in range(b):
+                    for k, (sl, roi, rr) in enumerate(((sl1, roi1, r1), (sl2, roi2, r2))):
+                        m = sl[i][roi[i]]
+                        if (m > 0.1).sum().item() > 1000:
+                            gmm = GaussianMixture(n_components=2, max_iter=10, tol=1e-2, reg_covar=5e-4, random_state=0)
+                            gmm.fit(m[m > 0.1].unsqueeze(-1).cpu().detach().numpy())
+                            means = gmm.means_
+                            if abs(means[0, 0] - means[1, 0]) > 1.0:
+                                noise_idx = gmm.means_.argmax()
+                                prob = gmm.predict_proba(sl[i].view(-1).unsqueeze(-1).cpu().detach().numpy())
+                                noise_mask = torch.tensor(prob[:, noise_idx] > 0.95).reshape(h, w)
+                                noise_mask = noise_mask & (rr[i] != 0).bool()
+                                rr[i][noise_mask] = 255
+                                hits[k] += 1
+                seg_loss_1 = R["losses"].get_seg_loss(s1, r2.type(torch.long), ignore_index=args.ignore_index)
+                seg_loss_2 = R["losses"].get_seg_loss(s2, r1.type(torch.long), ignore_index=args.ignore_index)
+                seg_loss = seg_loss_1 + seg_loss_2
+                sa1 = torch.flip(segs_1_aug, dims=[3])
+                sa2 = torch.flip(segs_2_aug, dims=[3])
+                sa1 = F.interpolate(sa1, size=inputs_denorm.shape[2:], mode="bilinear", align_corners=False)
+                sa2 = F.interpolate(sa2, size=inputs_denorm.shape[2:], mode="bilinear", align_corners=False)
+                pseudo_seg_1 = s1.detach().data.max(1)[1]
+                pseudo_seg_2 = s2.detach().data.max(1)[1]
+                conf1 = torch.softmax(s1.detach(), dim=1).max(1)[0]
+                conf2 = torch.softmax(s2.detach(), dim=1).max(1)[0]
+                un1 = (r2 == args.ignore_index).bool() & (conf1 > 0.9)
+                un2 = (r1 == args.ignore_index).bool() & (conf2 > 0.9)
+                pseudo_seg_1[~un1] = args.ignore_index
+                pseudo_seg_2[~un2] = args.ignore_index
+                reg_1, reg_2 = seg_loss_1 * 0.0, seg_loss_2 * 0.0
+                if un1.sum() > 0:
+                    reg_1 = (ce_criterion(sa1, pseudo_seg_1)).sum() / un1.sum()
+                if un2.sum() > 0:
+                    reg_2 = (ce_criterion(sa2, pseudo_seg_2)).sum() / un2.sum()
+                reg_loss = reg_1 + reg_2
+                extra_c = dict(refined_pre_1=refined_pre[0].to(torch.uint8), refined_pre_2=refined_pre[1].to(torch.uint8),
+                               ce_map_1=sl1[:, ::2, ::2].clone(), gmm_hits=np.array(hits), pseudo_seg_1=pseudo_seg_1.to(torch.uint8),
+                               pseudo_seg_2=pseudo_seg_2.to(torch.uint8), n_uncertain=np.array([int(un1.sum()), int(un2.sum())]),
+                               reg_loss=reg_loss.detach(), segs_1_aug=segs_1_aug.detach(), segs_2_aug=segs_2_aug.detach())
             refined = (r1, r2)
         ptc = R["losses"].get_masked_ptc_loss(fmap_1, CH.label_to_aff_mask(lab[0])) + \
             R["losses"].get_masked_ptc_loss(fmap_2, CH.label_to_aff_mask(lab[1]))
@@ -217,13 +277,16 @@ def main():
         sim = (1 + cs(f1.detach(), f2).mean()) + (1 + cs(f2.detach(), f1).mean())
         if n_iter <= args.cam_iters:
             loss = 1.0 * cls_loss + args.w_ptc * ptc + 0.0 * seg_loss + 0.1 * sim
+        elif n_iter <= args.gmm_iters:
+            loss = 1.0 * cls_loss + args.w_ptc * ptc + args.w_seg * seg_loss + 0.1 * sim + 0.00 * reg_loss
         else:
-            loss = 1.0 * cls_loss + args.w_ptc * ptc + args.w_seg * seg_loss + 0.1 * sim
+            loss = 1.0 * cls_loss + args.w_ptc * ptc + args.w_seg * seg_loss + 0.1 * sim + 0.05 * reg_loss
         loss.backward()
         grads = {k: (v.grad.clone() if v.grad is not None else None) for k, v in sia.named_parameters()}
         return dict(loss=loss.detach(), cls_loss=cls_loss.detach(), ptc=ptc.detach(), seg=seg_loss.detach(),
                     sim=sim.detach(), lab=lab, refined=refined, cams=(cams_1, cams_aux_1, cams_2, cams_aux_2),
-                    grads=grads, segs=(segs_1.detach(), segs_2.detach()), fmaps=(fmap_1.detach(), fmap_2.detach()))
+                    grads=grads, segs=seg_lowres, fmaps=(fmap_1.detach(), fmap_2.detach()),
+                    extra_c=(extra_c if n_iter >= args.cam_iters else {}))
 
     for tag, n_iter in (("A", 100), ("B", 5000)):
         ref = ref_step(n_iter)
@@ -264,6 +327,43 @@ def main():
             cams_aux_2=ref["cams"][3][:, ::4],
             segs_1=ref["segs"][0], segs_2=ref["segs"][1], fmap_1=ref["fmaps"][0], fmap_2=ref["fmaps"][1],
             **extra, **gsave)
+
+    print("[2c] tiny siamese: phase C (GMM noise filter via sklearn + consistency regularisation), 128^2 inputs")
+    inputs_c, cls_c, box_c = O.synthetic_batch(2, NC - 1, 128, seed=9)
+    aug_c, _, _ = O.synthetic_batch(2, NC - 1, 128, seed=19)
+    aug_c = torch.flip(0.7 * inputs_c + 0.3 * aug_c, dims=[3]).contiguous()   # stand-in for RandAugment + flip (imutils.py:305-317)
+    n_c = 9000
+    # random-init logits are never confident: sharpen the seg heads so that the GMM filter (needs > 1000 roi pixels with
+    # CE > 0.1 and two well separated modes) and the confidence-gated consistency loss are actually exercised
+    pp_c = {k: (v * 40.0 if k.endswith("decoder.conv8.weight") else v.clone()) for k, v in pp.items()}
+    sia.load_state_dict(pp_c, strict=True)
+    ref = ref_step(n_c, inputs_c, cls_c, box_c, aug_c)
+    sia.load_state_dict(pp, strict=True)
+    leaf = {k: v.clone().requires_grad_(k.split(".", 1)[1] != "encoder.pos_embed") for k, v in pp_c.items()}
+    loss, pc = O.train_step_losses(leaf, inputs_c, cls_c, box_c, n_c, cfg, args, inputs_aug=aug_c)
+    loss.backward()
+    print(f"    phase C: loss ref {ref['loss'].item():.6f} oracle {loss.item():.6f}; gmm hits {ref['extra_c']['gmm_hits']}, "
+          f"uncertain px {ref['extra_c']['n_uncertain']}, reg {ref['extra_c']['reg_loss'].item():.6f}")
+    close(loss, ref["loss"], what="loss C")
+    close(pc["reg_loss"], ref["extra_c"]["reg_loss"], what="reg C")
+    same(pc["refined_1"], ref["refined"][0], "refined_1 C", budget=2)
+    same(pc["pseudo_seg_1"].to(torch.uint8), ref["extra_c"]["pseudo_seg_1"], "pseudo_seg_1 C")
+    worst, gsave = 0.0, {}
+    for k, g in ref["grads"].items():
+        og = leaf[k].grad
+        if g is None:
+            continue
+        worst = max(worst, (og - g).abs().max().item() / max(g.abs().max().item(), 1e-12))
+        gsave["grad." + k] = g if g.numel() <= 4096 else g.reshape(-1)[::7].clone()
+    print(f"      worst relative grad err over {len(gsave)} tensors: {worst:.2e}")
+    assert worst < 5e-4
+    ec = ref["extra_c"]
+    npz("tiny_step_C", n_iter=n_c, loss=ref["loss"], cls_loss=ref["cls_loss"], ptc_loss=ref["ptc"], seg_loss=ref["seg"],
+        sim_loss=ref["sim"], reg_loss=ec["reg_loss"], refined_1=ref["refined"][0].to(torch.uint8),
+        refined_2=ref["refined"][1].to(torch.uint8), refined_pre_1=ec["refined_pre_1"], refined_pre_2=ec["refined_pre_2"],
+        ce_map_1_sub=ec["ce_map_1"], gmm_hits=ec["gmm_hits"], pseudo_seg_1=ec["pseudo_seg_1"], pseudo_seg_2=ec["pseudo_seg_2"],
+        n_uncertain=ec["n_uncertain"], segs_1=ref["segs"][0], segs_2=ref["segs"][1], segs_1_aug=ec["segs_1_aug"],
+        segs_2_aug=ec["segs_2_aug"], **gsave)
 
     # ------------------------------------------------------------------ optimiser
     print("[3] PolyWarmupAdamW: 3 steps on two small tensors")

@@ -212,3 +212,60 @@ def test_coco_schedule_step_runs_and_matches_oracle_cls_loss(dev):
         assert torch.isfinite(loss).all()
         if n_iter > 8000:
             assert set(torch.unique(out["refined_1"]).tolist()) <= set(range(NC)) | {255}
+
+
+def test_tiny_phase_c_matches_reference(dev, golden_dir):
+    """Phase C: sklearn GMM noise filter (exercised: both students hit) + confidence-gated consistency loss on the
+    0.75x aug branch, vs the reference composition (tests/golden/tiny_step_C.npz)."""
+    pytest.importorskip("sklearn")
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd import trainer
+    from oracle import dupl_oracle as O
+    g = load(golden_dir, "tiny_step_C")
+    NC = 21
+    pp = O.make_siamese_params(O.VIT_TINY, NC, seed=2)
+    pp = {k: (v * 40.0 if k.endswith("decoder.conv8.weight") else v) for k, v in pp.items()}
+    model = siamese_network("tiny_test", num_classes=NC, pretrained=False, aux_layer=-3)
+    model.load_state_dict(pp, strict=True)
+    model.to(dev)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    inputs, cls_label, img_box = O.synthetic_batch(2, NC - 1, 128, seed=9)
+    aug, _, _ = O.synthetic_batch(2, NC - 1, 128, seed=19)
+    aug = torch.flip(0.7 * inputs + 0.3 * aug, dims=[3]).contiguous()
+    args = trainer.StepArgs()
+    model.flat_storage.grad.zero_()
+    loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, int(g["n_iter"]), args,
+                                       cls_label_host=cls_label, inputs_aug=aug.to(dev))
+    loss.sum().backward()
+    model.flat_storage.wait_streams()
+    torch.cuda.synchronize()
+    assert list(out["gmm_hits"]) == list(g["gmm_hits"]) == [1, 1]
+    for k in ("refined_1", "refined_2", "pseudo_seg_1", "pseudo_seg_2"):
+        mism = int((out[k].cpu().numpy().astype(np.uint8) != g[k]).sum())
+        print(f"{k}: {mism} mismatches of {g[k].size}")
+        assert mism <= 6, k     # argmax / threshold near-ties only
+    nu = [int(out["n_uncertain"][0].item()), int(out["n_uncertain"][1].item())]
+    assert abs(nu[0] - int(g["n_uncertain"][0])) <= 6 and abs(nu[1] - int(g["n_uncertain"][1])) <= 6
+    for k in ("loss", "cls_loss", "ptc_loss", "seg_loss", "sim_loss", "reg_loss"):
+        ref = float(np.asarray(g[k]).reshape(-1)[0])
+        got = float(out[k].reshape(-1)[0].item())
+        print(f"{k}: ref {ref:.6f} got {got:.6f}")
+        assert abs(got - ref) <= 2e-3 * max(1.0, abs(ref)), k
+    worst, errs = 0.0, []
+    for k in g.files:
+        if not k.startswith("grad."):
+            continue
+        name = k[5:]
+        got = model.flat_storage.view(0 if name.startswith("branch1.") else 1, name.split(".", 1)[1], grad=True).cpu().numpy()
+        ref = g[k]
+        if ref.shape != got.shape:
+            got = got.reshape(-1)[::7]
+        e = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+        errs.append((float(e), name))
+        if e > worst:
+            worst, wname = e, name
+    errs.sort(reverse=True)
+    print("phase C grad errs:", [(f"{e:.1e}", n) for e, n in errs[:12]], "... median", errs[len(errs) // 2])
+    print(f"phase C: worst rel grad err {worst:.2e} ({wname})")
+    assert worst < 2e-3

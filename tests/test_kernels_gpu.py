@@ -374,3 +374,55 @@ def test_conv_and_adamw(dev, golden_dir):
             adamw_segment(p, gr, m, v, t + 1, lr0 * mult, 0.9, 0.999, 1e-8, 0.01)
             ref = torch.from_numpy(g[f"p{nm}{t}"].reshape(-1))
             assert (p[:n].cpu() - ref).abs().max().item() < 5e-7
+
+
+@pytest.mark.parametrize("h,H", [(6, 128), (8, 128), (4, 64), (21, 448)])
+@pytest.mark.parametrize("flip", [False, True])
+@pytest.mark.parametrize("balanced", [True, False])
+def test_seg_loss_variants(dev, h, H, flip, balanced):
+    """Fused upsample + CE: integer (wave-reduced atomics) and non-integer (per-lane atomics, border taps that collapse
+    onto one cell) scale factors, w-flipped low-res logits, balanced (get_seg_loss) and plain-mean (consistency) forms."""
+    from dupl_amd.model import losses as LS
+    g = torch.Generator().manual_seed(h * 1000 + H)
+    seg = torch.randn(2, 21, h, h, generator=g) * 3
+    lab = torch.randint(0, 21, (2, H, H), generator=g)
+    lab[torch.rand(2, H, H, generator=g) < 0.6] = 255
+    s = seg.clone().to(dev).requires_grad_(True)
+    l = LS._SegLoss.apply(s, lab.to(dev), H, H, 255, flip, balanced)
+    l.backward()
+    sr = seg.clone().double().requires_grad_(True)
+    x = torch.flip(sr, dims=[3]) if flip else sr
+    up = F.interpolate(x, size=(H, H), mode="bilinear", align_corners=False)
+    ce = F.cross_entropy(up, lab, ignore_index=255, reduction="none")
+    if balanced:
+        bg, fg = (lab == 0), (lab != 0) & (lab != 255)
+        ref = 0.5 * ((ce * bg).sum() / (bg.sum() + 1e-6) + (ce * fg).sum() / (fg.sum() + 1e-6))
+    else:
+        ref = ce.sum() / (lab != 255).sum()
+    ref.backward()
+    assert abs(l.item() - ref.item()) < 5e-6 * max(1.0, abs(ref.item()))
+    assert relerr(s.grad, sr.grad) < 1e-5
+    cm = LS.seg_ce_map(seg.to(dev), lab.to(dev), (H, H), 255, flip=flip)
+    assert (cm.cpu().double() - ce).abs().max().item() < 2e-5
+
+
+def test_seg_pseudo_label_and_mask_fill(dev):
+    from dupl_amd.model import losses as LS
+    g = torch.Generator().manual_seed(5)
+    seg = torch.randn(2, 21, 8, 8, generator=g) * 6
+    other = torch.randint(0, 3, (2, 128, 128), generator=g).float()
+    other[other == 2] = 255.0
+    ps, cnt = LS.seg_pseudo_label(seg.to(dev), other.to(dev), (128, 128), 255, 0.9)
+    up = F.interpolate(seg, size=(128, 128), mode="bilinear", align_corners=False)
+    ref = up.max(1)[1]
+    conf = torch.softmax(up, dim=1).max(1)[0]
+    un = (other == 255) & (conf > 0.9)
+    ref[~un] = 255
+    mism = int((ps.cpu() != ref).sum())
+    assert mism <= 3 and abs(int(cnt.item()) - int(un.sum())) <= 3     # conf == 0.9 / argmax ties at fp32 round-off
+    lab = other.clone().to(dev)
+    mask = (torch.rand(2, 128, 128, generator=g) < 0.3)
+    LS.mask_fill_(lab, mask.to(dev), 255.0)
+    exp = other.clone()
+    exp[mask] = 255.0
+    assert torch.equal(lab.cpu(), exp)

@@ -108,3 +108,22 @@ def test_vitb_forward(golden_dir):
     with torch.no_grad():
         cam_aux, cam = O.network_forward(sp, xb, O.VIT_BASE, cam_only=True)
     assert close(cam, d["cam"]) and close(cam_aux, d["cam_aux"])
+
+
+def test_tiny_step_phase_c(golden_dir):
+    """Phase C of the oracle (sklearn GMM filter + consistency loss) against the reference composition."""
+    import pytest
+    pytest.importorskip("sklearn")
+    d = g(golden_dir, "tiny_step_C")
+    pp = O.make_siamese_params(O.VIT_TINY, 21, seed=2)
+    pp = {k: (v * 40.0 if k.endswith("decoder.conv8.weight") else v) for k, v in pp.items()}
+    inputs, cls_label, img_box = O.synthetic_batch(2, 20, 128, seed=9)
+    aug, _, _ = O.synthetic_batch(2, 20, 128, seed=19)
+    aug = torch.flip(0.7 * inputs + 0.3 * aug, dims=[3]).contiguous()
+    with torch.no_grad():
+        loss, pc = O.train_step_losses(pp, inputs, cls_label, img_box, int(d["n_iter"]), O.VIT_TINY, inputs_aug=aug)
+    assert abs(loss.item() - float(d["loss"].reshape(-1)[0])) < 1e-4
+    assert list(pc["gmm_hits"]) == list(d["gmm_hits"])
+    assert (pc["refined_1"].numpy().astype(np.uint8) != d["refined_1"]).sum() <= 2
+    assert np.array_equal(pc["pseudo_seg_1"].numpy().astype(np.uint8), d["pseudo_seg_1"])
+    assert abs(pc["reg_loss"].item() - float(d["reg_loss"].reshape(-1)[0])) < 1e-4

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """DuPL VOC training entry point with the reference's launch surface (train_final_voc.py:33-90,541-560):
     python -m torch.distributed.run --nproc_per_node=N --master-addr 127.0.0.1 train_final_voc.py [flags]
-on the MI355X engine (dupl_amd).  Synthetic batches; phases A and B."""
+on the MI355X engine (dupl_amd).  Synthetic batches; phases A, B and C."""
 from dupl_amd.train_main import main
 
 if __name__ == "__main__":
