@@ -1,0 +1,73 @@
+"""-m gpu: the launch surface -- train_final_voc.py / train_final_coco.py under torch.distributed.run (world 1, RCCL
+backend initialised), tiny backbone, a few iterations crossing phase boundaries; and the DDP wrapper's exchange path
+forced on at world_size 1 (all-reduce over RCCL on the student streams) against the plain single-process step."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, extra, port):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, script), "--backbone", "tiny_test", "--crop_size", "128",
+           "--samples_per_gpu", "2", "--log_iters", "2", "--eval_iters", "1000000"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout + r.stderr
+
+
+def test_train_final_voc_script_runs_all_phases(dev):
+    out = _run("train_final_voc.py", ["--cam_iters", "2", "--gmm_iters", "4", "--max_iters", "6", "--warmup_iters", "2"], 29611)
+    assert "Iter: 2;" in out and "Iter: 6;" in out
+
+
+def test_train_final_coco_script_runs(dev):
+    out = _run("train_final_coco.py", ["--cam_iters", "2", "--gmm_iters", "1000", "--max_iters", "4", "--warmup_iters", "2",
+                                       "--num_classes", "81"], 29612)
+    assert "Iter: 4;" in out
+
+
+def test_ddp_exchange_on_gpu_world1(dev):
+    """RCCL all-reduce path (forced at world 1) gives the same gradients as the plain step; exercises the post-backward
+    hooks, the autograd-engine finalise callback and the stream ordering with two student streams."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DUPL_ROOT"])
+from oracle import dupl_oracle as O
+from dupl_amd.model.model_dupl import siamese_network
+from dupl_amd.model.PAR import PAR
+from dupl_amd.ddp import DistributedDataParallel
+from dupl_amd import trainer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl")
+dev = torch.device("cuda:0")
+pp = O.make_siamese_params(O.VIT_TINY, 21, seed=2)
+inputs, cls_label, img_box = O.synthetic_batch(2, 20, 64, seed=5)
+par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+grads = []
+for use_ddp in (False, True):
+    m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    m.load_state_dict(pp); m.to(dev); m.enable_dual_stream(True)
+    w = DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True) if use_ddp else m
+    if use_ddp:
+        w.reducer.world = 2          # force the exchange path: all_reduce(SUM) over 1 rank, then * 1/2
+    loss, out = trainer.compute_losses(w, par, inputs.to(dev), cls_label.to(dev), img_box, 5000, trainer.StepArgs(), cls_label)
+    loss.sum().backward()
+    m.flat_storage.wait_streams(); torch.cuda.synchronize()
+    grads.append(m.flat_storage.grad.clone())
+lo, hi = m.flat_storage.trainable_range(0)
+e = (grads[1][lo:hi] * 2 - grads[0][lo:hi]).abs().max().item() / grads[0][lo:hi].abs().max().item()
+print("DDP_REL_ERR", e)
+assert e < 1e-5
+dist.destroy_process_group()
+'''
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DUPL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DDP_REL_ERR" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
