@@ -24,6 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_IMG_PHASE_AB = 3.44e12       # BASELINE.md section 2 (algorithmic, both students, fwd+bwd = 3x fwd)
+FLOP_SHARED_PASS = 2 * 0.1570e12      # the scale-1.0 un-flipped ms-CAM encoder pass == the training forward's encoder pass
+                                      # (same weights, same input): executed once per student when --share-encoder (default)
 PEAK_F32_MFMA = 157.3e12              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (f32 in / f32 acc)
 
 
@@ -43,6 +45,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--forward-precision", default="f32", choices=["f32", "h3"],
                     help="f32: exact f32-MFMA everywhere (default); h3: split-fp16 3-pass MFMA for the Linear forwards")
+    ap.add_argument("--no-share-encoder", action="store_true",
+                    help="run the training forward's encoder pass separately from ms-CAM's identical scale-1.0 pass, exactly "
+                         "like the reference does (default: computed once and shared; outputs are bit-identical)")
     ap.add_argument("--single-stream", action="store_true", help="run the two students back to back on one stream")
     return ap.parse_args()
 
@@ -175,6 +180,7 @@ def main():
     _ops.set_forward_precision(args.forward_precision)
     C = 20 if args.dataset == "voc" else 80
     sargs = trainer.StepArgs() if args.dataset == "voc" else trainer.coco_step_args()
+    sargs.share_encoder_pass = not args.no_share_encoder
     torch.manual_seed(0)
     model = siamese_network(args.backbone, num_classes=C + 1, pretrained=False, aux_layer=-3)
     groups = model.get_param_groups()
@@ -219,6 +225,7 @@ def main():
     imgs_per_s = world * args.batch * args.steps / dt
     log(f"timed region: {args.steps} steps in {dt:.3f} s -> {imgs_per_s:.2f} img/s")
 
+    flop_exec = FLOP_PER_IMG_PHASE_AB - (0.0 if args.no_share_encoder else FLOP_SHARED_PASS)
     roof = None
     if not args.no_roofline:
         model.enable_dual_stream(False)   # per-kernel durations are only meaningful without a co-running stream
@@ -234,7 +241,8 @@ def main():
                 "profiles/r01_final_pmc_hbm.txt)", "algorithmic_bytes_per_launch": round(gbytes / max(gn, 1)),
                 "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
                 "kernel_share_of_step": round(gms / ms, 3),
-                "step_frac_of_peak": round(imgs_per_s / world * FLOP_PER_IMG_PHASE_AB / PEAK_F32_MFMA, 4),
+                "step_frac_of_peak": round(imgs_per_s / world * flop_exec / PEAK_F32_MFMA, 4),
+                "step_flop_per_img": {"reference_algorithm": FLOP_PER_IMG_PHASE_AB, "executed": flop_exec},
                 "note": "HIP event pairs around every launch of the kernel during one extra step run right after the timed "
                         "region (same stream, same workload); algorithmic flops = 2*M*N*K per launch"}
     cpu = None
@@ -253,6 +261,7 @@ def main():
                           "global_batch": world * args.batch, "img_per_gpu": args.batch, "num_classes": C + 1,
                           "n_iter": args.n_iter, "parallelism": f"dp{world}", "student_streams": 1 if args.single_stream else 2,
                           "forward_precision": args.forward_precision,
+                          "shared_scale1_encoder_pass": not args.no_share_encoder,
                           "loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec))

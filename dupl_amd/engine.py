@@ -283,11 +283,35 @@ class HeadSaved:
     h7: Tensor = None
 
 
-def network_forward(P: StudentParams, x: Tensor, save: bool):
+def cam_logits_shared(P: StudentParams, x: Tensor, x_flip: Tensor):
+    """cam_only logits of [x ; flip(x)] where the un-flipped half is run WITH activation saving so that the training
+    forward of the same step (same weights, same x) can reuse it instead of running the encoder again
+    (the reference recomputes it: cam_helper.py:171 under no_grad, then train_final_voc.py:204).
+    Returns (cam_aux_tok, cam_tok) [2B*(1+n), C] and the cache (tf, aux, EncoderSaved) of the un-flipped half."""
+    C = P.num_classes - 1
+    Wc = P.w["classifier.weight"].view(C, -1)
+    Wa = P.w["aux_classifier.weight"].view(C, -1)
+    tf, aux, enc = encoder_forward(P, x, save=True)
+    tf2, aux2, _ = encoder_forward(P, x_flip, save=False)
+    rows = tf.shape[0]
+    cam = torch.empty((2 * rows, C), device=x.device, dtype=torch.float32)
+    cam_aux = torch.empty((2 * rows, C), device=x.device, dtype=torch.float32)
+    ops.linear(tf, Wc, out=cam[:rows])
+    ops.linear(tf2, Wc, out=cam[rows:])
+    ops.linear(aux, Wa, out=cam_aux[:rows])
+    ops.linear(aux2, Wa, out=cam_aux[rows:])
+    return cam_aux, cam, (tf, aux, enc)
+
+
+def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
     """network.forward (model_dupl.py:69-106), training / val branch.
-    Returns (cls_x4 (B,C), seg (B,C+1,h,w), x4 (B,D,h,w), cls_aux (B,C)), saved."""
+    Returns (cls_x4 (B,C), seg (B,C+1,h,w), x4 (B,D,h,w), cls_aux (B,C)), saved.
+    enc_cache: (tf, aux, EncoderSaved) of THIS x from cam_logits_shared -> the encoder pass is not repeated."""
     cfg = P.cfg
-    tf, aux, enc = encoder_forward(P, x, save)
+    if enc_cache is not None:
+        tf, aux, enc = enc_cache
+    else:
+        tf, aux, enc = encoder_forward(P, x, save)
     B = x.shape[0]
     h, w = x.shape[2] // cfg.patch, x.shape[3] // cfg.patch
     n, D, C = h * w, cfg.embed_dim, P.num_classes - 1

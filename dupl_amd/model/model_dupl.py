@@ -49,8 +49,8 @@ class _NetworkFn(torch.autograd.Function):
     gradients into the flat gradient buffer and returns nothing for them."""
 
     @staticmethod
-    def forward(ctx, anchor, x, net):
-        outs, sv = engine.network_forward(net._P, x, save=True)
+    def forward(ctx, anchor, x, net, enc_cache=None):
+        outs, sv = engine.network_forward(net._P, x, save=True, enc_cache=enc_cache)
         ctx.net, ctx.sv = net, sv
         ctx.set_materialize_grads(False)
         net._live_graphs += 1     # forwards of this student whose backward has not run yet (phase C has two)
@@ -64,7 +64,7 @@ class _NetworkFn(torch.autograd.Function):
         net._live_graphs = max(0, net._live_graphs - 1)
         for hook in net._post_backward_hooks:
             hook(net)
-        return None, None, None
+        return None, None, None, None
 
 
 class network(nn.Module):
@@ -165,6 +165,10 @@ class network(nn.Module):
         if self._anchor is None or self._anchor.device != device:
             self._anchor = torch.zeros(1, device=device, requires_grad=True)
         return self._anchor
+
+    def forward_shared(self, x, enc_cache):
+        """Training forward that reuses the encoder pass ms-CAM already ran on this x (engine.cam_logits_shared)."""
+        return _NetworkFn.apply(self._anchor_for(x.device), x, self, enc_cache)
 
     def forward(self, x, cam_only=False, val=False, cam_with_grad=False):
         if not x.is_cuda:
@@ -267,6 +271,23 @@ class siamese_network(nn.Module):
             self._store.scale_streams = {}
         return self
 
+    def ms_cam_and_forward(self, inputs, scales):
+        """Fused step front-end: for each student the multi-scale CAMs (cam_helper.multi_scale_cam2_siamese) AND the
+        training forward (self(inputs)) -- the scale-1.0 un-flipped encoder pass is shared between the two (the
+        reference runs it twice with identical weights and input; outputs are identical).
+        Returns ((cam_1, cam_aux_1), (cam_2, cam_aux_2), {"branch1": ..., "branch2": ...})."""
+        from ..utils import cam_helper
+        inputs = inputs.contiguous().float()
+
+        def one(net):
+            share = {}
+            cams = cam_helper._ms_cam(net._P, inputs, scales, share=share)
+            outs = net.forward_shared(share["x"], share["enc"]) if torch.is_grad_enabled() else net(inputs)
+            return cams, outs
+
+        (c1, o1), (c2, o2) = self.per_student(lambda: one(self.branch1), lambda: one(self.branch2))
+        return c1, c2, {"branch1": o1, "branch2": o2}
+
     def per_student(self, fn1, fn2):
         """Evaluate fn1() for student 1 and fn2() for student 2, concurrently when dual-stream is enabled."""
         if not (getattr(self, "_dual", False) and self._store.streams):
@@ -281,10 +302,15 @@ class siamese_network(nn.Module):
             r2 = fn2()
         main.wait_stream(s1)
         main.wait_stream(s2)
-        for r in (r1, r2):
-            for t in (r if isinstance(r, (tuple, list)) else (r,)):
-                if torch.is_tensor(t):
-                    t.record_stream(main)
+        def rec(r):
+            if torch.is_tensor(r):
+                r.record_stream(main)
+            elif isinstance(r, (tuple, list)):
+                for t in r:
+                    rec(t)
+
+        rec(r1)
+        rec(r2)
         return r1, r2
 
     def get_param_groups(self):

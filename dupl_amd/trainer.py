@@ -40,6 +40,7 @@ class StepArgs:
     samples_per_gpu: int = 2
     gmm_valid_thre: float = 1.0
     gamma: float = 0.95
+    share_encoder_pass: bool = True   # reuse ms-CAM's scale-1.0 encoder pass as the training forward (identical values)
     schedule: str = "voc"        # "voc": train_final_voc.py:194-456; "coco": train_final_coco.py:190-448
     coco_switch_iter: int = 12000  # train_final_coco.py:241,312: bkg_v2 on aux CAMs until here, then dynamic thresholds
 
@@ -86,14 +87,18 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     inputs_denorm = ops.denormalize_img(inputs.contiguous()) if not phase_a else None
 
     core = model.module if hasattr(model, "module") else model
-    (cams_1, cams_aux_1), (cams_2, cams_aux_2) = core.per_student(
-        lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=1),
-        lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=2))
-
-    if phase_c:
-        res = model(torch.cat([inputs, inputs_aug], dim=0), need_sp=True)     # train_final_voc.py:291-295
+    if phase_c or not args.share_encoder_pass:
+        (cams_1, cams_aux_1), (cams_2, cams_aux_2) = core.per_student(
+            lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=1),
+            lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=2))
+        if phase_c:
+            res = model(torch.cat([inputs, inputs_aug], dim=0), need_sp=True)     # train_final_voc.py:291-295
+        else:
+            res = model(inputs)
     else:
-        res = model(inputs)
+        # the scale-1.0 un-flipped ms-CAM encoder pass and the training forward see the same weights and input:
+        # run it once, with activation saving, and feed both (reference: cam_helper.py:171 then train_final_voc.py:204)
+        (cams_1, cams_aux_1), (cams_2, cams_aux_2), res = core.ms_cam_and_forward(inputs, args.cam_scales)
     cls_1, segs_1, fmap_1, cls_aux_1 = res["branch1"]
     cls_2, segs_2, fmap_2, cls_aux_2 = res["branch2"]
 

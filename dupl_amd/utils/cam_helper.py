@@ -22,8 +22,9 @@ def _student(model, branch):
     return m._P
 
 
-def _ms_cam(P, inputs, scales):
-    """cam_helper.py:164-204 fused: per scale one no-grad encoder pass over [x ; flip(x)] at that resolution and one
+def _ms_cam(P, inputs, scales, share=None):
+    """cam_helper.py:164-204 fused (`share`: optional dict that receives the encoder state of the un-flipped
+    scale-1.0 pass under key "enc" for reuse by the training forward of the same step): per scale one no-grad encoder pass over [x ; flip(x)] at that resolution and one
     skinny GEMM per classifier; all scales are then up-sampled / flip-max'ed / ReLU'ed / summed and min-max
     normalised by two streaming kernels (the low-resolution logits stay token-major)."""
     inputs = inputs.contiguous().float()
@@ -47,6 +48,10 @@ def _ms_cam(P, inputs, scales):
                     cam_aux_t, cam_t = engine.cam_logits(P, x2)
                 cam_t.record_stream(cur)
                 cam_aux_t.record_stream(cur)
+            elif share is not None and s == 1.0:
+                x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
+                cam_aux_t, cam_t, share["enc"] = engine.cam_logits_shared(P, x2[:b], x2[b:])
+                share["x"] = x2[:b]
             else:
                 x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
                 cam_aux_t, cam_t = engine.cam_logits(P, x2)
