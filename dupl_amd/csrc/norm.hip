@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // Backward: each wave walks ROWS_PER_WAVE rows, keeps per-lane partial dgamma/dbeta in registers and
 // issues one atomicAdd per column per block at the end (via LDS reduction across the 4 waves).
-constexpr int LNB_ROWS = 16;  // rows per wave
+constexpr int LNB_ROWS = 4;   // rows per wave (16 rows per block): ~200 blocks at B*N = 3140 instead of 50
 
 template <int LN_MAXC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -212,7 +212,7 @@ extern "C" int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int
                            dupl_stream_t s) {
     if (!x || !out || M <= 0 || N <= 0) return DUPL_ERR_ARG;
     if (!accumulate) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, out, 0.f, (long)N);
-    long gy = (M + 255) / 256;
+    long gy = (M + 63) / 64;       // 16 rows per thread-row-group pass: enough blocks to fill the chip on B*N ~ 3000 rows
     if (gy > 256) gy = 256;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (int)gy), dim3(256), 0, (hipStream_t)s, x, out, (long)M, N, ldx);
