@@ -283,24 +283,33 @@ class HeadSaved:
     h7: Tensor = None
 
 
-def cam_logits_shared(P: StudentParams, x: Tensor, x_flip: Tensor):
-    """cam_only logits of [x ; flip(x)] where the un-flipped half is run WITH activation saving so that the training
-    forward of the same step (same weights, same x) can reuse it instead of running the encoder again
-    (the reference recomputes it: cam_helper.py:171 under no_grad, then train_final_voc.py:204).
-    Returns (cam_aux_tok, cam_tok) [2B*(1+n), C] and the cache (tf, aux, EncoderSaved) of the un-flipped half."""
+def _prefix_saved(sv: EncoderSaved, b: int, rows: int) -> EncoderSaved:
+    """Activation record of the first `b` images of a larger saved batch (every tensor is image-major, so a row
+    prefix is a contiguous view: nothing is copied)."""
+    out = EncoderSaved(B=b, h=sv.h, w=sv.w, x_img=sv.x_img[:b])
+    for s in sv.blocks:
+        out.blocks.append(BlockSaved(x_in=s.x_in[:rows], mean1=s.mean1[:rows], rstd1=s.rstd1[:rows], ln1=s.ln1[:rows],
+                                     qkv=s.qkv[:rows], lse=s.lse[:b], att=s.att[:rows], x_mid=s.x_mid[:rows],
+                                     mean2=s.mean2[:rows], rstd2=s.rstd2[:rows], ln2=s.ln2[:rows], pre1=s.pre1[:rows],
+                                     h1=s.h1[:rows]))
+    out.x_last, out.mean_f, out.rstd_f = sv.x_last[:rows], sv.mean_f[:rows], sv.rstd_f[:rows]
+    return out
+
+
+def cam_logits_shared(P: StudentParams, x2: Tensor, b: int):
+    """cam_only logits of x2 = [x ; flip(x)] (2b images) run WITH activation saving, so that the training forward of
+    the same step (same weights, same x = x2[:b]) reuses the encoder pass instead of repeating it (the reference runs
+    it twice: cam_helper.py:171 under no_grad, then train_final_voc.py:204).  The whole 2b batch goes through the
+    kernels in one piece (large grids); the cache handed back is the row-prefix view of the un-flipped half.
+    Returns (cam_aux_tok, cam_tok) [2b*(1+n), C] and the cache (tf, aux, EncoderSaved)."""
     C = P.num_classes - 1
     Wc = P.w["classifier.weight"].view(C, -1)
     Wa = P.w["aux_classifier.weight"].view(C, -1)
-    tf, aux, enc = encoder_forward(P, x, save=True)
-    tf2, aux2, _ = encoder_forward(P, x_flip, save=False)
-    rows = tf.shape[0]
-    cam = torch.empty((2 * rows, C), device=x.device, dtype=torch.float32)
-    cam_aux = torch.empty((2 * rows, C), device=x.device, dtype=torch.float32)
-    ops.linear(tf, Wc, out=cam[:rows])
-    ops.linear(tf2, Wc, out=cam[rows:])
-    ops.linear(aux, Wa, out=cam_aux[:rows])
-    ops.linear(aux2, Wa, out=cam_aux[rows:])
-    return cam_aux, cam, (tf, aux, enc)
+    tf, aux, enc = encoder_forward(P, x2, save=True)
+    cam = ops.linear(tf, Wc)
+    cam_aux = ops.linear(aux, Wa)
+    rows = tf.shape[0] // 2
+    return cam_aux, cam, (tf[:rows], aux[:rows], _prefix_saved(enc, b, rows))
 
 
 def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
@@ -354,7 +363,7 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
     G, W = P.g, P.w
     dtf = ops.zeros((B * N, D), dev)
     dta = None
-    aux_is_final = sv.aux.data_ptr() == sv.tf.data_ptr()
+    aux_is_final = sv.aux.data_ptr() == sv.tf.data_ptr()   # aux_layer == last block: embeds[-1] is the final LN output
     # ---- heads
     if dx4 is not None:
         ops.nchw_to_tokens_add(dx4.contiguous(), dtf, B, n, D, skip_cls=True)

@@ -50,7 +50,7 @@ def _ms_cam(P, inputs, scales, share=None):
                 cam_aux_t.record_stream(cur)
             elif share is not None and s == 1.0:
                 x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
-                cam_aux_t, cam_t, share["enc"] = engine.cam_logits_shared(P, x2[:b], x2[b:])
+                cam_aux_t, cam_t, share["enc"] = engine.cam_logits_shared(P, x2, b)
                 share["x"] = x2[:b]
             else:
                 x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
