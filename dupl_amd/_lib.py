@@ -71,7 +71,16 @@ class _Lib:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  dupl_amd has no CPU / eager fallback by design.")
+        # The process must hold ONE HIP runtime.  torch ships its own libamdhip64 (SONAME libamdhip64.so.7, found by
+        # libtorch_hip under the file name libamdhip64.so): when torch is loaded first our NEEDED libamdhip64.so.7
+        # binds to that copy; loaded the other way round the dynamic linker maps /opt/rocm's runtime for us and torch's
+        # for torch, and torch stream handles passed across the C ABI are then foreign (launches fail with -2).
+        import torch  # noqa: F401  (device memory + streams come from torch: load its runtime first)
         self.cdll = ctypes.CDLL(LIB_PATH)
+        runtimes = {ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln}
+        if len(runtimes) > 1:
+            raise ImportError(f"two HIP runtimes mapped in one process ({sorted(runtimes)}): stream handles and "
+                              "device pointers would not be interchangeable")
         self.protos = parse_header()
         for name, argtypes in self.protos.items():
             fn = getattr(self.cdll, name)  # AttributeError if the .so does not export a declared symbol

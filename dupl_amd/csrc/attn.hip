@@ -406,6 +406,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(const float* __restri
 
 extern "C" int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd,
                                   float scale, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!qkv || !out || B <= 0 || N <= 0 || H <= 0 || (hd != 32 && hd != 64)) return DUPL_ERR_ARG;
     dim3 grid((N + 127) / 128, H, B), block(ANT);
     if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale);
@@ -415,6 +416,7 @@ extern "C" int dupl_attention_fwd(const float* qkv, float* out, float* lse, int3
 
 extern "C" int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta,
                                   float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, float scale, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || N <= 0 || H <= 0 || (hd != 32 && hd != 64))
         return DUPL_ERR_ARG;
     const long total = (long)B * N * H;

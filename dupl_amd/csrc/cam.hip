@@ -181,6 +181,7 @@ inline int ew_grid(long n) {
 
 extern "C" int dupl_resize_bilinear(const float* in, float* out, int32_t B, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
                                     int32_t Wo, int32_t flip_cat, int32_t align_corners, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!in || !out || B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return DUPL_ERR_ARG;
     const long total = (long)B * C * Ho * Wo;
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, in, out, B, C, Hi, Wi, Ho,
@@ -190,6 +191,7 @@ extern "C" int dupl_resize_bilinear(const float* in, float* out, int32_t B, int3
 
 extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const int32_t* ws, int32_t nscale, int32_t row_off,
                              int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!lows || !hs || !ws || nscale <= 0 || nscale > 4 || !cam || !mm || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldc < C)
         return DUPL_ERR_ARG;
     CamFuseDesc d;
@@ -209,6 +211,7 @@ extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const 
 
 extern "C" int dupl_cam_minmax_normalise(float* cam, float* mm, int32_t planes, int32_t HW, int32_t have_minmax,
                                          dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!cam || !mm || planes <= 0 || HW <= 0) return DUPL_ERR_ARG;
     int gx = (HW + 1023) / 1024;
     if (gx > 64) gx = 64;
@@ -223,6 +226,7 @@ extern "C" int dupl_cam_minmax_normalise(float* cam, float* mm, int32_t planes, 
 extern "C" int dupl_cam_to_label(const float* cam, const float* cls_label, const int32_t* img_box, const float* high_thre,
                                  float bkg_thre, float low_thre, int32_t ignore_mid, int32_t ignore_index, int64_t* label,
                                  float* valid_cam, int32_t b, int32_t C, int32_t h, int32_t w, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!cam || !cls_label || !label || b <= 0 || C <= 0 || h <= 0 || w <= 0) return DUPL_ERR_ARG;
     if (img_box && ignore_mid && !high_thre) return DUPL_ERR_ARG;
     hipLaunchKernelGGL(cam_to_label_kernel, dim3(ew_grid((long)b * h * w)), dim3(256), 0, (hipStream_t)s, cam, cls_label,
@@ -231,6 +235,7 @@ extern "C" int dupl_cam_to_label(const float* cam, const float* cls_label, const
 }
 
 extern "C" int dupl_denormalize_img(const float* x, float* out, int32_t B, int32_t HW, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !out || B <= 0 || HW <= 0) return DUPL_ERR_ARG;
     hipLaunchKernelGGL(denormalize_kernel, dim3(ew_grid((long)B * 3 * HW)), dim3(256), 0, (hipStream_t)s, x, out, B, HW);
     return dupl_launch_status();

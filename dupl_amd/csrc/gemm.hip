@@ -246,6 +246,7 @@ extern "C" int dupl_set_gemm_tile(int32_t rows) {
 }
 
 extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!d || !d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->zdiv <= 0)
         return DUPL_ERR_ARG;
     if ((d->flags & (DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK | DUPL_GEMM_STORE_PRE)) && !d->aux) return DUPL_ERR_ARG;

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(HNT) void gemm_h3_kernel(const dupl_gemm_desc p) {
 // Same descriptor as dupl_gemm_f32; only the k-contiguous x k-contiguous layout and the forward epilogues
 // (bias, GELU, ReLU, |.|, store-pre, residual) are supported.
 extern "C" int dupl_gemm_h3(const dupl_gemm_desc* d, dupl_stream_t stream) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!d || !d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->zdiv <= 0)
         return DUPL_ERR_ARG;
     const int unsupported = DUPL_GEMM_A_MCONTIG | DUPL_GEMM_B_NCONTIG | DUPL_GEMM_ACCUM | DUPL_GEMM_MUL_DGELU |

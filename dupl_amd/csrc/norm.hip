@@ -180,6 +180,7 @@ inline int ew_grid(long n) {
 
 extern "C" int dupl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                   float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !gamma || !beta || !y || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256) return DUPL_ERR_ARG;
     const int grid = (int)((rows + 3) / 4);
 #define LN_FWD(MC) hipLaunchKernelGGL(layernorm_fwd_kernel<MC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, gamma, beta, y, \
@@ -195,6 +196,7 @@ extern "C" int dupl_layernorm_fwd(const float* x, const float* gamma, const floa
 extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                                   int64_t rows, int32_t D, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256)
         return DUPL_ERR_ARG;
     const int grid = (int)((rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS));
@@ -210,6 +212,7 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
 
 extern "C" int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int32_t ldx, int32_t accumulate,
                            dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !out || M <= 0 || N <= 0) return DUPL_ERR_ARG;
     if (!accumulate) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, out, 0.f, (long)N);
     long gy = (M + 63) / 64;       // 16 rows per thread-row-group pass: enough blocks to fill the chip on B*N ~ 3000 rows
@@ -220,18 +223,21 @@ extern "C" int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int
 }
 
 extern "C" int dupl_fill(float* p, float v, int64_t n, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!p || n < 0) return DUPL_ERR_ARG;
     if (n == 0) return DUPL_OK;
     hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, p, v, (long)n);
     return dupl_launch_status();
 }
 extern "C" int dupl_axpy(float* y, const float* x, float a, int64_t n, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!y || !x || n < 0) return DUPL_ERR_ARG;
     if (n == 0) return DUPL_OK;
     hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, y, x, a, (long)n);
     return dupl_launch_status();
 }
 extern "C" int dupl_scale(float* y, float a, int64_t n, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!y || n < 0) return DUPL_ERR_ARG;
     if (n == 0) return DUPL_OK;
     hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, y, a, (long)n);

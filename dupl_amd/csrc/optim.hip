@@ -35,6 +35,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 extern "C" int dupl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                           float wd, float bc1, float bc2_sqrt, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!p || !g || !m || !v || n <= 0) return DUPL_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
          reinterpret_cast<uintptr_t>(v)) & 15)

@@ -269,3 +269,40 @@ def test_tiny_phase_c_matches_reference(dev, golden_dir):
     print("phase C grad errs:", [(f"{e:.1e}", n) for e, n in errs[:12]], "... median", errs[len(errs) // 2])
     print(f"phase C: worst rel grad err {worst:.2e} ({wname})")
     assert worst < 2e-3
+
+
+@pytest.mark.parametrize("S,second", [(96, None), (128, None), (96, 128)])
+def test_single_student_gradients_vs_oracle_autograd(dev, S, second):
+    """Single `network` (config-1 style), arbitrary linear functional of all four outputs: every parameter gradient of
+    the hand-written backward vs torch autograd through the oracle; `second`: a second forward at another resolution
+    whose gradients must accumulate (phase C's aug branch)."""
+    from dupl_amd.model.model_dupl import network
+    from oracle import dupl_oracle as O
+    cfg, NC = O.VIT_TINY, 21
+    sp = O.make_student_params(cfg, NC, seed=1)
+    net = network("tiny_test", num_classes=NC, pretrained=False, aux_layer=-3)
+    net.load_state_dict(sp)
+    net.to(dev)
+    x = O.hash_normal(f"x{S}", (2, 3, S, S), seed=1)
+    shapes = ((2, NC - 1), (2, NC, S // 16, S // 16), (2, 96, S // 16, S // 16), (2, NC - 1))
+    R = [O.hash_normal(f"r{i}{S}", shp, seed=2) for i, shp in enumerate(shapes)]
+    leaf = {k: v.clone().requires_grad_(k != "encoder.pos_embed") for k, v in sp.items()}
+    ref = sum((o * r).sum() for o, r in zip(O.network_forward(leaf, x, cfg), R))
+    net._store.grad.zero_()
+    got = sum((o * r.to(dev)).sum() for o, r in zip(net(x.to(dev)), R))
+    if second:
+        x2 = O.hash_normal(f"x2{second}", (2, 3, second, second), seed=3)
+        ref = ref + (O.network_forward(leaf, x2, cfg)[1] ** 2).sum()
+        got = got + (net(x2.to(dev))[1] ** 2).sum()
+    ref.backward()
+    got.backward()
+    torch.cuda.synchronize()
+    assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    worst = 0.0
+    for k, v in leaf.items():
+        if v.grad is None:
+            assert float(net._store.view(0, k, grad=True).abs().max()) == 0.0, k
+            continue
+        g = net._store.view(0, k, grad=True).cpu()
+        worst = max(worst, ((g - v.grad).abs().max() / v.grad.abs().max().clamp_min(1e-20)).item())
+    assert worst < 2e-5, worst
