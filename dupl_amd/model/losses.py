@@ -148,6 +148,42 @@ def get_reg_loss(seg_aug, pseudo_seg, size, ignore_index=255):
     return _SegLoss.apply(seg_aug, pseudo_seg, int(size[0]), int(size[1]), ignore_index, True, False)
 
 
+GMM_STATS = 16
+_GMM_UNIFORMS = {}
+
+
+def _gmm_uniforms(seed: int):
+    """The three uniforms sklearn's k-means++ draws from RandomState(seed) for n_clusters=2 (first centre through
+    RandomState.choice -> random_sample(); two trial centres through uniform(size=2))."""
+    if seed not in _GMM_UNIFORMS:
+        import numpy as np
+        rs = np.random.RandomState(seed)
+        u0 = float(rs.random_sample())
+        u1, u2 = (float(v) for v in rs.uniform(size=2))
+        _GMM_UNIFORMS[seed] = (u0, u1, u2)
+    return _GMM_UNIFORMS[seed]
+
+
+def gmm_noise_filter_(ce_map, label, ignore_index=255, gmm_valid_thre=1.0, gamma=0.95, min_ce=0.1, min_count=1000,
+                      reg_covar=5e-4, tol=1e-2, max_iter=10, random_state=0):
+    """The GMM label-noise filter of one student (train_final_voc.py:363-394) entirely on the device, in place on
+    `label` (b,H,W) float32: the reference's per-image sklearn GaussianMixture(2, max_iter, tol, reg_covar,
+    random_state) fit on the CE values of the foreground pseudo-labels and the relabelling of the high-loss mode.
+    Returns the (b, GMM_STATS) statistics tensor (see include/dupl_hip.h); no host synchronisation."""
+    b = label.shape[0]
+    HW = label[0].numel()
+    assert label.dtype == torch.float32 and label.is_contiguous() and ce_map.shape == label.shape
+    ce = ce_map.contiguous()
+    xs = torch.empty((b, HW), device=label.device, dtype=torch.float32)
+    lab = torch.empty((b, HW), device=label.device, dtype=torch.uint8)
+    stats = torch.empty((b, GMM_STATS), device=label.device, dtype=torch.float32)
+    u0, u1, u2 = _gmm_uniforms(int(random_state))
+    L().dupl_gmm_noise_filter(ce.data_ptr(), label.data_ptr(), xs.data_ptr(), lab.data_ptr(), stats.data_ptr(), b, HW,
+                              int(ignore_index), float(min_ce), int(min_count), float(gmm_valid_thre), float(gamma),
+                              float(reg_covar), float(tol), int(max_iter), u0, u1, u2, _stream())
+    return stats
+
+
 def mask_fill_(label, mask, value):
     """label[mask] = value, in place (label float32, mask uint8/bool of the same shape)."""
     m = mask.to(torch.uint8).contiguous()

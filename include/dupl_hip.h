@@ -199,6 +199,20 @@ int dupl_seg_ce_map(const float* logits, const void* label, int32_t is_i64, int3
 int dupl_seg_pseudo_label(const float* logits, const float* other_label, int32_t ignore_index, float conf_thr,
                           int64_t* out_label, float* count, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H,
                           int32_t W, dupl_stream_t s);
+/* The phase-C label-noise filter on the device (train_final_voc.py:358-394), one workgroup per image: fits the
+ * reference's sklearn GaussianMixture(n_components=2, max_iter=em_iters, tol=em_tol, reg_covar, random_state=seed)
+ * (k-means++ / Lloyd initialisation included) on the ce_map values of the pixels with label != 0, != ignore_index and
+ * ce > min_ce -- only when more than min_count of them exist -- and, when |mean0 - mean1| > valid_thre, sets
+ * label = ignore_index where P(high-mean component | ce) > gamma and label != 0.  label (B,HW) float32 in/out.
+ * u0,u1,u2 = the three uniforms numpy's RandomState(seed) yields (random_sample(), uniform(size=2)): sklearn's
+ * k-means++ consumes exactly those.  xs_scratch (B*HW floats) and lab_scratch (B*HW bytes) are work space.
+ * stats [B][DUPL_GMM_STATS] = {n selected, filtered?, mean0, mean1, cov0, cov1, weight0, weight1, EM iterations,
+ * Lloyd iterations, mean log-likelihood, k-means centre0, centre1, #pixels relabelled, first seed index, second}. */
+#define DUPL_GMM_STATS 16
+int dupl_gmm_noise_filter(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch, float* stats,
+                          int32_t B, int32_t HW, int32_t ignore_index, float min_ce, int32_t min_count,
+                          float valid_thre, float gamma, float reg_covar, float em_tol, int32_t em_iters, double u0,
+                          double u1, double u2, dupl_stream_t s);
 /* label[i] = value where mask[i] != 0 (noise-mask write-back, train_final_voc.py:381,393) */
 int dupl_mask_fill(float* label, const uint8_t* mask, float value, int64_t n, dupl_stream_t s);
 /* dlogits (token-major, zero first) += gscale[0] * d loss / d logits (wave-reduced atomics when H/h, W/w are multiples

@@ -426,3 +426,67 @@ def test_seg_pseudo_label_and_mask_fill(dev):
     exp = other.clone()
     exp[mask] = 255.0
     assert torch.equal(lab.cpu(), exp)
+
+
+# ------------------------------------------------------------------------------------------ GMM label-noise filter
+def _gmm_case(kind, H, W, seed):
+    """Synthetic CE map + pseudo-label map: `bimodal` = a clean low-loss mode and a noisy high-loss mode (the case
+    the filter exists for), `unimodal` = one mode (means closer than gmm_valid_thre), `few` = < 1000 selected px."""
+    rng = np.random.RandomState(seed)
+    label = rng.randint(0, 21, size=(H, W)).astype(np.float32)
+    label[rng.rand(H, W) < 0.35] = 0.0
+    label[rng.rand(H, W) < 0.10] = 255.0
+    if kind == "few":
+        label[:] = 0.0
+        label[:20, :30] = 3.0
+    low = np.abs(rng.normal(0.35, 0.15, size=(H, W)))
+    high = rng.normal(3.2, 0.7, size=(H, W))
+    if kind == "unimodal":
+        ce = np.abs(rng.normal(0.8, 0.3, size=(H, W)))
+    else:
+        ce = np.where(rng.rand(H, W) < 0.3, high, low)
+    ce = np.maximum(ce, 0.0).astype(np.float32)
+    ce[label == 255.0] = 0.0          # ce_criterion gives 0 at ignored pixels
+    return ce, label
+
+
+@pytest.mark.parametrize("H,W", [(128, 128), (448, 448), (97, 131)])
+def test_gmm_noise_filter_vs_sklearn(dev, H, W):
+    """dupl_gmm_noise_filter vs the reference's sklearn call (oracle.gmm_noise_filter_ restates train_final_voc.py:
+    363-394): same k-means++ seeds, fitted parameters to 1e-3, relabelled pixels identical up to threshold ties."""
+    pytest.importorskip("sklearn")
+    from sklearn.mixture import GaussianMixture
+    from sklearn.cluster import kmeans_plusplus
+    from oracle import dupl_oracle as O
+    from dupl_amd.model import losses as LS
+    kinds = ["bimodal", "unimodal", "few", "bimodal"]
+    cases = [_gmm_case(k, H, W, 100 + i) for i, k in enumerate(kinds)]
+    ce = torch.from_numpy(np.stack([c[0] for c in cases]))
+    lab = torch.from_numpy(np.stack([c[1] for c in cases]))
+    ref = lab.clone()
+    hits = O.gmm_noise_filter_(ce, ref, 1.0, 0.95)
+    got = lab.clone().to(dev)
+    stats = LS.gmm_noise_filter_(ce.to(dev), got, 255, 1.0, 0.95)
+    torch.cuda.synchronize()
+    stats = stats.cpu().numpy()
+    got = got.cpu()
+    print("stats:\n", stats.round(4))
+    assert int(stats[:, 1].sum()) == hits
+    for i, kind in enumerate(kinds):
+        sel = (cases[i][1] != 0) & (cases[i][1] != 255) & (cases[i][0] > 0.1)
+        x = cases[i][0][sel].reshape(-1, 1)
+        assert int(stats[i, 0]) == x.shape[0]
+        if x.shape[0] <= 1000:
+            assert stats[i, 1] == 0 and torch.equal(got[i], lab[i])
+            continue
+        gm = GaussianMixture(n_components=2, max_iter=10, tol=1e-2, reg_covar=5e-4, random_state=0).fit(x)
+        _, idx = kmeans_plusplus(x - x.mean(axis=0), 2, random_state=np.random.RandomState(0))
+        assert [int(stats[i, 14]), int(stats[i, 15])] == [int(idx[0]), int(idx[1])], "k-means++ seeds"
+        assert int(stats[i, 8]) == gm.n_iter_, "EM iteration count"
+        np.testing.assert_allclose(stats[i, 2:4], gm.means_[:, 0], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(stats[i, 4:6], gm.covariances_[:, 0, 0], rtol=2e-3, atol=1e-5)
+        np.testing.assert_allclose(stats[i, 6:8], gm.weights_, rtol=1e-3, atol=1e-4)
+        mism = int((got[i] != ref[i]).sum())
+        print(f"case {i} ({kind}): n {x.shape[0]}, relabelled {int(stats[i, 13])}, mismatching px {mism}")
+        assert mism <= max(2, x.shape[0] // 20000), kind
+        assert (stats[i, 1] == 1) == (kind == "bimodal")
