@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 FLOP_PER_IMG_PHASE_AB = 3.44e12       # BASELINE.md section 2 (algorithmic, both students, fwd+bwd = 3x fwd)
 FLOP_SHARED_PASS = 2 * 0.1570e12      # the scale-1.0 un-flipped ms-CAM encoder pass == the training forward's encoder pass
                                       # (same weights, same input): executed once per student when --share-encoder (default)
+FLOP_PHASE_C_AUG = 6 * (0.0828e12 + 0.0052e12)   # phase C: fwd+bwd of both students on the 336^2 strong-aug batch
+FLOP_PHASE_C_DEAD = 4 * (0.1570e12 + 0.0093e12)  # phase C: the reference's discarded 2b forward (never executed here)
 PEAK_F32_MFMA = 157.3e12              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (f32 in / f32 acc)
 
 
@@ -49,6 +51,9 @@ def parse():
                     help="run the training forward's encoder pass separately from ms-CAM's identical scale-1.0 pass, exactly "
                          "like the reference does (default: computed once and shared; outputs are bit-identical)")
     ap.add_argument("--single-stream", action="store_true", help="run the two students back to back on one stream")
+    ap.add_argument("--gmm-host", action="store_true",
+                    help="phase C only: fit the label-noise GMMs with the reference's host-side sklearn call instead of "
+                         "the device kernel")
     return ap.parse_args()
 
 
@@ -88,7 +93,7 @@ def cpu_baseline(args, C):
                                                                    bkg_thre=0.45, high_thre=0.65,
                                                                    high_target=tuple([0.55] * 80))
     t0 = time.perf_counter()
-    loss, _ = O.train_step_losses(leaf, inputs, cls_label, img_box, args.n_iter, cfg, sargs)
+    loss, _ = O.train_step_losses(leaf, inputs, cls_label, img_box, 5000, cfg, sargs)   # always the phase-B headline step
     loss.backward()
     mom = {}
     for k, p in leaf.items():
@@ -193,9 +198,18 @@ def main():
                             warmup_iter=1500, max_iter=sargs.max_iters, warmup_ratio=1e-6, power=0.9).bind(model.flat_storage)
     par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
     inputs, cls_label, img_box, cls_host = make_batch(args, rank, dev, C)
+    phase = "A" if args.n_iter + args.warmup + args.steps < sargs.cam_iters else ("B" if args.n_iter + args.warmup + args.steps < sargs.gmm_iters else "C")
+    inputs_aug = None
+    if phase == "C":
+        from dupl_amd.synthetic import synthetic_batch
+        aug, _, _ = synthetic_batch(args.batch, C, args.size, seed=1100 + rank)
+        # stand-in for the strongly augmented, w-flipped view of the same images (train_final_voc.py:191)
+        inputs_aug = torch.flip(0.7 * inputs + 0.3 * aug.to(dev), dims=[3]).contiguous()
+        sargs.gmm_on_device = not args.gmm_host
 
     def step(i):
-        return trainer.train_step(ddp, optim, par, inputs, cls_label, img_box, args.n_iter + i, sargs, cls_label_host=cls_host)
+        return trainer.train_step(ddp, optim, par, inputs, cls_label, img_box, args.n_iter + i, sargs, cls_label_host=cls_host,
+                                  inputs_aug=inputs_aug)
 
     def barrier():
         if world > 1:
@@ -225,7 +239,9 @@ def main():
     imgs_per_s = world * args.batch * args.steps / dt
     log(f"timed region: {args.steps} steps in {dt:.3f} s -> {imgs_per_s:.2f} img/s")
 
-    flop_exec = FLOP_PER_IMG_PHASE_AB - (0.0 if args.no_share_encoder else FLOP_SHARED_PASS)
+    flop_ref = FLOP_PER_IMG_PHASE_AB + (FLOP_PHASE_C_AUG + FLOP_PHASE_C_DEAD if phase == "C" else 0.0)
+    flop_exec = FLOP_PER_IMG_PHASE_AB - (0.0 if args.no_share_encoder else FLOP_SHARED_PASS) + \
+        (FLOP_PHASE_C_AUG if phase == "C" else 0.0)
     roof = None
     if not args.no_roofline:
         model.enable_dual_stream(False)   # per-kernel durations are only meaningful without a co-running stream
@@ -242,7 +258,7 @@ def main():
                 "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
                 "kernel_share_of_step": round(gms / ms, 3),
                 "step_frac_of_peak": round(imgs_per_s / world * flop_exec / PEAK_F32_MFMA, 4),
-                "step_flop_per_img": {"reference_algorithm": FLOP_PER_IMG_PHASE_AB, "executed": flop_exec},
+                "step_flop_per_img": {"reference_algorithm": flop_ref, "executed": flop_exec},
                 "note": "HIP event pairs around every launch of the kernel during one extra step run right after the timed "
                         "region (same stream, same workload); algorithmic flops = 2*M*N*K per launch"}
     cpu = None
@@ -251,17 +267,18 @@ def main():
         cpu = cpu_baseline(args, C)
         log(f"cpu baseline: {cpu}")
     if rank == 0:
-        rec = {"metric": f"training img/s at 448^2, {'VOC' if args.dataset == 'voc' else 'COCO'} dual-student ViT-B/16, phase B step",
+        rec = {"metric": f"training img/s at 448^2, {'VOC' if args.dataset == 'voc' else 'COCO'} dual-student ViT-B/16, phase {phase} step",
                "value": round(imgs_per_s, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{'VOC2012' if args.dataset == 'voc' else 'MSCOCO2014'} {args.size}^2 dual-student "
-                                      f"{args.backbone} + ms-CAM(1.0,0.5,1.5) + PAR + cross seg loss, phase B, "
+                                      f"{args.backbone} + ms-CAM(1.0,0.5,1.5) + PAR + cross seg loss, phase {phase}, "
                                       f"{args.batch} img/GPU, DDP world_size={world}",
                           "global_batch": world * args.batch, "img_per_gpu": args.batch, "num_classes": C + 1,
                           "n_iter": args.n_iter, "parallelism": f"dp{world}", "student_streams": 1 if args.single_stream else 2,
                           "forward_precision": args.forward_precision,
                           "shared_scale1_encoder_pass": not args.no_share_encoder,
+                          **({"gmm": "host sklearn" if args.gmm_host else "device"} if phase == "C" else {}),
                           "loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec))

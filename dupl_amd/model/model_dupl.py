@@ -271,22 +271,33 @@ class siamese_network(nn.Module):
             self._store.scale_streams = {}
         return self
 
-    def ms_cam_and_forward(self, inputs, scales):
+    def ms_cam_and_forward(self, inputs, scales, inputs_aug=None):
         """Fused step front-end: for each student the multi-scale CAMs (cam_helper.multi_scale_cam2_siamese) AND the
         training forward (self(inputs)) -- the scale-1.0 un-flipped encoder pass is shared between the two (the
         reference runs it twice with identical weights and input; outputs are identical).
+        With `inputs_aug` (phase C, forward(cat([inputs, inputs_aug]), need_sp=True), model_dupl.py:193-205) the
+        0.75x strong-aug segmentation forward of each student runs on that student's stream too and the result
+        carries "branch1_aug" / "branch2_aug".
         Returns ((cam_1, cam_aux_1), (cam_2, cam_aux_2), {"branch1": ..., "branch2": ...})."""
         from ..utils import cam_helper
         inputs = inputs.contiguous().float()
+        x_aug = None
+        if inputs_aug is not None:
+            H, W = inputs_aug.shape[2:]
+            x_aug = ops.resize_bilinear(inputs_aug.contiguous().float(), int(H * 0.75), int(W * 0.75))
 
         def one(net):
             share = {}
             cams = cam_helper._ms_cam(net._P, inputs, scales, share=share)
             outs = net.forward_shared(share["x"], share["enc"]) if torch.is_grad_enabled() else net(inputs)
-            return cams, outs
+            seg_aug = net(x_aug)[1] if x_aug is not None else None
+            return cams, outs, seg_aug
 
-        (c1, o1), (c2, o2) = self.per_student(lambda: one(self.branch1), lambda: one(self.branch2))
-        return c1, c2, {"branch1": o1, "branch2": o2}
+        (c1, o1, a1), (c2, o2, a2) = self.per_student(lambda: one(self.branch1), lambda: one(self.branch2))
+        res = {"branch1": o1, "branch2": o2}
+        if x_aug is not None:
+            res["branch1_aug"], res["branch2_aug"] = a1, a2
+        return c1, c2, res
 
     def per_student(self, fn1, fn2):
         """Evaluate fn1() for student 1 and fn2() for student 2, concurrently when dual-stream is enabled."""
@@ -347,10 +358,10 @@ class siamese_network(nn.Module):
                 x, x_aug = x.chunk(2)
                 b, _, H, W = x_aug.shape
                 x_aug = ops.resize_bilinear(x_aug.contiguous(), int(H * 0.75), int(W * 0.75))
-                res["branch1"] = self.branch1(x)
-                res["branch2"] = self.branch2(x)
-                res["branch1_aug"] = self.branch1(x_aug)[1]
-                res["branch2_aug"] = self.branch2(x_aug)[1]
+                # the reference first runs both students on the whole 2b batch and discards the result
+                # (model_dupl.py:190-191): that dead forward is not computed here
+                (res["branch1"], res["branch1_aug"]), (res["branch2"], res["branch2_aug"]) = self.per_student(
+                    lambda: (self.branch1(x), self.branch1(x_aug)[1]), lambda: (self.branch2(x), self.branch2(x_aug)[1]))
                 return res
             res["branch1"], res["branch2"] = self.per_student(lambda: self.branch1(x), lambda: self.branch2(x))
             return res

@@ -75,8 +75,8 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     `cls_label_host`: CPU copy of `cls_label` (the data loader has it anyway); with it phases A and B contain no
     host<->device synchronisation at all and the host can run a full step ahead of the GPU.
     Phase C (n_iter >= gmm_iters, train_final_voc.py:358-436) needs `inputs_aug`, the strongly augmented + w-flipped
-    batch from the data pipeline (train_final_voc.py:191); its GMM filter is the reference's host-side sklearn call
-    (one device->host transfer of the CE maps per step, like the reference)."""
+    batch from the data pipeline (train_final_voc.py:191); its GMM filter runs on the device (csrc/gmm.hip) unless
+    args.gmm_on_device is False (then: the reference's host-side sklearn call, one D2H of the CE maps per step)."""
     if cls_label_host is None:
         cls_label_host = cls_label.detach().cpu()
     phase_c = n_iter >= args.gmm_iters
@@ -88,7 +88,7 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     inputs_denorm = ops.denormalize_img(inputs.contiguous()) if not phase_a else None
 
     core = model.module if hasattr(model, "module") else model
-    if phase_c or not args.share_encoder_pass:
+    if not args.share_encoder_pass:
         (cams_1, cams_aux_1), (cams_2, cams_aux_2) = core.per_student(
             lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=1),
             lambda: cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=2))
@@ -99,7 +99,8 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     else:
         # the scale-1.0 un-flipped ms-CAM encoder pass and the training forward see the same weights and input:
         # run it once, with activation saving, and feed both (reference: cam_helper.py:171 then train_final_voc.py:204)
-        (cams_1, cams_aux_1), (cams_2, cams_aux_2), res = core.ms_cam_and_forward(inputs, args.cam_scales)
+        (cams_1, cams_aux_1), (cams_2, cams_aux_2), res = core.ms_cam_and_forward(
+            inputs, args.cam_scales, inputs_aug=inputs_aug if phase_c else None)
     cls_1, segs_1, fmap_1, cls_aux_1 = res["branch1"]
     cls_2, segs_2, fmap_2, cls_aux_2 = res["branch2"]
 

@@ -235,7 +235,10 @@ def test_tiny_phase_c_matches_reference(dev, golden_dir, gmm_on_device):
     inputs, cls_label, img_box = O.synthetic_batch(2, NC - 1, 128, seed=9)
     aug, _, _ = O.synthetic_batch(2, NC - 1, 128, seed=19)
     aug = torch.flip(0.7 * inputs + 0.3 * aug, dims=[3]).contiguous()
-    args = trainer.StepArgs(gmm_on_device=gmm_on_device)
+    # device GMM + shared scale-1.0 pass + two student streams (the default product path)  vs  host sklearn + the
+    # reference's separate passes on one stream
+    args = trainer.StepArgs(gmm_on_device=gmm_on_device, share_encoder_pass=gmm_on_device)
+    model.enable_dual_stream(gmm_on_device)
     model.flat_storage.grad.zero_()
     loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, int(g["n_iter"]), args,
                                        cls_label_host=cls_label, inputs_aug=aug.to(dev))
