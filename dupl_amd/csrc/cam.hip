@@ -6,19 +6,6 @@
 
 namespace {
 
-// PyTorch upsample_bilinear2d source index (align_corners False clamps negatives to 0)
-__device__ __forceinline__ void bil_src(int o, float scale, int in, bool align, int& i0, int& i1, float& l1) {
-    float r = align ? scale * o : fmaxf(scale * (o + 0.5f) - 0.5f, 0.f);
-    i0 = (int)r;
-    if (i0 > in - 1) i0 = in - 1;
-    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
-    l1 = r - (float)i0;
-}
-__device__ __forceinline__ float bil_scale(int in, int out, bool align) {
-    if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    return (float)in / (float)out;
-}
-
 __global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int Hi, int Wi,
                                        int Ho, int Wo, int flip_cat, int align) {
     const long total = (long)B * C * Ho * Wo;

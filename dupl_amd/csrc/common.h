@@ -17,6 +17,19 @@ static inline int dupl_launch_status() {
     return e == hipSuccess ? DUPL_OK : DUPL_ERR_LAUNCH;
 }
 
+// PyTorch upsample_bilinear2d source index (align_corners False clamps negatives to 0)
+__device__ __forceinline__ void bil_src(int o, float scale, int in, bool align, int& i0, int& i1, float& l1) {
+    float r = align ? scale * o : fmaxf(scale * (o + 0.5f) - 0.5f, 0.f);
+    i0 = (int)r;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = r - (float)i0;
+}
+__device__ __forceinline__ float bil_scale(int in, int out, bool align) {
+    if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    return (float)in / (float)out;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -6,7 +6,10 @@
 namespace {
 
 // x (B,3,H,W) -> rows [B*h*w][3*P*P] (column = c*P*P + py*P + px).  One float4 per thread.
-__global__ void patch_im2row_kernel(const float* __restrict__ x, float* __restrict__ rows, int B, int H, int W, int P) {
+// H, W need not be multiples of P: like the stride-P convolution it replaces, the trailing H % P rows / W % P columns
+// are ignored (tools/eval_seg_voc.py feeds int(h * 1.25)-sized images).  vec: rows are 16-byte aligned (W % 4 == 0).
+__global__ void patch_im2row_kernel(const float* __restrict__ x, float* __restrict__ rows, int B, int H, int W, int P,
+                                    int vec) {
     const int h = H / P, w = W / P;
     const int K = 3 * P * P, K4 = K / 4;
     const long total = (long)B * h * w * K4;
@@ -16,7 +19,10 @@ __global__ void patch_im2row_kernel(const float* __restrict__ x, float* __restri
         const int pw = (int)(r % w), ph = (int)((r / w) % h), b = (int)(r / ((long)w * h));
         const int k = k4 * 4;
         const int c = k / (P * P), rem = k - c * P * P, py = rem / P, px = rem - py * P;
-        const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * 3 + c) * H + ph * P + py) * W + pw * P + px);
+        const float* src = x + (((long)b * 3 + c) * H + ph * P + py) * W + pw * P + px;
+        float4 v;
+        if (vec) v = *reinterpret_cast<const float4*>(src);
+        else v = make_float4(src[0], src[1], src[2], src[3]);
         *reinterpret_cast<float4*>(rows + r * K + k) = v;
     }
 }
@@ -182,9 +188,10 @@ inline int ew_grid(long n, int per = 256) {
 
 extern "C" int dupl_patch_im2row(const float* x, float* rows, int32_t B, int32_t H, int32_t W, int32_t P, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
-    if (!x || !rows || B <= 0 || P <= 0 || (P & 3) || H % P || W % P) return DUPL_ERR_ARG;
-    const long total = (long)B * 3 * H * W / 4;
-    hipLaunchKernelGGL(patch_im2row_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, x, rows, B, H, W, P);
+    if (!x || !rows || B <= 0 || P <= 0 || (P & 3) || H < P || W < P) return DUPL_ERR_ARG;
+    const long total = (long)B * (H / P) * (W / P) * 3 * P * P / 4;
+    const int vec = ((W & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    hipLaunchKernelGGL(patch_im2row_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, x, rows, B, H, W, P, vec);
     return dupl_launch_status();
 }
 

@@ -362,3 +362,49 @@ def scale_(y: Tensor, a: float):
 def zeros(shape, device) -> Tensor:
     t = torch.empty(shape, device=device, dtype=torch.float32)
     return fill_(t, 0.0)
+
+
+# ------------------------------------------------------------------------------------------ validation / evaluation
+def upsample_argmax(logits: Tensor, H: int, W: int) -> Tensor:
+    """argmax_c of the bilinear (align_corners=False) up-sampling of logits (B,C,h,w) to (H,W) -> (B,H,W) int64."""
+    B, C, h, w = logits.shape
+    logits = _chk(logits.contiguous())
+    out = torch.empty((B, H, W), device=logits.device, dtype=torch.int64)
+    L().dupl_upsample_argmax(logits.data_ptr(), out.data_ptr(), B, C, h, w, int(H), int(W), _stream())
+    return out
+
+
+def msc_seg_accum_(acc: Tensor, segs: Tensor, first: bool) -> Tensor:
+    """acc (1,C,H,W) = [max with] up(segs[0]) + flip(up(segs[1])), segs (2,C,h,w): one scale of eval_seg_voc.py:58-72."""
+    two, C, h, w = segs.shape
+    assert two == 2 and acc.shape[1] == C and acc.is_contiguous()
+    segs = _chk(segs.contiguous())
+    H, W = acc.shape[-2:]
+    L().dupl_msc_seg_accum(segs.data_ptr(), acc.data_ptr(), C, h, w, H, W, int(first), _stream())
+    return acc
+
+
+def argmax_channels(x: Tensor) -> Tensor:
+    B, C = x.shape[:2]
+    HW = x[0, 0].numel()
+    x = _chk(x.contiguous())
+    out = torch.empty((B,) + tuple(x.shape[2:]), device=x.device, dtype=torch.int64)
+    L().dupl_argmax_channels(x.data_ptr(), out.data_ptr(), B, C, HW, _stream())
+    return out
+
+
+def confusion_accum(gt: Tensor, pred: Tensor, hist: Tensor) -> Tensor:
+    """hist (nc,nc) int64 += confusion counts of the pixels with 0 <= gt < nc (evaluate._fast_hist)."""
+    assert gt.dtype == torch.int64 and pred.dtype == torch.int64 and hist.dtype == torch.int64
+    assert gt.numel() == pred.numel() and gt.is_cuda and pred.is_cuda and hist.is_cuda and hist.is_contiguous()
+    gt, pred = gt.contiguous(), pred.contiguous()
+    L().dupl_confusion_accum(gt.data_ptr(), pred.data_ptr(), gt.numel(), hist.shape[0], hist.data_ptr(), _stream())
+    return hist
+
+
+def multilabel_f1_accum(logits: Tensor, label: Tensor, total: Tensor) -> Tensor:
+    """total[0] += sum over rows of f1((logits > 0), label)  (evaluate.multilabel_score per image)."""
+    B, C = logits.shape
+    logits, label = _chk(logits.contiguous()), _chk(label.contiguous().float())
+    L().dupl_multilabel_f1_accum(logits.data_ptr(), label.data_ptr(), B, C, total.data_ptr(), _stream())
+    return total

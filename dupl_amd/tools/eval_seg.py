@@ -1,0 +1,69 @@
+"""Offline multi-scale + flip segmentation inference (reference: tools/eval_seg_voc.py:38-91,154-193 and
+tools/eval_seg_coco_ddp.py:54-139), pre-CRF.
+
+    python -m dupl_amd.tools.eval_seg --model_path work_dir/checkpoints/checkpoint.pth ...   (needs a data loader)
+
+`msc_seg_logits` is the per-image core: for every scale the two students run on [x_s; flip(x_s)], the low-resolution
+logits are up-sampled to the label size, the flipped half is flipped back and added, and the scales are combined with
+an element-wise max -- fused into one accumulate kernel per scale (csrc/eval.hip::msc_seg_accum_kernel), so the
+(3, 2, C, H, W) stack the reference builds is never materialised.  `load_checkpoint` reads the reference's checkpoint
+format (torch.save(model.state_dict()) of the DDP-wrapped model: keys prefixed `module.`, train_final_voc.py:514-519).
+DenseCRF post-processing (utils/dcrf.py) is a CPU third-party step and stays outside this package."""
+from collections import OrderedDict
+
+import torch
+
+from .. import ops
+from ..utils import evaluate
+from ..utils.pyutils import format_tabs
+
+
+def load_checkpoint(model, path_or_state):
+    """tools/eval_seg_voc.py:173-178: strip the DDP `module.` prefix and load strictly."""
+    sd = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, str) else path_or_state
+    new = OrderedDict((k.replace("module.", ""), v) for k, v in sd.items())
+    model.load_state_dict(new, strict=True)
+    return model
+
+
+def msc_seg_logits(model, inputs, out_size, scales=(1.0, 1.5, 1.25)):
+    """inputs (1,3,h,w) on the device -> (seg_1, seg_2), each (1,C1,H,W): eval_seg_voc.py:52-75."""
+    assert inputs.shape[0] == 1
+    core = model.module if hasattr(model, "module") else model
+    _, _, h, w = inputs.shape
+    H, W = int(out_size[0]), int(out_size[1])
+    accs = None
+    with torch.no_grad():
+        for i, sc in enumerate(scales):
+            # F.interpolate(inputs, [int(h*sc), int(w*sc)]) and cat([x, x.flip(-1)]) in one kernel (flip_cat)
+            cat = ops.resize_bilinear(inputs.contiguous().float(), int(h * sc), int(w * sc), flip_cat=True)
+            res = core(cat)
+            segs = (res["branch1"][1], res["branch2"][1])
+            if accs is None:
+                C1 = segs[0].shape[1]
+                accs = [torch.empty((1, C1, H, W), device=inputs.device, dtype=torch.float32) for _ in range(2)]
+            for acc, s in zip(accs, segs):
+                ops.msc_seg_accum_(acc, s, first=(i == 0))
+    return accs[0], accs[1]
+
+
+def validate(model, data_loader, args, num_classes=21, cat_list=None, keep_logits=None):
+    """eval_seg_voc._validate: multi-scale seg predictions of both students over a loader of
+    (name, inputs (1,3,h,w), labels (1,H,W), cls_label) -> (seg_score_1, seg_score_2).
+    keep_logits(name, branch, logits) is called with the (1,C1,H,W) device logits (the reference np.save()s them for the
+    CRF stage)."""
+    from ..utils.train_helper import _device_of, _fetch
+    dev = _device_of(model)
+    cms = [evaluate.ConfusionMatrix(num_classes, dev) for _ in range(2)]
+    model.eval()
+    for data in data_loader:
+        inputs, labels, _ = _fetch(data, dev)
+        seg = msc_seg_logits(model, inputs, labels.shape[1:], getattr(args, "scales", (1.0, 1.5, 1.25)))
+        for k in range(2):
+            cms[k].update(labels, ops.argmax_channels(seg[k]))
+            if keep_logits is not None:
+                keep_logits(data[0], k + 1, seg[k])
+    sc = [c.scores() for c in cms]
+    if cat_list is not None:
+        print(format_tabs(sc, ["Seg_1", "Seg_2"], cat_list=cat_list))
+    return sc[0], sc[1]

@@ -79,7 +79,7 @@ def setup_seed(seed):
     random.seed(seed)
 
 
-def train(args, dataset: str, loader=None):
+def train(args, dataset: str, loader=None, val_loader=None):
     from .ddp import DistributedDataParallel
     from .model.model_dupl import siamese_network
     from .model.PAR import PAR
@@ -152,6 +152,19 @@ def train(args, dataset: str, loader=None):
             os.makedirs(args.ckpt_dir, exist_ok=True)
             sd = wrapped.state_dict() if distributed else {"module." + k: v for k, v in model.state_dict().items()}
             torch.save(sd, os.path.join(args.ckpt_dir, "checkpoint.pth"))     # keys prefixed `module.` (train_final_voc.py:519)
+        if (n_iter + 1) % args.eval_iters == 0 and rank == 0:
+            # in-loop validation on rank 0 (train_final_voc.py:521-533); with no dataset mounted a few synthetic
+            # native-size samples stand in for the val split so that the path is exercised end to end
+            vl = val_loader
+            if vl is None:
+                from .synthetic_val import synthetic_val_samples
+                vl = [((f"synthetic{i}",), x, lab, cls) for i, (x, lab, cls) in enumerate(
+                    synthetic_val_samples(sizes=((375, 500), (333, 500), (500, 375)), num_fg=C, seed=n_iter))]
+            validate = train_helper.validate_siamase if voc else train_helper.validate_siamase_coco
+            tv = time.time()
+            s1, s2, tab, items = validate(model=wrapped, data_loader=vl, args=args, return_item=True)
+            logging.info("val cls score: %.6f (branch1) %.6f (branch2); %d images in %.2fs" % (s1, s2, len(vl), time.time() - tv))
+            logging.info("\n" + tab)
     torch.cuda.synchronize()
     if distributed:
         dist.destroy_process_group()

@@ -254,6 +254,25 @@ int dupl_fill(float* p, float v, int64_t n, dupl_stream_t s);
 int dupl_axpy(float* y, const float* x, float a, int64_t n, dupl_stream_t s); /* y += a*x */
 int dupl_scale(float* y, float a, int64_t n, dupl_stream_t s);
 
+/* ------------------------------------------------------------------ validation / evaluation */
+/* torch.argmax(F.interpolate(logits, (H,W), 'bilinear', align_corners=False), dim=1) fused: logits (B,C,h,w) NCHW ->
+ * out (B,H,W) int64 (utils/train_helper.py:143-145, the Seg_k prediction of validate_siamase). */
+int dupl_upsample_argmax(const float* logits, int64_t* out, int32_t B, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W,
+                         dupl_stream_t s);
+/* one scale of tools/eval_seg_voc.py:58-72: segs (2,C,h,w) = the logits of [x; flip(x)]; v = up(segs[0]) +
+ * flip(up(segs[1])) at (H,W); acc (C,H,W) = v when first != 0, else max(acc, v) (the max over scales). */
+int dupl_msc_seg_accum(const float* segs, float* acc, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W, int32_t first,
+                       dupl_stream_t s);
+/* argmax over the channel axis of x (B,C,HW) -> out (B,HW) int64, first maximum wins */
+int dupl_argmax_channels(const float* x, int64_t* out, int32_t B, int32_t C, int64_t HW, dupl_stream_t s);
+/* utils/evaluate.py:9-16 (_fast_hist) accumulated on the device: hist[t*nc + p] += 1 over the n pixels with
+ * 0 <= gt < nc (predictions outside [0,nc) are skipped as well).  hist: nc*nc int64, zeroed by the caller. */
+int dupl_confusion_accum(const int64_t* gt, const int64_t* pred, int64_t n, int32_t num_classes, int64_t* hist,
+                         dupl_stream_t s);
+/* utils/evaluate.py:4-6 (sklearn f1_score of one multi-hot row): sum[0] += 2TP/(2TP+FP+FN) of (logits > 0) vs label,
+ * per row of (B,C). */
+int dupl_multilabel_f1_accum(const float* logits, const float* label, int32_t B, int32_t C, float* sum, dupl_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

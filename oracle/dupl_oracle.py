@@ -638,3 +638,97 @@ def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tens
     return loss, pieces
 
 
+
+
+# ----------------------------------------------------------------------------------------------
+# in-loop validation, mIoU, offline multi-scale segmentation inference
+# ----------------------------------------------------------------------------------------------
+def fast_hist(label_true: np.ndarray, label_pred: np.ndarray, num_classes: int) -> np.ndarray:
+    """utils/evaluate.py:9-16: confusion matrix of the pixels whose ground truth is in [0, num_classes)."""
+    mask = (label_true >= 0) & (label_true < num_classes)
+    hist = np.bincount(num_classes * label_true[mask].astype(int) + label_pred[mask], minlength=num_classes ** 2)
+    return hist.reshape(num_classes, num_classes)
+
+
+def scores_from_hist(hist: np.ndarray) -> Dict[str, object]:
+    """utils/evaluate.py:22-36 (the part of `scores` after the histogram): pAcc, mAcc, mIoU over the classes that
+    occur in the ground truth, per-class IoU (nan where a class never occurs in truth or prediction)."""
+    hist = hist.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        acc = np.diag(hist).sum() / hist.sum()
+        acc_cls = np.nanmean(np.diag(hist) / hist.sum(axis=1))
+        iu = np.diag(hist) / (hist.sum(axis=1) + hist.sum(axis=0) - np.diag(hist))
+    valid = hist.sum(axis=1) > 0
+    return {"pAcc": acc, "mAcc": acc_cls, "miou": np.nanmean(iu[valid]), "iou": dict(zip(range(hist.shape[0]), iu))}
+
+
+def scores(label_trues, label_preds, num_classes: int = 21) -> Dict[str, object]:
+    """utils/evaluate.py:18-36."""
+    hist = np.zeros((num_classes, num_classes))
+    for lt, lp in zip(label_trues, label_preds):
+        hist += fast_hist(np.asarray(lt).flatten(), np.asarray(lp).flatten(), num_classes)
+    return scores_from_hist(hist)
+
+
+def multilabel_f1(y_true: np.ndarray, y_pred: np.ndarray) -> float:
+    """utils/evaluate.py:4-6 = sklearn.metrics.f1_score(y_true, y_pred) for one binary label vector:
+    2TP / (2TP + FP + FN), 0 when that denominator is 0 (sklearn's zero_division default, with a warning)."""
+    tp = float(((y_true == 1) & (y_pred == 1)).sum())
+    fp = float(((y_true == 0) & (y_pred == 1)).sum())
+    fn = float(((y_true == 1) & (y_pred == 0)).sum())
+    den = 2 * tp + fp + fn
+    return 2 * tp / den if den > 0 else 0.0
+
+
+def validate_siamese(params: Dict[str, Tensor], samples, cfg: ViTConfig, crop_size: int, num_classes: int = 21,
+                     args: "StepArgs" = None, scales=(1.0, 0.5, 1.5)):
+    """validate_siamase / validate_siamase_coco (utils/train_helper.py:90-185, 188-283).
+    samples: iterable of (inputs (1,3,H,W) float, labels (1,H,W) integer, cls_label (1,C)).
+    Returns {"cls_score_1","cls_score_2", "hist": {name: (nc,nc) int64}, "scores": {name: scores dict},
+             "maps": {name: [per-image int16 maps]}} with names CAM_1, aux_CAM_1, Seg_1, CAM_2, aux_CAM_2, Seg_2."""
+    args = args or StepArgs()
+    names = ["CAM_1", "aux_CAM_1", "Seg_1", "CAM_2", "aux_CAM_2", "Seg_2"]
+    maps = {n: [] for n in names}
+    gts, f1 = [], {1: [], 2: []}
+    p = {1: sub_params(params, "branch1."), 2: sub_params(params, "branch2.")}
+    with torch.no_grad():
+        for inputs, labels, cls_label in samples:
+            x = F.interpolate(inputs, size=[crop_size, crop_size], mode="bilinear", align_corners=False)
+            gts.append(labels[0].numpy().astype(np.int16))
+            for k in (1, 2):
+                cls, segs, _, _ = network_forward(p[k], x, cfg)
+                pred = (cls > 0).to(torch.int16)
+                f1[k].append(multilabel_f1(cls_label.numpy()[0], pred.numpy()[0]))
+                cam, cam_aux = multi_scale_cam(p[k], x, cfg, scales)
+                size = labels.shape[1:]
+                for nm, c in ((f"CAM_{k}", cam), (f"aux_CAM_{k}", cam_aux)):
+                    rc = F.interpolate(c, size=size, mode="bilinear", align_corners=False)
+                    lab = cam_to_label(rc, cls_label, bkg_thre=args.bkg_thre, high_thre=args.high_thre,
+                                       low_thre=args.low_thre, ignore_index=args.ignore_index)
+                    maps[nm].append(lab[0].numpy().astype(np.int16))
+                rs = F.interpolate(segs, size=size, mode="bilinear", align_corners=False)
+                maps[f"Seg_{k}"].append(torch.argmax(rs, dim=1)[0].numpy().astype(np.int16))
+    hist = {}
+    for n in names:
+        h = np.zeros((num_classes, num_classes), dtype=np.int64)
+        for lt, lp in zip(gts, maps[n]):
+            h += fast_hist(lt.flatten(), lp.flatten(), num_classes)
+        hist[n] = h
+    return {"cls_score_1": float(np.mean(f1[1])), "cls_score_2": float(np.mean(f1[2])), "hist": hist,
+            "scores": {n: scores_from_hist(hist[n]) for n in names}, "maps": maps, "gts": gts}
+
+
+def msc_seg_logits(p: Dict[str, Tensor], inputs: Tensor, out_size, cfg: ViTConfig, scales=(1.0, 1.5, 1.25)) -> Tensor:
+    """One student's multi-scale + flip segmentation logits (tools/eval_seg_voc.py:52-75): per scale, the logits of
+    [x; flip(x)] are up-sampled to the label size and summed (the flipped one flipped back); the scales are combined
+    with an element-wise max.  inputs (1,3,h,w) -> (1,C1,H,W)."""
+    _, _, h, w = inputs.shape
+    per_scale = []
+    with torch.no_grad():
+        for sc in scales:
+            xi = F.interpolate(inputs, size=[int(h * sc), int(w * sc)], mode="bilinear", align_corners=False)
+            cat = torch.cat([xi, xi.flip(-1)], dim=0)
+            _, segs, _, _ = network_forward(p, cat, cfg)
+            segs = F.interpolate(segs, size=out_size, mode="bilinear", align_corners=False)
+            per_scale.append(segs[:1] + segs[1:].flip(-1))
+    return torch.max(torch.stack(per_scale, dim=0), dim=0)[0]

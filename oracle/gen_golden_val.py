@@ -1,0 +1,135 @@
+"""Golden vectors for SURVEY 8f-2 (in-loop validation + mIoU) and 8f-4 (multi-scale segmentation inference)
+(authoring container only; needs /root/reference).  Run:  python oracle/gen_golden_val.py
+
+The reference's `utils/train_helper.py` and `tools/eval_seg_voc.py` cannot be imported here (texttable, imageio,
+torchvision, joblib are absent), so -- as oracle/gen_golden.py does for the training step -- the REFERENCE'S OWN
+pieces (siamese_network.forward, cam_helper.multi_scale_cam2_siamese, cam_helper.cam_to_label, utils.evaluate.scores /
+multilabel_score; F.interpolate / argmax) are composed exactly as validate_siamase (train_helper.py:90-185) and
+eval_seg_voc._validate (tools/eval_seg_voc.py:38-91) compose them, and the oracle's restatement is asserted equal.
+Writes tests/golden/val_tiny.npz (data only)."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+
+from oracle import dupl_oracle as O  # noqa: E402
+from oracle.gen_golden import import_reference, npz, close, REF  # noqa: E402
+from dupl_amd.synthetic_val import synthetic_val_samples  # noqa: E402
+
+
+def main():
+    torch.set_num_threads(8)
+    R = import_reference()
+    CH = R["cam_helper"]
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_evaluate", os.path.join(REF, "utils", "evaluate.py"))
+    EV = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(EV)
+
+    cfg, NC, crop = O.VIT_TINY, 21, 64
+    pp = O.make_siamese_params(cfg, NC, seed=2)
+    # sharpen the heads so that CAM labels / seg argmax are not degenerate with hash-initialised weights
+    pp = {k: (v * 6.0 if ("classifier.weight" in k or k.endswith("decoder.conv8.weight")) else v) for k, v in pp.items()}
+    sia = R["siamese"]("tiny_test", num_classes=NC, pretrained=False, aux_layer=-3)
+    sia.load_state_dict(pp, strict=True)
+    sia.eval()
+    args = O.StepArgs()
+    samples = synthetic_val_samples()
+
+    # ---- validate_siamase, composed from the reference's functions (train_helper.py:90-185)
+    names = ["CAM_1", "aux_CAM_1", "Seg_1", "CAM_2", "aux_CAM_2", "Seg_2"]
+    maps = {n: [] for n in names}
+    gts, f1 = [], {1: [], 2: []}
+    with torch.no_grad():
+        for inputs, labels, cls_label in samples:
+            x = F.interpolate(inputs, size=[crop, crop], mode="bilinear", align_corners=False)
+            res = sia(x, val=True)
+            gts.append(labels[0].numpy().astype(np.int16))
+            for k in (1, 2):
+                _cls, _segs, _, _ = res[f"branch{k}"]
+                cls_pred = (_cls > 0).type(torch.int16)
+                f1[k].append(EV.multilabel_score(cls_label.numpy()[0], cls_pred.numpy()[0]))
+                _cams, _cams_aux = CH.multi_scale_cam2_siamese(sia, inputs=x, scales=args.cam_scales, branch=k)
+                for nm, c in ((f"CAM_{k}", _cams), (f"aux_CAM_{k}", _cams_aux)):
+                    rc = F.interpolate(c, size=labels.shape[1:], mode="bilinear", align_corners=False)
+                    lab = CH.cam_to_label(rc, cls_label, bkg_thre=args.bkg_thre, high_thre=args.high_thre,
+                                          low_thre=args.low_thre, ignore_index=args.ignore_index)
+                    maps[nm].append(lab[0].numpy().astype(np.int16))
+                rs = F.interpolate(_segs, size=labels.shape[1:], mode="bilinear", align_corners=False)
+                maps[f"Seg_{k}"].append(torch.argmax(rs, dim=1)[0].numpy().astype(np.int16))
+    ref_scores = {n: EV.scores(gts, maps[n], num_classes=NC) for n in names}
+    ref_hist = {n: sum(EV._fast_hist(lt.flatten(), lp.flatten(), NC) for lt, lp in zip(gts, maps[n])) for n in names}
+    cls_score = [float(np.mean(f1[1])), float(np.mean(f1[2]))]
+
+    o = O.validate_siamese(pp, samples, cfg, crop, NC, args, scales=args.cam_scales)
+    for n in names:
+        for a, b in zip(o["maps"][n], maps[n]):
+            assert np.array_equal(a, b), n
+        assert np.array_equal(o["hist"][n], ref_hist[n]), n
+        assert abs(o["scores"][n]["miou"] - ref_scores[n]["miou"]) < 1e-12, n
+        assert abs(o["scores"][n]["pAcc"] - ref_scores[n]["pAcc"]) < 1e-12, n
+        ia = np.array(list(o["scores"][n]["iou"].values()))
+        ib = np.array(list(ref_scores[n]["iou"].values()))
+        assert np.allclose(ia, ib, equal_nan=True), n
+    assert abs(o["cls_score_1"] - cls_score[0]) < 1e-12 and abs(o["cls_score_2"] - cls_score[1]) < 1e-12
+    print("validate_siamase: oracle == reference composition;",
+          {n: round(float(ref_scores[n]['miou']), 4) for n in names}, "cls f1", cls_score,
+          "label histogram Seg_1:", np.unique(np.concatenate([m.flatten() for m in maps['Seg_1']]), return_counts=True))
+
+    # ---- multi-scale + flip segmentation inference (tools/eval_seg_voc.py:52-75) on the native-size images
+    scales = (1.0, 1.5, 1.25)
+    msc, preds = {1: [], 2: []}, {1: [], 2: []}
+    with torch.no_grad():
+        for inputs, labels, cls_label in samples:
+            _, _, h, w = inputs.shape
+            lists = {1: [], 2: []}
+            for sc in scales:
+                _inputs = F.interpolate(inputs, size=[int(h * sc), int(w * sc)], mode="bilinear", align_corners=False)
+                inputs_cat = torch.cat([_inputs, _inputs.flip(-1)], dim=0)
+                res = sia(inputs_cat)
+                for k in (1, 2):
+                    segs = F.interpolate(res[f"branch{k}"][1], size=labels.shape[1:], mode="bilinear", align_corners=False)
+                    lists[k].append(segs[:1, ...] + segs[1:, ...].flip(-1))
+            for k in (1, 2):
+                seg = torch.max(torch.stack(lists[k], dim=0), dim=0)[0]
+                msc[k].append(seg)
+                preds[k].append(torch.argmax(seg, dim=1)[0].numpy().astype(np.int16))
+    for k in (1, 2):
+        p = O.sub_params(pp, f"branch{k}.")
+        for (inputs, labels, _), r in zip(samples, msc[k]):
+            om = O.msc_seg_logits(p, inputs, labels.shape[1:], cfg, scales)
+            close(om, r, 2e-5, f"msc seg branch{k}")
+    seg_scores = {k: EV.scores(gts, preds[k], num_classes=NC) for k in (1, 2)}
+    print("eval_seg: oracle == reference composition; mIoU", {k: round(float(seg_scores[k]['miou']), 4) for k in (1, 2)})
+
+    def iou_arr(s):
+        return np.array(list(s["iou"].values()), dtype=np.float64)
+
+    arrays = dict(crop_size=crop, scales=np.array(scales), cls_scores=np.array(cls_score),
+                  msc_miou=np.array([seg_scores[1]["miou"], seg_scores[2]["miou"]]),
+                  msc_iou_1=iou_arr(seg_scores[1]), msc_iou_2=iou_arr(seg_scores[2]))
+    for n in names:
+        arrays[f"hist.{n}"] = ref_hist[n].astype(np.int64)
+        arrays[f"miou.{n}"] = np.float64(ref_scores[n]["miou"])
+        arrays[f"pacc.{n}"] = np.float64(ref_scores[n]["pAcc"])
+        arrays[f"macc.{n}"] = np.float64(ref_scores[n]["mAcc"])
+        arrays[f"iou.{n}"] = iou_arr(ref_scores[n])
+        for i, m in enumerate(maps[n]):
+            arrays[f"map.{n}.{i}"] = m.astype(np.uint8)
+    for k in (1, 2):
+        for i, (m, pr) in enumerate(zip(msc[k], preds[k])):
+            arrays[f"msc_logits.{k}.{i}"] = m[:, :, ::3, ::3].contiguous()
+            arrays[f"msc_pred.{k}.{i}"] = pr.astype(np.uint8)
+    npz("val_tiny", **arrays)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+"""SURVEY 8f-2 / 8f-4 on the GPU: in-loop validation (validate_siamase), device confusion matrices / mIoU, multi-scale
+segmentation inference and the reference checkpoint format, against tests/golden/val_tiny.npz (made by
+oracle/gen_golden_val.py from the reference's own functions) and against the oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["CAM_1", "aux_CAM_1", "Seg_1", "CAM_2", "aux_CAM_2", "Seg_2"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _tiny_model(dev):
+    from dupl_amd.model.model_dupl import siamese_network
+    from oracle import dupl_oracle as O
+    pp = O.make_siamese_params(O.VIT_TINY, 21, seed=2)
+    pp = {k: (v * 6.0 if ("classifier.weight" in k or k.endswith("decoder.conv8.weight")) else v) for k, v in pp.items()}
+    model = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    model.load_state_dict(pp, strict=True)
+    return model.to(dev), pp
+
+
+def _loader():
+    from dupl_amd.synthetic_val import synthetic_val_samples
+    return [((f"img{i}",), x, lab, cls) for i, (x, lab, cls) in enumerate(synthetic_val_samples())]
+
+
+def test_confusion_f1_argmax_kernels(dev):
+    from dupl_amd import ops
+    from dupl_amd.utils import evaluate
+    rng = np.random.RandomState(0)
+    for nc, n in ((21, 100_003), (81, 250_000), (200, 50_000)):
+        gt = rng.randint(0, nc + 2, size=n).astype(np.int64)
+        gt[rng.rand(n) < 0.1] = 255
+        pred = rng.randint(0, nc, size=n).astype(np.int64)
+        cm = evaluate.ConfusionMatrix(nc, dev)
+        cm.update(torch.from_numpy(gt).to(dev), torch.from_numpy(pred).to(dev))
+        cm.update(torch.from_numpy(gt[: n // 2]).to(dev), torch.from_numpy(pred[: n // 2]).to(dev))
+        ref = evaluate._fast_hist(gt, pred, nc) + evaluate._fast_hist(gt[: n // 2], pred[: n // 2], nc)
+        assert np.array_equal(cm.hist.cpu().numpy(), ref)
+    logits = torch.randn(3, 21, 13, 17)
+    up = F.interpolate(logits, size=(75, 100), mode="bilinear", align_corners=False)
+    got = ops.upsample_argmax(logits.to(dev), 75, 100).cpu()
+    assert int((got != up.argmax(1)).sum()) <= 2
+    assert torch.equal(ops.argmax_channels(up.to(dev)).cpu(), up.argmax(1))
+    from sklearn.metrics import f1_score
+    cls = torch.randn(5, 20)
+    lab = (torch.rand(5, 20) < 0.2).float()
+    lab[3] = 0
+    cls[3] = -1.0                      # no positives anywhere: f1 = 0
+    tot = torch.zeros(1, device=dev)
+    ops.multilabel_f1_accum(cls.to(dev), lab.to(dev), tot)
+    ref = sum(f1_score(lab[i].numpy(), (cls[i] > 0).numpy().astype(np.float32), zero_division=0) for i in range(5))
+    assert abs(float(tot.item()) - ref) < 1e-5
+
+
+def _cam_tie_pixels(pp, crop):
+    """Pixels whose CAM label is decided by a floating-point tie: min-max normalisation maps the maximum of EVERY
+    class plane to 1/(1+1e-5), so two present classes that peak at the same location differ by rounding only (the
+    oracle itself flips such pixels between machines).  Returned per confusion-matrix name."""
+    from oracle import dupl_oracle as O
+    from dupl_amd.synthetic_val import synthetic_val_samples
+    ties = {n: 0 for n in NAMES}
+    with torch.no_grad():
+        for x, lab, cls in synthetic_val_samples():
+            xin = F.interpolate(x, size=[crop, crop], mode="bilinear", align_corners=False)
+            for k in (1, 2):
+                cams = O.multi_scale_cam(O.sub_params(pp, f"branch{k}."), xin, O.VIT_TINY, (1.0, 0.5, 1.5))
+                for nm, c in zip((f"CAM_{k}", f"aux_CAM_{k}"), cams):
+                    v = cls[:, :, None, None] * F.interpolate(c, size=lab.shape[1:], mode="bilinear", align_corners=False)
+                    top = v.topk(2, dim=1).values
+                    tie = ((top[:, 0] - top[:, 1]) < 1e-5) & (top[:, 0] > 0.5)
+                    ties[nm] += int((tie | ((top[:, 0] - 0.5).abs() < 1e-5)).sum())
+    return ties
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_validate_siamase_matches_reference(dev, golden_dir, dual):
+    from dupl_amd.utils import train_helper
+    g = np.load(os.path.join(golden_dir, "val_tiny.npz"))
+    model, pp = _tiny_model(dev)
+    model.enable_dual_stream(dual)
+    ties = _cam_tie_pixels(pp, int(g["crop_size"]))
+    print("fp-tie pixels per map:", ties)
+    args = types.SimpleNamespace(crop_size=int(g["crop_size"]), cam_scales=(1.0, 0.5, 1.5), bkg_thre=0.5, high_thre=0.7,
+                                 low_thre=0.25, ignore_index=255)
+    captured = {}
+    from dupl_amd.utils import evaluate
+    orig = evaluate.ConfusionMatrix.scores
+
+    def spy(self):
+        captured[len(captured)] = self.hist.cpu().numpy().copy()
+        return orig(self)
+
+    evaluate.ConfusionMatrix.scores = spy
+    try:
+        c1, c2, table, items = train_helper.validate_siamase(model=model, data_loader=_loader(), args=args, return_item=True)
+    finally:
+        evaluate.ConfusionMatrix.scores = orig
+    print(table)
+    assert model.training
+    assert abs(c1 - float(g["cls_scores"][0])) < 1e-6 and abs(c2 - float(g["cls_scores"][1])) < 1e-6
+    for i, n in enumerate(NAMES):
+        ref = g[f"hist.{n}"]
+        diff = int(np.abs(captured[i] - ref).sum())
+        print(f"{n}: confusion-matrix L1 difference {diff} of {int(ref.sum())} px")
+        assert captured[i].sum() == ref.sum()
+        assert diff <= 2 * ties[n] + 4, n     # every differing pixel moves one count between two bins
+        ref_item = float(np.mean(g[f"iou.{n}"] * 100))
+        if np.isnan(ref_item):
+            assert np.isnan(items[i])
+        else:
+            assert abs(items[i] - ref_item) < 0.05 + 100.0 * ties[n] / max(int(ref.sum()), 1)
+
+
+def test_msc_seg_inference_and_checkpoint(dev, golden_dir, tmp_path):
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.tools import eval_seg
+    from dupl_amd.utils import evaluate
+    g = np.load(os.path.join(golden_dir, "val_tiny.npz"))
+    src, pp = _tiny_model(dev)
+    # the reference's checkpoint: state_dict of the DDP-wrapped model (keys prefixed `module.`)
+    path = str(tmp_path / "checkpoint.pth")
+    torch.save({"module." + k: v.detach().cpu() for k, v in src.state_dict().items()}, path)
+    model = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    eval_seg.load_checkpoint(model, path)
+    model.to(dev)
+    for k, v in pp.items():
+        assert torch.equal(model.state_dict()[k].cpu(), v), k
+    loader = _loader()
+    scales = tuple(float(s) for s in g["scales"])
+    kept = {}
+    args = types.SimpleNamespace(scales=scales)
+    s1, s2 = eval_seg.validate(model, loader, args, num_classes=21, keep_logits=lambda name, k, t: kept.__setitem__((name[0], k), t.cpu()))
+    for i in range(len(loader)):
+        for k in (1, 2):
+            got = kept[(f"img{i}", k)]
+            ref = torch.from_numpy(g[f"msc_logits.{k}.{i}"])
+            err = float((got[:, :, ::3, ::3] - ref).abs().max() / ref.abs().max())
+            assert err < 2e-4, (i, k, err)
+            mism = int((got.argmax(1)[0].numpy().astype(np.uint8) != g[f"msc_pred.{k}.{i}"]).sum())
+            assert mism <= 3, (i, k, mism)
+    for k, s in ((1, s1), (2, s2)):
+        ref = float(g["msc_miou"][k - 1])
+        print(f"branch{k}: msc mIoU {s['miou']:.6f} (reference {ref:.6f})")
+        assert abs(s["miou"] - ref) < 2e-3

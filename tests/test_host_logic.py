@@ -107,3 +107,33 @@ def test_par_pos_term_matches_reference_formula():
     got = ops.par_pos_term([1, 2, 4, 8, 12, 24])
     ref = 0.01 * O.par_pos_affinity().numpy()
     assert np.allclose(got, ref, rtol=1e-5, atol=1e-10)
+
+
+def test_evaluate_scores_and_tables():
+    """utils/evaluate.py + utils/pyutils.py host API: scores == oracle restatement, f1 == sklearn, table shape."""
+    from dupl_amd.utils import evaluate, pyutils
+    from dupl_amd.datasets import voc, coco
+    from oracle import dupl_oracle as O
+    from sklearn.metrics import f1_score
+    assert len(voc.class_list) == 21 and len(coco.class_list) == 81
+    rng = np.random.RandomState(3)
+    gts = [rng.randint(0, 21, size=(9, 7)) for _ in range(4)]
+    for gmap in gts:
+        gmap[rng.rand(9, 7) < 0.1] = 255
+    preds = [rng.randint(0, 15, size=(9, 7)) for _ in range(4)]
+    a, b = evaluate.scores(gts, preds), O.scores(gts, preds)
+    assert a["miou"] == b["miou"] and a["pAcc"] == b["pAcc"] and a["mAcc"] == b["mAcc"]
+    assert np.allclose(list(a["iou"].values()), list(b["iou"].values()), equal_nan=True)
+    p255 = [np.where(rng.rand(9, 7) < 0.2, 255, p) for p in preds]
+    ps = evaluate.pseudo_scores(gts, p255)
+    assert 0.0 <= ps["pAcc"] <= 1.0
+    for _ in range(20):
+        yt = (rng.rand(20) < 0.2).astype(np.float32)
+        yp = (rng.rand(20) < 0.3).astype(np.int16)
+        assert abs(evaluate.multilabel_score(yt, yp) - f1_score(yt, yp, zero_division=0)) < 1e-12
+        assert evaluate.multilabel_score(yt, yp) == O.multilabel_f1(yt, yp)
+    table, items = pyutils.format_tabs([a, a], ["CAM_1", "Seg_1"], cat_list=voc.class_list, return_item=True)
+    assert len(table.splitlines()) == 21 + 4 and len(items) == 2
+    m = pyutils.AverageMeter()
+    m.add({"x": 1.0}); m.add({"x": 3.0})
+    assert m.pop("x") == 2.0

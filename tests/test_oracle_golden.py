@@ -127,3 +127,28 @@ def test_tiny_step_phase_c(golden_dir):
     assert (pc["refined_1"].numpy().astype(np.uint8) != d["refined_1"]).sum() <= 2
     assert np.array_equal(pc["pseudo_seg_1"].numpy().astype(np.uint8), d["pseudo_seg_1"])
     assert abs(pc["reg_loss"].item() - float(d["reg_loss"].reshape(-1)[0])) < 1e-4
+
+
+def test_validation_and_msc_seg_vs_reference(golden_dir):
+    """O.validate_siamese and O.msc_seg_logits replay tests/golden/val_tiny.npz (the reference's
+    functions composed as validate_siamase / eval_seg_voc._validate, oracle/gen_golden_val.py)."""
+    from dupl_amd.synthetic_val import synthetic_val_samples
+    g = np.load(os.path.join(golden_dir, "val_tiny.npz"))
+    cfg, NC = O.VIT_TINY, 21
+    pp = O.make_siamese_params(cfg, NC, seed=2)
+    pp = {k: (v * 6.0 if ("classifier.weight" in k or k.endswith("decoder.conv8.weight")) else v) for k, v in pp.items()}
+    samples = synthetic_val_samples()
+    o = O.validate_siamese(pp, samples, cfg, int(g["crop_size"]), NC, O.StepArgs())
+    assert abs(o["cls_score_1"] - float(g["cls_scores"][0])) < 1e-9
+    assert abs(o["cls_score_2"] - float(g["cls_scores"][1])) < 1e-9
+    for n in ("CAM_1", "aux_CAM_1", "Seg_1", "CAM_2", "aux_CAM_2", "Seg_2"):
+        assert int(np.abs(o["hist"][n] - g[f"hist.{n}"]).sum()) <= 4, n      # bit-equal on the authoring machine
+        assert abs(o["scores"][n]["miou"] - float(g[f"miou.{n}"])) < 1e-3
+        for i, m in enumerate(o["maps"][n]):
+            assert int((m.astype(np.uint8) != g[f"map.{n}.{i}"]).sum()) <= 2, (n, i)
+    scales = tuple(float(s) for s in g["scales"])
+    x, lab, _ = samples[0]
+    for k in (1, 2):
+        m = O.msc_seg_logits(O.sub_params(pp, f"branch{k}."), x, lab.shape[1:], cfg, scales)
+        ref = torch.from_numpy(g[f"msc_logits.{k}.0"])
+        assert float((m[:, :, ::3, ::3] - ref).abs().max() / ref.abs().max()) < 5e-5

@@ -22,9 +22,16 @@ def _run(script, extra, port):
     return r.stdout + r.stderr
 
 
-def test_train_final_voc_script_runs_all_phases(dev):
-    out = _run("train_final_voc.py", ["--cam_iters", "2", "--gmm_iters", "4", "--max_iters", "6", "--warmup_iters", "2"], 29611)
+def test_train_final_voc_script_runs_all_phases(dev, tmp_path):
+    """phases A -> B -> C, then the iteration-6 checkpoint (reference format) + in-loop validation (validate_siamase)."""
+    out = _run("train_final_voc.py", ["--cam_iters", "2", "--gmm_iters", "4", "--max_iters", "6", "--warmup_iters", "2",
+                                      "--eval_iters", "6", "--work_dir", str(tmp_path)], 29611)
     assert "Iter: 2;" in out and "Iter: 6;" in out
+    assert "val cls score" in out and "mIoU" in out and "aux_CAM_2" in out
+    ckpts = [os.path.join(d, f) for d, _, fs in os.walk(tmp_path) for f in fs if f == "checkpoint.pth"]
+    assert len(ckpts) == 1
+    sd = torch.load(ckpts[0], map_location="cpu")
+    assert all(k.startswith("module.branch") for k in sd) and len(sd) == 2 * 61   # tiny backbone: 61 tensors per student
 
 
 def test_train_final_coco_script_runs(dev):
