@@ -154,6 +154,30 @@ class FlatStorage:
         s = student * self.student_numel
         return s + self.seg_bounds[SEG_BACKBONE][0], s + self.seg_bounds[SEG_DECODER][1]
 
+    def block_range(self, i: int) -> Tuple[int, int]:
+        """[start, end) within a student of transformer block i's tensors in the backbone segment."""
+        pre = f"encoder.blocks.{i}."
+        offs = [(o, n) for k, (o, n) in self.layout.items() if k.startswith(pre) and param_segment(k) == SEG_BACKBONE]
+        return min(o for o, _ in offs), max((o + n + 3) // 4 * 4 for o, n in offs)
+
+    def grad_buckets(self, student: int, blocks_per_bucket: int = 2) -> List[Tuple[int, int, object]]:
+        """Partition of the student's trainable gradient range into (lo, hi, trigger) buckets in the order the backward
+        pass finalises them (network_backward's on_ready events): "heads" = [cls | decoder] once the heads and the
+        decoder are back-propagated; an int i = the blocks [i, i+k) once block i is done (the backward walks the blocks
+        downwards, their tensors are contiguous); "stem" = cls_token / patch embedding plus the lowest blocks, and the
+        norm segment (LayerNorm affine parameters of every block, final only at the end)."""
+        s = student * self.student_numel
+        depth = self.cfg.depth
+        k = max(1, int(blocks_per_bucket))
+        out = [(s + self.seg_bounds[SEG_CLS][0], s + self.seg_bounds[SEG_DECODER][1], "heads")]
+        i = depth
+        while i - k > 0:
+            out.append((s + self.block_range(i - k)[0], s + self.block_range(i - 1)[1], i - k))
+            i -= k
+        out.append((s + self.seg_bounds[SEG_BACKBONE][0], s + self.block_range(i - 1)[1], "stem"))
+        out.append((s + self.seg_bounds[SEG_NORM][0], s + self.seg_bounds[SEG_NORM][1], "stem"))
+        return out
+
 
 class StudentParams:
     """Read-only bundle of one student's parameter / gradient views used by the engine."""
@@ -352,8 +376,10 @@ def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
 # backward
 # ------------------------------------------------------------------------------------------------
 def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], dseg: Optional[Tensor],
-                     dx4: Optional[Tensor], dcls_aux: Optional[Tensor]):
-    """Adjoint of network_forward; accumulates into P.g[...] (the flat gradient buffer)."""
+                     dx4: Optional[Tensor], dcls_aux: Optional[Tensor], on_ready=None):
+    """Adjoint of network_forward; accumulates into P.g[...] (the flat gradient buffer).
+    on_ready(event): called (host side, stream order) when a part of this student's gradient is final: "heads" after
+    the classifier / decoder gradients, i after transformer block i, "stem" at the end (FlatStorage.grad_buckets)."""
     cfg = P.cfg
     enc = sv.enc
     B, h, w = enc.B, enc.h, enc.w
@@ -400,6 +426,8 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         ops.L().dupl_col2im_dil3(dcol6.data_ptr(), dtf.data_ptr() + 4 * D, B, h, w, D, dil, D, N * D, 1, None, ops._stream())
         del dcol6
         P.mark_grad(SEG_DECODER)
+    if on_ready is not None:
+        on_ready("heads")
     # ---- final LayerNorm
     dx = ops.layernorm_bwd(dtf, enc.x_last, W["encoder.norm.weight"], enc.mean_f, enc.rstd_f,
                            G["encoder.norm.weight"], G["encoder.norm.bias"])
@@ -433,6 +461,8 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         dx = ops.layernorm_bwd(dln1, s.x_in, W[p + "norm1.weight"], s.mean1, s.rstd1,
                                G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid)
         enc.blocks[i] = None  # release activations as we go
+        if on_ready is not None:
+            on_ready(i)
     # ---- token assembly / patch embed
     dpatch = ops.assemble_tokens_bwd(dx, G["encoder.cls_token"], B, n, D)
     rows = ops.patch_im2row(enc.x_img, cfg.patch)
@@ -440,3 +470,5 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
     ops.colsum(dpatch, G["encoder.patch_embed.proj.bias"], accumulate=True)
     P.mark_grad(SEG_BACKBONE)
     P.mark_grad(SEG_NORM)
+    if on_ready is not None:
+        on_ready("stem")

@@ -59,7 +59,14 @@ class _NetworkFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dcls, dseg, dx4, dcls_aux):
         net = ctx.net
-        engine.network_backward(net._P, ctx.sv, dcls, dseg, dx4, dcls_aux)
+        on_ready = None
+        if net._grad_ready_hooks and net._live_graphs <= 1:
+            # last pending forward of this student: its gradient ranges become final block by block (phase C has
+            # two forwards per student; the first one to be back-propagated only accumulates)
+            def on_ready(event):
+                for hook in net._grad_ready_hooks:
+                    hook(net, event)
+        engine.network_backward(net._P, ctx.sv, dcls, dseg, dx4, dcls_aux, on_ready=on_ready)
         ctx.sv = None
         net._live_graphs = max(0, net._live_graphs - 1)
         for hook in net._post_backward_hooks:
@@ -81,6 +88,7 @@ class network(nn.Module):
         self._store = FlatStorage(cfg, num_classes, 1) if _store is None else _store
         self._student = _student
         self._post_backward_hooks: List[Callable] = []
+        self._grad_ready_hooks: List[Callable] = []     # hook(net, event) during the last pending backward (ddp.py)
         self._live_graphs = 0
         self._anchor = None
         self._build_modules()

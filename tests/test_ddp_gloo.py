@@ -39,6 +39,14 @@ def _worker(rank, world, port, q):
             lo, hi = st.trainable_range(s)
             bk = ddp.reducer.student_buckets(s)
             ok_buckets &= bk[0][0] == lo and bk[-1][1] == hi and all(a[1] == b[0] for a, b in zip(bk, bk[1:])) and len(bk) > 1
+        # layer-granular plan (issued during the backward): disjoint, covers the trainable range exactly, ordered as
+        # the backward finalises it (heads, blocks downwards, stem + norm)
+        for s in (0, 1):
+            lo, hi = st.trainable_range(s)
+            plan = sorted(ddp.reducer.plan[s])
+            ok_buckets &= plan[0][0] == lo and plan[-1][1] == hi and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+            trig = [p[2] for p in ddp.reducer.plan[s]]
+            ok_buckets &= trig[0] == "heads" and trig[-2:] == ["stem", "stem"] and trig[1:-2] == sorted(trig[1:-2], reverse=True)
         # fake per-rank gradients; frozen segment gets a sentinel that must survive
         g_local = hash_normal(f"grad_rank{rank}", (st.grad.numel(),), std=1.0, seed=1)
         st.grad.copy_(g_local)
@@ -46,9 +54,16 @@ def _worker(rank, world, port, q):
             flo = s * st.student_numel
             st.grad[flo: flo + st.seg_bounds[0][1]] = 7.0 + rank
         # drive the hook protocol by hand: student 0's backward ends, then student 1's, then the engine callback
+        # student 0: the per-layer events of a backward (heads, blocks 3..0 of the tiny backbone, stem), then the
+        # post-backward hook; student 1: only the post-backward hook (e.g. a backward that reported nothing)
+        for ev in ["heads", 3, 2, 1, 0, "stem"]:
+            ddp.reducer.grad_ready(0, ev)
+        n_layerwise = len(ddp.reducer._pending)
         for net in (m.branch1, m.branch2):
             ddp.reducer.reduce_student_async(net._student)
+        ok_buckets &= n_layerwise >= len(ddp.reducer.plan[0]) and len(ddp.reducer._pending) > n_layerwise
         ddp.reducer.finish()
+        ok_buckets &= not any(ddp.reducer._issued)
         expect = sum(hash_normal(f"grad_rank{r}", (st.grad.numel(),), std=1.0, seed=1) for r in range(world)) / world
         ok_mean, ok_frozen = True, True
         for s in (0, 1):

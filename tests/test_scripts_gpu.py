@@ -57,21 +57,40 @@ dev = torch.device("cuda:0")
 pp = O.make_siamese_params(O.VIT_TINY, 21, seed=2)
 inputs, cls_label, img_box = O.synthetic_batch(2, 20, 64, seed=5)
 par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
-grads = []
-for use_ddp in (False, True):
-    m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
-    m.load_state_dict(pp); m.to(dev); m.enable_dual_stream(True)
-    w = DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True) if use_ddp else m
-    if use_ddp:
-        w.reducer.world = 2          # force the exchange path: all_reduce(SUM) over 1 rank, then * 1/2
-    loss, out = trainer.compute_losses(w, par, inputs.to(dev), cls_label.to(dev), img_box, 5000, trainer.StepArgs(), cls_label)
-    loss.sum().backward()
-    m.flat_storage.wait_streams(); torch.cuda.synchronize()
-    grads.append(m.flat_storage.grad.clone())
-lo, hi = m.flat_storage.trainable_range(0)
-e = (grads[1][lo:hi] * 2 - grads[0][lo:hi]).abs().max().item() / grads[0][lo:hi].abs().max().item()
-print("DDP_REL_ERR", e)
-assert e < 1e-5
+aug, _, _ = O.synthetic_batch(2, 20, 64, seed=19)
+aug = torch.flip(0.7 * inputs + 0.3 * aug, dims=[3]).contiguous().to(dev)
+for n_iter in (5000, 9000):          # phase B: one forward per student; phase C: two (only the last one may exchange)
+    grads, snaps = [], []
+    for use_ddp in (False, True):
+        m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+        m.load_state_dict(pp); m.to(dev); m.enable_dual_stream(True)
+        w = DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True) if use_ddp else m
+        if use_ddp:
+            w.reducer.world = 2          # force the exchange path: all_reduce(SUM) over 1 rank, then * 1/2
+            issue = w.reducer._issue
+            def spy(lo, hi, issue=issue, store=m.flat_storage):
+                snaps.append((lo, hi, store.grad[lo:hi].clone()))   # stream-ordered snapshot at issue time
+                issue(lo, hi)
+            w.reducer._issue = spy
+        loss, out = trainer.compute_losses(w, par, inputs.to(dev), cls_label.to(dev), img_box, n_iter, trainer.StepArgs(), cls_label,
+                                           inputs_aug=aug if n_iter >= 8000 else None)
+        loss.sum().backward()
+        m.flat_storage.wait_streams(); torch.cuda.synchronize()
+        grads.append(m.flat_storage.grad.clone())
+    st = m.flat_storage
+    covered = torch.zeros_like(grads[0], dtype=torch.bool)
+    for lo, hi, snap in snaps:
+        # a bucket must be FINAL when it is handed to the all-reduce: nothing may add to it afterwards
+        assert torch.equal(snap * 0.5, grads[1][lo:hi]), ("bucket issued before its gradient was final", n_iter, lo, hi)
+        assert not covered[lo:hi].any(), "bucket issued twice"
+        covered[lo:hi] = True
+    for s_ in (0, 1):
+        lo, hi = st.trainable_range(s_)
+        assert covered[lo:hi].all(), "trainable range not fully exchanged"
+        e = (grads[1][lo:hi] * 2 - grads[0][lo:hi]).abs().max().item() / grads[0][lo:hi].abs().max().item()
+        print("DDP_REL_ERR", n_iter, s_, e, "buckets", len(snaps))
+        assert e < 1e-5
+    assert len(snaps) >= 2 * 4, "per-layer buckets were not used"
 dist.destroy_process_group()
 '''
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DUPL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613",
