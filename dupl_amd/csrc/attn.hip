@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 
 // dQ: block = 128 query rows (wave = 32), loops over key tiles.
 template <int HD>
-__global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(ANT, 2) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dqkv, int N, int H, float scale) {
     constexpr int SK = HD + 1, HH = HD / 2, ND = HD / 32;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(const float* __restric
 
 // dK, dV: block = 128 key rows (wave = 32 keys), loops over query tiles of KT rows.
 template <int HD>
-__global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(ANT, 2) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            float* __restrict__ dqkv, int N, int H, float scale) {
     constexpr int SQ = HD + 1, HH = HD / 2, ND = HD / 32;
