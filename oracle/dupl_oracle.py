@@ -518,6 +518,16 @@ class StepArgs:
     high_target: Tuple[float, ...] = VOC_HIGH_TARGET
     gmm_valid_thre: float = 1.0
     gamma: float = 0.95
+    schedule: str = "voc"          # "coco": train_final_coco.py:190-448 (hard-coded 8000 / 12000 switch points)
+    coco_switch_iter: int = 12000  # train_final_coco.py:241,312,443
+
+
+def coco_step_args(**kw) -> "StepArgs":
+    """train_final_coco.py:75-86,161-162."""
+    d = dict(cam_iters=8000, gmm_iters=32000, max_iters=80000, bkg_thre=0.45, high_thre=0.65, low_thre=0.25,
+             high_target=tuple([0.55] * 80), schedule="coco")
+    d.update(kw)
+    return StepArgs(**d)
 
 
 def gmm_noise_filter_(ce_map: Tensor, refined: Tensor, gmm_valid_thre: float, gamma: float) -> int:
@@ -545,7 +555,9 @@ def gmm_noise_filter_(ce_map: Tensor, refined: Tensor, gmm_valid_thre: float, ga
 
 def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tensor, img_box,
                       n_iter: int, cfg: ViTConfig, args: StepArgs = StepArgs(), inputs_aug: Optional[Tensor] = None):
-    """One iteration's loss assembly for phases A, B and C (train_final_voc.py:194-456).
+    """One iteration's loss assembly for phases A, B and C (train_final_voc.py:194-456; with args.schedule == "coco"
+    the variations of train_final_coco.py:190-448: no PTC in phase A, thresholds descending from iteration 12000,
+    refine_cams_with_bkg_v2 on the AUX CAMs until 12000, hard-coded loss weights).
     Returns (loss, dict of detached pieces).  `params` leaves may require grad.  Phase C (n_iter >= gmm_iters) needs
     `inputs_aug`, the strongly augmented + w-flipped batch the data pipeline supplies (train_final_voc.py:191)."""
     p1, p2 = sub_params(params, "branch1."), sub_params(params, "branch2.")
@@ -560,33 +572,43 @@ def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tens
     cls_loss = msm(cls_1, cls_label) + msm(cls_aux_1, cls_label) + msm(cls_2, cls_label) + msm(cls_aux_2, cls_label)
 
     phase_a = n_iter < args.cam_iters
+    coco = args.schedule == "coco"
     b, _, h, w = inputs.shape
     if phase_a:
         high = args.high_thre
     else:
         C = cls_label.shape[1]
+        off = args.coco_switch_iter if coco else args.cam_iters      # train_final_coco.py:241
         thr = cosine_descent(torch.ones(C) * args.high_thre, torch.tensor(args.high_target[:C]),
-                             n_iter - args.cam_iters, args.max_iters - args.cam_iters)
+                             n_iter - off, args.max_iters - off)
         high = torch.stack([torch.max(thr[torch.nonzero(cls_label[i]).squeeze(-1)]) for i in range(b)])
     fh, fw = fmap_1.shape[2:]
-    labels = []
-    for ca in (cams_aux_1, cams_aux_2):
-        r = F.interpolate(ca, size=(fh, fw), mode="bilinear", align_corners=False)
-        _, pl = cam_to_label(r, cls_label, img_box=img_box, ignore_mid=True, bkg_thre=args.bkg_thre,
-                             high_thre=high, low_thre=args.low_thre, ignore_index=args.ignore_index)
-        labels.append(pl)
-    ptc = masked_ptc_loss(fmap_1, label_to_aff_mask(labels[0])) + \
-        masked_ptc_loss(fmap_2, label_to_aff_mask(labels[1]))
-    pieces = {"pseudo_label_aux_1": labels[0], "pseudo_label_aux_2": labels[1],
-              "cams_1": cams_1, "cams_2": cams_2, "cams_aux_1": cams_aux_1, "cams_aux_2": cams_aux_2}
+    pieces = {"cams_1": cams_1, "cams_2": cams_2, "cams_aux_1": cams_aux_1, "cams_aux_2": cams_aux_2}
+    if phase_a and coco:
+        ptc = torch.ones(1)                                          # train_final_coco.py:216
+    else:
+        labels = []
+        for ca in (cams_aux_1, cams_aux_2):
+            r = F.interpolate(ca, size=(fh, fw), mode="bilinear", align_corners=False)
+            _, pl = cam_to_label(r, cls_label, img_box=img_box, ignore_mid=True, bkg_thre=args.bkg_thre,
+                                 high_thre=high, low_thre=args.low_thre, ignore_index=args.ignore_index)
+            labels.append(pl)
+        ptc = masked_ptc_loss(fmap_1, label_to_aff_mask(labels[0])) + \
+            masked_ptc_loss(fmap_2, label_to_aff_mask(labels[1]))
+        pieces["pseudo_label_aux_1"], pieces["pseudo_label_aux_2"] = labels
     reg = torch.zeros(1)
     if phase_a:
         seg = torch.ones(1)
     else:
         hmap = high.view(b, 1, 1, 1) * torch.ones(b, 1, h, w)
         rep = cls_label[:, :, None, None]
-        r1 = refine_cams(inputs_denorm, cams_1 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box)
-        r2 = refine_cams(inputs_denorm, cams_2 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box)
+        if coco and n_iter <= args.coco_switch_iter:
+            # train_final_coco.py:312-322: refine_cams_with_bkg_v2 (scalar high threshold) on the AUX CAMs
+            r1 = refine_cams(inputs_denorm, cams_aux_1 * rep, cls_label, args.high_thre, args.low_thre, args.ignore_index, img_box)
+            r2 = refine_cams(inputs_denorm, cams_aux_2 * rep, cls_label, args.high_thre, args.low_thre, args.ignore_index, img_box)
+        else:
+            r1 = refine_cams(inputs_denorm, cams_1 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box)
+            r2 = refine_cams(inputs_denorm, cams_2 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box)
         s1 = F.interpolate(segs_1, size=(h, w), mode="bilinear", align_corners=False)
         s2 = F.interpolate(segs_2, size=(h, w), mode="bilinear", align_corners=False)
         if n_iter < args.gmm_iters:
@@ -624,7 +646,14 @@ def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tens
             pieces["n_uncertain"] = (int(un1.sum()), int(un2.sum()))
         pieces["refined_1"], pieces["refined_2"] = r1, r2
     sim = sim_loss(fmap_1, fmap_2)
-    if n_iter <= args.cam_iters:
+    if coco:                                                         # train_final_coco.py:441-448
+        if n_iter <= 8000:
+            loss = 1.0 * cls_loss + 0.0 * ptc + 0.0 * seg + 0.0 * sim
+        elif n_iter <= 12000:
+            loss = 1.0 * cls_loss + 0.0 * ptc + 0.2 * seg + 0.05 * sim
+        else:
+            loss = 1.0 * cls_loss + 0.2 * ptc + 0.2 * seg + 0.05 * sim + 0.05 * reg
+    elif n_iter <= args.cam_iters:
         loss = 1.0 * cls_loss + args.w_ptc * ptc + 0.0 * seg + 0.1 * sim
     elif n_iter <= args.gmm_iters:
         loss = 1.0 * cls_loss + args.w_ptc * ptc + args.w_seg * seg + 0.1 * sim + 0.00 * reg

@@ -129,6 +129,29 @@ def test_tiny_step_phase_c(golden_dir):
     assert abs(pc["reg_loss"].item() - float(d["reg_loss"].reshape(-1)[0])) < 1e-4
 
 
+def test_coco_schedule_steps(golden_dir):
+    """schedule="coco" of the oracle replays tests/golden/tiny_step_coco_*.npz (train_final_coco.py composition)."""
+    for tag in ("A", "B1", "B2"):
+        d = g(golden_dir, f"tiny_step_coco_{tag}")
+        pp = O.make_siamese_params(O.VIT_TINY, 81, seed=4)
+        leaf = {k: v.clone().requires_grad_(k.split(".", 1)[1] != "encoder.pos_embed") for k, v in pp.items()}
+        inputs, cls_label, img_box = O.synthetic_batch(2, 80, 64, seed=15)
+        loss, pc = O.train_step_losses(leaf, inputs, cls_label, img_box, int(d["n_iter"]), O.VIT_TINY, O.coco_step_args())
+        loss.sum().backward()
+        assert abs(loss.sum().item() - float(d["loss"].reshape(-1)[0])) < 1e-5
+        if tag != "A":
+            assert np.array_equal(pc["pseudo_label_aux_1"].numpy().astype(np.uint8), d["pseudo_label_aux_1"])
+            assert (pc["refined_2"].numpy().astype(np.uint8) != d["refined_2"]).sum() <= 2
+        n = 0
+        for k in d.files:
+            if k.startswith("grad."):
+                got, ref = leaf[k[5:]].grad, d[k]
+                got = got.numpy() if got.shape == ref.shape else got.reshape(-1)[::7].numpy()
+                assert np.abs(got - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-12), k
+                n += 1
+        assert n >= 100
+
+
 def test_validation_and_msc_seg_vs_reference(golden_dir):
     """O.validate_siamese and O.msc_seg_logits replay tests/golden/val_tiny.npz (the reference's
     functions composed as validate_siamase / eval_seg_voc._validate, oracle/gen_golden_val.py)."""
