@@ -51,9 +51,6 @@ def parse():
                     help="run the training forward's encoder pass separately from ms-CAM's identical scale-1.0 pass, exactly "
                          "like the reference does (default: computed once and shared; outputs are bit-identical)")
     ap.add_argument("--single-stream", action="store_true", help="run the two students back to back on one stream")
-    ap.add_argument("--gmm-host", action="store_true",
-                    help="phase C only: fit the label-noise GMMs with the reference's host-side sklearn call instead of "
-                         "the device kernel")
     return ap.parse_args()
 
 
@@ -205,7 +202,6 @@ def main():
         aug, _, _ = synthetic_batch(args.batch, C, args.size, seed=1100 + rank)
         # stand-in for the strongly augmented, w-flipped view of the same images (train_final_voc.py:191)
         inputs_aug = torch.flip(0.7 * inputs + 0.3 * aug.to(dev), dims=[3]).contiguous()
-        sargs.gmm_on_device = not args.gmm_host
 
     def step(i):
         return trainer.train_step(ddp, optim, par, inputs, cls_label, img_box, args.n_iter + i, sargs, cls_label_host=cls_host,
@@ -278,7 +274,6 @@ def main():
                           "n_iter": args.n_iter, "parallelism": f"dp{world}", "student_streams": 1 if args.single_stream else 2,
                           "forward_precision": args.forward_precision,
                           "shared_scale1_encoder_pass": not args.no_share_encoder,
-                          **({"gmm": "host sklearn" if args.gmm_host else "device"} if phase == "C" else {}),
                           "loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec))

@@ -40,7 +40,6 @@ class StepArgs:
     samples_per_gpu: int = 2
     gmm_valid_thre: float = 1.0
     gamma: float = 0.95
-    gmm_on_device: bool = True    # False: the reference's host-side sklearn fit (utils/gmm_filter.py)
     share_encoder_pass: bool = True   # reuse ms-CAM's scale-1.0 encoder pass as the training forward (identical values)
     schedule: str = "voc"        # "voc": train_final_voc.py:194-456; "coco": train_final_coco.py:190-448
     coco_switch_iter: int = 12000  # train_final_coco.py:241,312: bkg_v2 on aux CAMs until here, then dynamic thresholds
@@ -75,8 +74,8 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     `cls_label_host`: CPU copy of `cls_label` (the data loader has it anyway); with it phases A and B contain no
     host<->device synchronisation at all and the host can run a full step ahead of the GPU.
     Phase C (n_iter >= gmm_iters, train_final_voc.py:358-436) needs `inputs_aug`, the strongly augmented + w-flipped
-    batch from the data pipeline (train_final_voc.py:191); its GMM filter runs on the device (csrc/gmm.hip) unless
-    args.gmm_on_device is False (then: the reference's host-side sklearn call, one D2H of the CE maps per step)."""
+    batch from the data pipeline (train_final_voc.py:191); its GMM label-noise filter runs on the device (csrc/gmm.hip),
+    so phase C has no host<->device synchronisation either."""
     if cls_label_host is None:
         cls_label_host = cls_label.detach().cpu()
     phase_c = n_iter >= args.gmm_iters
@@ -151,24 +150,12 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
                                                            ignore_index=args.ignore_index, img_box=img_box)
         if phase_c:
             # GMM label-noise filter on the detached per-pixel CE of each student w.r.t. ITS OWN labels (:360-394)
-            if args.gmm_on_device:
-                # one workgroup per image fits sklearn's 2-component mixture on the device (csrc/gmm.hip): no host sync
-                stats = []
-                for segs_k, r_k in ((segs_1, r1), (segs_2, r2)):
-                    ce = LS.seg_ce_map(segs_k, r_k, (h, w), args.ignore_index)
-                    stats.append(LS.gmm_noise_filter_(ce, r_k, args.ignore_index, args.gmm_valid_thre, args.gamma))
-                out["gmm_stats"] = stats      # (b, 16) per student; column 1 = image was filtered
-            else:
-                # the reference's own host-side sklearn call (two D2H round trips per step)
-                from .utils.gmm_filter import gmm_noise_masks
-                hits = []
-                for segs_k, r_k in ((segs_1, r1), (segs_2, r2)):
-                    ce = LS.seg_ce_map(segs_k, r_k, (h, w), args.ignore_index)
-                    mask, nh = gmm_noise_masks(ce.cpu().numpy(), r_k.cpu().numpy(), args.gmm_valid_thre, args.gamma)
-                    hits.append(nh)
-                    if nh:
-                        LS.mask_fill_(r_k, ops.to_device_async(mask, torch.uint8, inputs.device), float(args.ignore_index))
-                out["gmm_hits"] = hits
+            # one workgroup per image fits sklearn's 2-component mixture on the device (csrc/gmm.hip): no host round trip
+            stats = []
+            for segs_k, r_k in ((segs_1, r1), (segs_2, r2)):
+                ce = LS.seg_ce_map(segs_k, r_k, (h, w), args.ignore_index)
+                stats.append(LS.gmm_noise_filter_(ce, r_k, args.ignore_index, args.gmm_valid_thre, args.gamma))
+            out["gmm_stats"] = stats      # (b, 16) per student; column 1 = image was filtered
         # cross supervision: student 1 learns from student 2's labels and vice versa (train_final_voc.py:351-352)
         seg_loss = LS.get_seg_loss_lowres(segs_1, r2, (h, w), args.ignore_index) + \
             LS.get_seg_loss_lowres(segs_2, r1, (h, w), args.ignore_index)

@@ -237,11 +237,12 @@ def test_coco_schedule_step_matches_reference(dev, golden_dir, tag):
     assert nchk >= 100 and worst < 2e-3
 
 
-@pytest.mark.parametrize("gmm_on_device", [True, False])
-def test_tiny_phase_c_matches_reference(dev, golden_dir, gmm_on_device):
-    """Phase C: GMM noise filter (exercised: both students hit; on the device = csrc/gmm.hip, or the reference's
-    host-side sklearn call) + confidence-gated consistency loss on the 0.75x aug branch, vs the reference composition
-    (tests/golden/tiny_step_C.npz, generated with the reference's sklearn fit)."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_tiny_phase_c_matches_reference(dev, golden_dir, fused):
+    """Phase C: device GMM noise filter (csrc/gmm.hip; exercised: both students hit) + confidence-gated consistency
+    loss on the 0.75x aug branch, vs the reference composition (tests/golden/tiny_step_C.npz, generated with the
+    reference's host-side sklearn fit).  fused: shared scale-1.0 pass + two student streams (the default product
+    path); otherwise the reference's separate passes on one stream."""
     pytest.importorskip("sklearn")
     from dupl_amd.model.model_dupl import siamese_network
     from dupl_amd.model.PAR import PAR
@@ -258,21 +259,16 @@ def test_tiny_phase_c_matches_reference(dev, golden_dir, gmm_on_device):
     inputs, cls_label, img_box = O.synthetic_batch(2, NC - 1, 128, seed=9)
     aug, _, _ = O.synthetic_batch(2, NC - 1, 128, seed=19)
     aug = torch.flip(0.7 * inputs + 0.3 * aug, dims=[3]).contiguous()
-    # device GMM + shared scale-1.0 pass + two student streams (the default product path)  vs  host sklearn + the
-    # reference's separate passes on one stream
-    args = trainer.StepArgs(gmm_on_device=gmm_on_device, share_encoder_pass=gmm_on_device)
-    model.enable_dual_stream(gmm_on_device)
+    args = trainer.StepArgs(share_encoder_pass=fused)
+    model.enable_dual_stream(fused)
     model.flat_storage.grad.zero_()
     loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, int(g["n_iter"]), args,
                                        cls_label_host=cls_label, inputs_aug=aug.to(dev))
     loss.sum().backward()
     model.flat_storage.wait_streams()
     torch.cuda.synchronize()
-    if gmm_on_device:
-        hits = [int(st[:, 1].sum().item()) for st in out["gmm_stats"]]
-        print("device GMM stats:", [st.cpu().numpy().round(4).tolist() for st in out["gmm_stats"]])
-    else:
-        hits = list(out["gmm_hits"])
+    hits = [int(st[:, 1].sum().item()) for st in out["gmm_stats"]]
+    print("device GMM stats:", [st.cpu().numpy().round(4).tolist() for st in out["gmm_stats"]])
     assert hits == list(g["gmm_hits"]) == [1, 1]
     for k in ("refined_1", "refined_2", "pseudo_seg_1", "pseudo_seg_2"):
         mism = int((out[k].cpu().numpy().astype(np.uint8) != g[k]).sum())
