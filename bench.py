@@ -196,16 +196,10 @@ def main():
     par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
     inputs, cls_label, img_box, cls_host = make_batch(args, rank, dev, C)
     phase = "A" if args.n_iter + args.warmup + args.steps < sargs.cam_iters else ("B" if args.n_iter + args.warmup + args.steps < sargs.gmm_iters else "C")
-    inputs_aug = None
-    if phase == "C":
-        from dupl_amd.synthetic import synthetic_batch
-        aug, _, _ = synthetic_batch(args.batch, C, args.size, seed=1100 + rank)
-        # stand-in for the strongly augmented, w-flipped view of the same images (train_final_voc.py:191)
-        inputs_aug = torch.flip(0.7 * inputs + 0.3 * aug.to(dev), dims=[3]).contiguous()
+    # phase C: the strongly augmented view (train_final_voc.py:191, RandAugment(5, 10) + flip) is computed inside the step
 
     def step(i):
-        return trainer.train_step(ddp, optim, par, inputs, cls_label, img_box, args.n_iter + i, sargs, cls_label_host=cls_host,
-                                  inputs_aug=inputs_aug)
+        return trainer.train_step(ddp, optim, par, inputs, cls_label, img_box, args.n_iter + i, sargs, cls_label_host=cls_host)
 
     def barrier():
         if world > 1:

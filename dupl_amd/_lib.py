@@ -49,7 +49,7 @@ def _ctype(decl: str):
     base = d.replace("const", "").split()
     ty = base[0]
     return {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "uint8_t": ctypes.c_uint8,
-            "int": ctypes.c_int, "double": ctypes.c_double}[ty]
+            "int": ctypes.c_int, "double": ctypes.c_double, "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64}[ty]
 
 
 def parse_header(path: str = HEADER) -> Dict[str, List]:

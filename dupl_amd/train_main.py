@@ -129,16 +129,8 @@ def train(args, dataset: str, loader=None, val_loader=None):
             inputs, cls_label, img_box = synthetic_batch(args.samples_per_gpu, C, args.crop_size, seed=n_iter * 64 + rank)
             cls_host = cls_label
             inputs, cls_label = inputs.to(device), cls_label.to(device)
-        inputs_aug = None
-        if n_iter >= args.gmm_iters:
-            if it is not None:
-                raise RuntimeError("a real data loader must supply the strongly augmented batch (imutils.augment_data_strong "
-                                   "is host-side PIL RandAugment, outside the hot path)")
-            # synthetic stand-in for RandAugment(n=5, m=10) + w-flip (train_final_voc.py:191, imutils.py:305-317)
-            other, _, _ = synthetic_batch(args.samples_per_gpu, C, args.crop_size, seed=n_iter * 64 + rank + 7)
-            inputs_aug = torch.flip(0.7 * inputs + 0.3 * other.to(device), dims=[3]).contiguous()
-        out = trainer.train_step(wrapped, optim, par, inputs, cls_label, img_box, n_iter, sargs, cls_label_host=cls_host,
-                                 inputs_aug=inputs_aug)
+        # phase C's strongly augmented view (train_final_voc.py:191) is computed inside the step, on the device
+        out = trainer.train_step(wrapped, optim, par, inputs, cls_label, img_box, n_iter, sargs, cls_label_host=cls_host)
         for k in ("cls_loss", "ptc_loss", "seg_loss", "sim_loss"):
             acc[k] = acc.get(k, 0.0) + out[k].detach().reshape(-1)[0]     # device-side accumulation, no host sync
         if (n_iter + 1) % args.log_iters == 0 and rank == 0:

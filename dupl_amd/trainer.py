@@ -16,7 +16,7 @@ import torch
 
 from . import ops
 from .model import losses as LS
-from .utils import cam_helper
+from .utils import cam_helper, imutils
 from .utils.train_helper import cosine_descent
 
 VOC_HIGH_TARGET = (0.70, 0.70, 0.70, 0.70, 0.55, 0.55, 0.55, 0.55, 0.70, 0.55,
@@ -40,6 +40,8 @@ class StepArgs:
     samples_per_gpu: int = 2
     gmm_valid_thre: float = 1.0
     gamma: float = 0.95
+    strong_aug_n: int = 5        # train_final_voc.py:191: imutils.augment_data_strong(inputs_denorm.clone(), n=5, m=10)
+    strong_aug_m: int = 10
     share_encoder_pass: bool = True   # reuse ms-CAM's scale-1.0 encoder pass as the training forward (identical values)
     schedule: str = "voc"        # "voc": train_final_voc.py:194-456; "coco": train_final_coco.py:190-448
     coco_switch_iter: int = 12000  # train_final_coco.py:241,312: bkg_v2 on aux CAMs until here, then dynamic thresholds
@@ -73,18 +75,21 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     """Loss assembly of one iteration, phases A / B / C; returns (loss, dict of device scalars / tensors).
     `cls_label_host`: CPU copy of `cls_label` (the data loader has it anyway); with it phases A and B contain no
     host<->device synchronisation at all and the host can run a full step ahead of the GPU.
-    Phase C (n_iter >= gmm_iters, train_final_voc.py:358-436) needs `inputs_aug`, the strongly augmented + w-flipped
-    batch from the data pipeline (train_final_voc.py:191); its GMM label-noise filter runs on the device (csrc/gmm.hip),
+    Phase C (n_iter >= gmm_iters, train_final_voc.py:358-436) uses `inputs_aug`, the strongly augmented + w-flipped
+    batch (train_final_voc.py:191): computed here on the device (utils/imutils.augment_data_strong)
+    unless given; its GMM label-noise filter runs on the device (csrc/gmm.hip),
     so phase C has no host<->device synchronisation either."""
     if cls_label_host is None:
         cls_label_host = cls_label.detach().cpu()
     phase_c = n_iter >= args.gmm_iters
-    if phase_c and inputs_aug is None:
-        raise ValueError("phase C needs inputs_aug (strongly augmented, w-flipped batch)")
     coco = args.schedule == "coco"
     b, _, h, w = inputs.shape
     phase_a = n_iter < args.cam_iters
     inputs_denorm = ops.denormalize_img(inputs.contiguous()) if not phase_a else None
+    if phase_c and inputs_aug is None:
+        # train_final_voc.py:191: RandAugment(n=5, m=10) + w-flip of the de-normalised batch, here without leaving the
+        # device (the reference evaluates it every iteration and only uses it from gmm_iters on)
+        inputs_aug = imutils.augment_data_strong(inputs_denorm, n=args.strong_aug_n, m=args.strong_aug_m)
 
     core = model.module if hasattr(model, "module") else model
     if not args.share_encoder_pass:

@@ -273,6 +273,23 @@ int dupl_confusion_accum(const int64_t* gt, const int64_t* pred, int64_t n, int3
  * per row of (B,C). */
 int dupl_multilabel_f1_accum(const float* logits, const float* label, int32_t B, int32_t C, float* sum, dupl_stream_t s);
 
+/* ------------------------------------------------------------------ per-step strong augmentation
+ * utils/imutils.py:305-317 augment_data_strong / utils/randomaug.py RandAugment on the device: planar uint8 images
+ * (3,H,W), Pillow's exact 8-bit arithmetic (see csrc/augment.hip).  The op sequence per image is drawn on the host. */
+/* transforms.ToPILImage of a float tensor in [0,1]: out = (uint8)(x * 255) */
+int dupl_aug_to_u8(const float* x, uint8_t* out, int64_t n, dupl_stream_t s);
+/* mode 0: PIL.ImageOps.autocontrast, 1: PIL.ImageOps.equalize, in place; hist_scratch 768 uint32, lut_scratch 768 bytes */
+int dupl_aug_lut_op(uint8_t* img, int32_t H, int32_t W, int32_t mode, uint32_t* hist_scratch, uint8_t* lut_scratch,
+                    dupl_stream_t s);
+/* PIL.ImageOps.posterize(img, bits), in place over n bytes */
+int dupl_aug_posterize(uint8_t* img, int64_t n, int32_t bits, dupl_stream_t s);
+/* PIL.ImageEnhance.{Color (mode 0), Contrast (1), Brightness (2)}(img).enhance(factor), in place; sum_scratch: 1 uint64 */
+int dupl_aug_enhance(uint8_t* img, int32_t H, int32_t W, int32_t mode, float factor, uint64_t* sum_scratch, dupl_stream_t s);
+/* PIL.ImageEnhance.Sharpness(img).enhance(factor): out != in */
+int dupl_aug_sharpness(const uint8_t* in, uint8_t* out, int32_t H, int32_t W, float factor, dupl_stream_t s);
+/* transforms.ToTensor + Normalize(ImageNet mean/std) + torch.flip(dims=[2]): out (3,H,W) float32 */
+int dupl_aug_finish(const uint8_t* img, float* out, int32_t H, int32_t W, dupl_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -761,3 +761,63 @@ def msc_seg_logits(p: Dict[str, Tensor], inputs: Tensor, out_size, cfg: ViTConfi
             segs = F.interpolate(segs, size=out_size, mode="bilinear", align_corners=False)
             per_scale.append(segs[:1] + segs[1:].flip(-1))
     return torch.max(torch.stack(per_scale, dim=0), dim=0)[0]
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY 8f-3 (per-step part): the strong augmentation applied to every batch on the training path
+# (train_final_voc.py:191 -> utils/imutils.py:305-317 -> utils/randomaug.py:155-265)
+# ----------------------------------------------------------------------------------------------
+# randomaug.augment_list() (utils/randomaug.py:180-198): (op, minval, maxval), all photometric
+AUGMENT_LIST = (("AutoContrast", 0, 1), ("Equalize", 0, 1), ("Posterize", 0, 6), ("Color", 0.1, 1.9),
+                ("Contrast", 0.1, 1.9), ("Brightness", 0.1, 1.9), ("Sharpness", 0.1, 1.9))
+
+
+def rand_augment_ops(n: int, m: int, rng=None):
+    """RandAugment.__call__'s draw (randomaug.py:258-263): n ops with replacement from the list through
+    random.choices, magnitude val = m/30 * (max - min) + min.  rng: the `random` module (default) or a random.Random."""
+    import random as _random
+    rng = rng or _random
+    ops_ = rng.choices(AUGMENT_LIST, k=n)
+    return [(name, (float(m) / 30) * float(hi - lo) + lo) for name, lo, hi in ops_]
+
+
+def apply_pil_op(img, name: str, val: float):
+    """One op of utils/randomaug.py:62-110 on a PIL image -- third-party dependency: Pillow (PIL.ImageOps /
+    PIL.ImageEnhance), called exactly as the reference calls it."""
+    import PIL.ImageEnhance
+    import PIL.ImageOps
+    if name == "AutoContrast":
+        return PIL.ImageOps.autocontrast(img)
+    if name == "Equalize":
+        return PIL.ImageOps.equalize(img)
+    if name == "Posterize":
+        return PIL.ImageOps.posterize(img, max(1, int(val)))
+    if name == "Color":
+        return PIL.ImageEnhance.Color(img).enhance(val)
+    if name == "Contrast":
+        return PIL.ImageEnhance.Contrast(img).enhance(val)
+    if name == "Brightness":
+        return PIL.ImageEnhance.Brightness(img).enhance(val)
+    if name == "Sharpness":
+        return PIL.ImageEnhance.Sharpness(img).enhance(val)
+    raise ValueError(name)
+
+
+def augment_data_strong(images: Tensor, n: int = 4, m: int = 20, rng=None, ops_per_image=None) -> Tensor:
+    """utils/imutils.py:305-317: per image ToPILImage (x*255 -> uint8, truncation) -> RandAugment(n, m) -> ToTensor
+    (/255) -> Normalize(ImageNet mean / std) -> flip along W.  `images` (b,3,H,W) de-normalised floats in [0,1]; returns
+    a new tensor (the reference overwrites its argument).  ops_per_image overrides the random draw (tests)."""
+    from PIL import Image
+    mean = torch.tensor((0.485, 0.456, 0.406), dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225), dtype=torch.float32).view(3, 1, 1)
+    out = torch.empty_like(images, dtype=torch.float32)
+    for i in range(images.shape[0]):
+        u8 = images[i].mul(255).byte().permute(1, 2, 0).contiguous().numpy()      # transforms.ToPILImage
+        img = Image.fromarray(u8)
+        ops_ = ops_per_image[i] if ops_per_image is not None else rand_augment_ops(n, m, rng)
+        for name, val in ops_:
+            img = apply_pil_op(img, name, val)
+        t = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).to(torch.float32).div(255)   # transforms.ToTensor
+        t = (t - mean) / std                                                        # transforms.Normalize
+        out[i] = torch.flip(t, dims=[2])
+    return out

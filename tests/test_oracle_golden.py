@@ -175,3 +175,31 @@ def test_validation_and_msc_seg_vs_reference(golden_dir):
         m = O.msc_seg_logits(O.sub_params(pp, f"branch{k}."), x, lab.shape[1:], cfg, scales)
         ref = torch.from_numpy(g[f"msc_logits.{k}.0"])
         assert float((m[:, :, ::3, ::3] - ref).abs().max() / ref.abs().max()) < 5e-5
+
+
+def test_strong_augmentation_vs_reference(golden_dir):
+    """O.augment_data_strong / O.rand_augment_ops replay tests/golden/aug_strong.npz (the reference's utils/randomaug.py
+    RandAugment(5, 10) under random.seed, oracle/gen_golden_aug.py)."""
+    import random
+    import pytest
+    pytest.importorskip("PIL")
+    d = np.load(os.path.join(golden_dir, "aug_strong.npz"))
+    imgs = []
+    for i, (H, W) in enumerate(d["sizes"]):
+        x, _, _ = O.synthetic_batch(1, 20, int(max(H, W)), seed=40 + i)
+        imgs.append(O.denormalize_img2(x.clone())[:, :, :int(H), :int(W)].contiguous())
+    mean = torch.tensor((0.485, 0.456, 0.406)).view(3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225)).view(3, 1, 1)
+    k = 0
+    for s in d["seeds"]:
+        for i, x in enumerate(imgs):
+            random.seed(int(s))
+            ops_ = O.rand_augment_ops(5, 10)
+            assert ",".join(n for n, _ in ops_) == str(d["chain_ops"][k])
+            k += 1
+            out = O.augment_data_strong(x, ops_per_image=[ops_])
+            ref = torch.from_numpy(d[f"chain.{int(s)}.{i}"].copy()).permute(2, 0, 1).float().div(255)
+            assert torch.equal(out[0], torch.flip((ref - mean) / std, dims=[2]))
+    batch, _, _ = O.synthetic_batch(2, 20, 64, seed=44)
+    random.seed(123)
+    assert torch.equal(O.augment_data_strong(O.denormalize_img2(batch.clone()), n=5, m=10), torch.from_numpy(d["batch_out"]))
