@@ -74,7 +74,7 @@ __device__ __forceinline__ void store_chunk(const float4 v, float* __restrict__ 
 
 // BM = 128: wave tile 64x64 (2x2 MFMA tiles).  BM = 64: wave tile 32x64 (1x2) -- twice the blocks for small grids.
 template <bool A_MC, bool B_NC, int BM, int FAST>   // FAST: 0 guarded loader, 1 branch-free, 2 branch-free + k-range mask
-__global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, const int g_gm) {
     constexpr int MI = BM / 64;                 // 32-row MFMA tiles per wave along m
     constexpr int SA = A_MC ? (BM + 4) : (BM + 1);
     constexpr int SB = B_NC ? 132 : 129;
@@ -94,7 +94,14 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = lid / nbn, tn = lid - tm * nbn;
+    // grouped order inside the band: GM row-tiles x all n-tiles at a time, row-tile fastest, so that the ~128 blocks
+    // resident on one XCD cover a GM x (128/GM) patch of C (A and B panels of similar size) instead of 5 row-tiles x
+    // every n-tile (which re-streams the whole weight matrix through the 4 MB L2 for every 5 row-tiles)
+    const int gspan = g_gm * nbn;
+    const int gid = lid / gspan, gin = lid - gid * gspan;
+    const int gfirst = gid * g_gm;
+    const int gsz = min(nbm - gfirst, g_gm);
+    const int tm = gfirst + gin % gsz, tn = gin / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int z = blockIdx.y;
@@ -237,7 +244,14 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p) {
 
 }  // namespace
 
+static int g_group_m = 16;        // row-tiles per group of the block order (dupl_set_gemm_group)
 static int g_tile_override = 0;   // 0 = heuristic, 64 / 128 = forced (tuning knob, dupl_set_gemm_tile)
+
+extern "C" int dupl_set_gemm_group(int32_t gm) {
+    if (gm < 1 || gm > 4096) return DUPL_ERR_ARG;
+    g_group_m = gm;
+    return DUPL_OK;
+}
 
 extern "C" int dupl_set_gemm_tile(int32_t rows) {
     if (rows != 0 && rows != 64 && rows != 128) return DUPL_ERR_ARG;
@@ -287,12 +301,12 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     const bool kfull = (d->K % BK) == 0;   // split-K chunks are multiples of BK, so only the global tail matters
 #define DUPL_GEMM_LAUNCH(AM, BNC)                                                                                  \
     do {                                                                                                           \
-        if (small && fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 1>), grid, block, 0, s, *d);  \
-        else if (small && fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 2>), grid, block, 0, s, *d);      \
-        else if (small) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 0>), grid, block, 0, s, *d);              \
-        else if (fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 1>), grid, block, 0, s, *d);     \
-        else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 2>), grid, block, 0, s, *d);              \
-        else hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 0>), grid, block, 0, s, *d);                        \
+        if (small && fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 1>), grid, block, 0, s, *d, g_group_m);  \
+        else if (small && fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 2>), grid, block, 0, s, *d, g_group_m);      \
+        else if (small) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 0>), grid, block, 0, s, *d, g_group_m);              \
+        else if (fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 1>), grid, block, 0, s, *d, g_group_m);     \
+        else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 2>), grid, block, 0, s, *d, g_group_m);              \
+        else hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 0>), grid, block, 0, s, *d, g_group_m);                        \
     } while (0)
     if (!amc && !bnc) DUPL_GEMM_LAUNCH(false, false);
     else if (!amc && bnc) DUPL_GEMM_LAUNCH(false, true);

@@ -62,6 +62,8 @@ int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
 int dupl_gemm_h3(const dupl_gemm_desc* d, dupl_stream_t stream);
 /* tuning knob: force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic on the grid size) */
 int dupl_set_gemm_tile(int32_t rows);
+/* tuning knob: row-tiles per group of the block -> C-tile order inside an XCD band (default 16; 4096 = plain row-major) */
+int dupl_set_gemm_group(int32_t gm);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim D (D % 4 == 0, D <= 2048), one wavefront per row.
