@@ -64,17 +64,36 @@ __device__ __forceinline__ void load_rowfrag(float (&f)[HD / 2], const float* __
     }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs in linear (x, y, z) order, so the ceil(N/128) blocks that share one
+// head's K / V would each pull them into a different XCD's L2.  Same bijective band remap as the GEMM: XCD x owns a
+// contiguous run of (query-block, head, image) work items, i.e. whole heads.
+__device__ __forceinline__ void xcd_remap3(int remap, int& bx, int& by, int& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (!remap) return;
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * gridDim.z;
+    const int L = bx + gx * (by + gy * bz);
+    const int q = total >> 3, r = total & 7;
+    const int xcd = L & 7, idx = L >> 3;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = w % gx;
+    by = (w / gx) % gy;
+    bz = w / (gx * gy);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int HD>
 __global__ __launch_bounds__(ANT) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                       float* __restrict__ lse, int N, int H, float scale) {
+                                                       float* __restrict__ lse, int N, int H, float scale, int remap) {
     constexpr int SK = HD + 1, SV = HD + 1, HH = HD / 2, ND = HD / 32;
     __shared__ __attribute__((aligned(16))) float smem[KT * SK + KT * SV];
     float* Ks = smem;
     float* Vs = smem + KT * SK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    int bx, h, b;
+    xcd_remap3(remap, bx, h, b);
+    const int q0 = bx * 128 + wave * 32;
     const int D = H * HD, ld = 3 * D;
     const float* base = qkv + (size_t)b * N * ld + h * HD;
     const int qrow = q0 + l31;
@@ -222,13 +241,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 template <int HD>
 __global__ __launch_bounds__(ANT, 2) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          float* __restrict__ dqkv, int N, int H, float scale) {
+                                                          float* __restrict__ dqkv, int N, int H, float scale, int remap) {
     constexpr int SK = HD + 1, HH = HD / 2, ND = HD / 32;
     __shared__ __attribute__((aligned(16))) float smem[2 * KT * SK];
     float* Ks = smem;
     float* Vs = smem + KT * SK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    int bx, h, b;
+    xcd_remap3(remap, bx, h, b);
+    const int q0 = bx * 128 + wave * 32;
     const int D = H * HD, ld = 3 * D;
     const float* base = qkv + (size_t)b * N * ld + h * HD;
     const int qrow = q0 + l31;
@@ -303,7 +324,7 @@ __global__ __launch_bounds__(ANT, 2) void attn_bwd_dq_kernel(const float* __rest
 template <int HD>
 __global__ __launch_bounds__(ANT, 2) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           float* __restrict__ dqkv, int N, int H, float scale) {
+                                                           float* __restrict__ dqkv, int N, int H, float scale, int remap) {
     constexpr int SQ = HD + 1, HH = HD / 2, ND = HD / 32;
     __shared__ __attribute__((aligned(16))) float smem[2 * KT * SQ + 2 * KT];
     float* Qs = smem;
@@ -311,7 +332,9 @@ __global__ __launch_bounds__(ANT, 2) void attn_bwd_dkv_kernel(const float* __res
     float* Ls = smem + 2 * KT * SQ;   // lse tile
     float* Ds = Ls + KT;              // delta tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128 + wave * 32;
+    int bx, h, b;
+    xcd_remap3(remap, bx, h, b);
+    const int k0 = bx * 128 + wave * 32;
     const int D = H * HD, ld = 3 * D;
     const float* base = qkv + (size_t)b * N * ld + h * HD;
     const float* dob = dout + (size_t)b * N * D + h * HD;
@@ -404,13 +427,20 @@ __global__ __launch_bounds__(ANT, 2) void attn_bwd_dkv_kernel(const float* __res
 
 }  // namespace
 
+static int g_attn_remap = 1;   // XCD-aware block order (dupl_set_attention_remap)
+
+extern "C" int dupl_set_attention_remap(int32_t on) {
+    g_attn_remap = on ? 1 : 0;
+    return DUPL_OK;
+}
+
 extern "C" int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd,
                                   float scale, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!qkv || !out || B <= 0 || N <= 0 || H <= 0 || (hd != 32 && hd != 64)) return DUPL_ERR_ARG;
     dim3 grid((N + 127) / 128, H, B), block(ANT);
-    if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale);
-    else hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale);
+    if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale, g_attn_remap);
+    else hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale, g_attn_remap);
     return dupl_launch_status();
 }
 
@@ -424,11 +454,11 @@ extern "C" int dupl_attention_bwd(const float* qkv, const float* out, const floa
                        delta, B, N, H, hd);
     dim3 grid((N + 127) / 128, H, B), block(ANT);
     if (hd == 64) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
     }
     return dupl_launch_status();
 }

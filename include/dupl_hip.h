@@ -94,6 +94,8 @@ int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int3
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,
                        float scale, dupl_stream_t s);
+/* tuning knob: 1 (default) = XCD-aware workgroup order of the attention kernels (whole heads per XCD), 0 = plain */
+int dupl_set_attention_remap(int32_t on);
 
 /* ---------------------------------------------------------------------------------------------
  * Token plumbing (vit.py:176-184, 289-306; model_dupl.py:64-67, 88-95). */
