@@ -37,9 +37,9 @@ __global__ void upsample_argmax_kernel(const float* __restrict__ logits, long lo
     }
 }
 
-// acc[c][y][x] = (first ? v : max(acc, v)),  v = up(segs[0])[c][y][x] + up(segs[1])[c][y][W-1-x]
+// v = up(segs[0])[c][y][x] + up(segs[1])[c][y][W-1-x];  acc[c][y][x] = v (mode 0), max(acc, v) (1), acc + v (2)
 __global__ void msc_seg_accum_kernel(const float* __restrict__ segs, float* __restrict__ acc, int C, int h, int w, int H,
-                                     int W, int first) {
+                                     int W, int mode) {
     const long total = (long)C * H * W;
     const float sy = bil_scale(h, H, false), sx = bil_scale(w, W, false);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -52,7 +52,7 @@ __global__ void msc_seg_accum_kernel(const float* __restrict__ segs, float* __re
         const float* p0 = segs + (long)c * h * w;
         const float* p1 = segs + ((long)C + c) * h * w;
         const float v = bil_tap(p0, w, y0, y1, x0, x1, ly, lx) + bil_tap(p1, w, y0, y1, f0, f1, ly, lf);
-        acc[i] = first ? v : fmaxf(acc[i], v);
+        acc[i] = mode == 0 ? v : (mode == 1 ? fmaxf(acc[i], v) : acc[i] + v);
     }
 }
 
@@ -135,11 +135,11 @@ extern "C" int dupl_upsample_argmax(const float* logits, int64_t* out, int32_t B
 }
 
 extern "C" int dupl_msc_seg_accum(const float* segs, float* acc, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W,
-                                  int32_t first, dupl_stream_t s) {
+                                  int32_t mode, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
-    if (!segs || !acc || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DUPL_ERR_ARG;
+    if (!segs || !acc || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return DUPL_ERR_ARG;
     hipLaunchKernelGGL(msc_seg_accum_kernel, dim3(ew_grid((long)C * H * W)), dim3(256), 0, (hipStream_t)s, segs, acc, C, h, w,
-                       H, W, first);
+                       H, W, mode);
     return dupl_launch_status();
 }
 

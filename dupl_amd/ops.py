@@ -374,13 +374,14 @@ def upsample_argmax(logits: Tensor, H: int, W: int) -> Tensor:
     return out
 
 
-def msc_seg_accum_(acc: Tensor, segs: Tensor, first: bool) -> Tensor:
-    """acc (1,C,H,W) = [max with] up(segs[0]) + flip(up(segs[1])), segs (2,C,h,w): one scale of eval_seg_voc.py:58-72."""
+def msc_seg_accum_(acc: Tensor, segs: Tensor, mode: int) -> Tensor:
+    """v = up(segs[0]) + flip(up(segs[1])), segs (2,C,h,w); acc (1,C,H,W) = v (mode 0) | max(acc, v) (1) | acc + v (2):
+    one scale of eval_seg_voc.py:58-72 (max) / eval_seg_coco_ddp.py:80-119 (sum)."""
     two, C, h, w = segs.shape
     assert two == 2 and acc.shape[1] == C and acc.is_contiguous()
     segs = _chk(segs.contiguous())
     H, W = acc.shape[-2:]
-    L().dupl_msc_seg_accum(segs.data_ptr(), acc.data_ptr(), C, h, w, H, W, int(first), _stream())
+    L().dupl_msc_seg_accum(segs.data_ptr(), acc.data_ptr(), C, h, w, H, W, int(mode), _stream())
     return acc
 
 

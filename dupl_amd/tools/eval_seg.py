@@ -43,8 +43,57 @@ def msc_seg_logits(model, inputs, out_size, scales=(1.0, 1.5, 1.25)):
                 C1 = segs[0].shape[1]
                 accs = [torch.empty((1, C1, H, W), device=inputs.device, dtype=torch.float32) for _ in range(2)]
             for acc, s in zip(accs, segs):
-                ops.msc_seg_accum_(acc, s, first=(i == 0))
+                ops.msc_seg_accum_(acc, s, mode=(0 if i == 0 else 1))
     return accs[0], accs[1]
+
+
+def msc_seg_logits_coco(model, inputs, scales=(1.0, 1.25, 1.5), size=448):
+    """tools/eval_seg_coco_ddp.py:76-119: the image is first resized to size x size; per scale the logits of
+    [x_s; flip(x_s)] are resized to the scale-1 logit size, the flipped half is flipped back and added, and the scales
+    are SUMMED (VOC takes the max at label size).  -> (seg_1, seg_2), each (1,C1,size/16,size/16); the caller up-samples
+    the sum to the label size (ops.upsample_argmax)."""
+    assert inputs.shape[0] == 1
+    core = model.module if hasattr(model, "module") else model
+    x = ops.resize_bilinear(inputs.contiguous().float(), size, size)
+    accs = None
+    order = [1.0] + [float(s) for s in scales if float(s) != 1.0]      # the reference always starts with scale 1
+    with torch.no_grad():
+        for i, sc in enumerate(order):
+            cat = ops.resize_bilinear(x, int(size * sc), int(size * sc), flip_cat=True)
+            res = core(cat)
+            segs = (res["branch1"][1], res["branch2"][1])
+            if accs is None:
+                C1, hs, ws = segs[0].shape[1:]
+                accs = [torch.empty((1, C1, hs, ws), device=x.device, dtype=torch.float32) for _ in range(2)]
+            for acc, s in zip(accs, segs):
+                ops.msc_seg_accum_(acc, s, mode=(0 if i == 0 else 2))
+    return accs[0], accs[1]
+
+
+def validate_coco(model, data_loader, args, num_classes=81, cat_list=None, process_group=None):
+    """eval_seg_coco_ddp._validate on this rank's shard of the loader (the reference splits the val set round-robin over
+    the ranks, tools/eval_seg_coco_ddp.py:239-245, and every rank scores its own shard).  With `process_group` (or an
+    initialised default group) the per-rank confusion matrices are additionally summed over the ranks -- nc^2 int64
+    counters, the only exchange of the evaluation path -- so that every rank returns the scores of the WHOLE set."""
+    import torch.distributed as dist
+    from ..utils.train_helper import _device_of, _fetch
+    dev = _device_of(model)
+    cms = [evaluate.ConfusionMatrix(num_classes, dev) for _ in range(2)]
+    model.eval()
+    scales = getattr(args, "scales", (1.0, 1.25, 1.5))
+    for data in data_loader:
+        inputs, labels, _ = _fetch(data, dev)
+        seg = msc_seg_logits_coco(model, inputs, scales, getattr(args, "crop_size", 448))
+        H, W = labels.shape[1:]
+        for k in range(2):
+            cms[k].update(labels, ops.upsample_argmax(seg[k], H, W))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        for c in cms:
+            dist.all_reduce(c.hist, op=dist.ReduceOp.SUM, group=process_group)
+    sc = [c.scores() for c in cms]
+    if cat_list is not None:
+        print(format_tabs(sc, ["Seg_1", "Seg_2"], cat_list=cat_list))
+    return sc[0], sc[1]
 
 
 def validate(model, data_loader, args, num_classes=21, cat_list=None, keep_logits=None):

@@ -263,9 +263,10 @@ int dupl_scale(float* y, float a, int64_t n, dupl_stream_t s);
  * out (B,H,W) int64 (utils/train_helper.py:143-145, the Seg_k prediction of validate_siamase). */
 int dupl_upsample_argmax(const float* logits, int64_t* out, int32_t B, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W,
                          dupl_stream_t s);
-/* one scale of tools/eval_seg_voc.py:58-72: segs (2,C,h,w) = the logits of [x; flip(x)]; v = up(segs[0]) +
- * flip(up(segs[1])) at (H,W); acc (C,H,W) = v when first != 0, else max(acc, v) (the max over scales). */
-int dupl_msc_seg_accum(const float* segs, float* acc, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W, int32_t first,
+/* one scale of tools/eval_seg_voc.py:58-72 / tools/eval_seg_coco_ddp.py:80-119: segs (2,C,h,w) = the logits of
+ * [x; flip(x)]; v = up(segs[0]) + flip(up(segs[1])) at (H,W); acc (C,H,W) = v (mode 0), max(acc, v) (mode 1: VOC's max
+ * over scales at label size), acc + v (mode 2: COCO's sum over scales at the scale-1 logit size). */
+int dupl_msc_seg_accum(const float* segs, float* acc, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W, int32_t mode,
                        dupl_stream_t s);
 /* argmax over the channel axis of x (B,C,HW) -> out (B,HW) int64, first maximum wins */
 int dupl_argmax_channels(const float* x, int64_t* out, int32_t B, int32_t C, int64_t HW, dupl_stream_t s);

@@ -763,6 +763,27 @@ def msc_seg_logits(p: Dict[str, Tensor], inputs: Tensor, out_size, cfg: ViTConfi
     return torch.max(torch.stack(per_scale, dim=0), dim=0)[0]
 
 
+def msc_seg_logits_coco(p: Dict[str, Tensor], inputs: Tensor, cfg: ViTConfig, scales=(1.0, 1.25, 1.5), size: int = 448) -> Tensor:
+    """tools/eval_seg_coco_ddp.py:76-119 for one student: resize to size x size; scale 1 gives the (h_s, w_s) logit
+    grid; every other scale's logits of [x_s; flip(x_s)] are resized to (h_s, w_s); flipped halves are flipped back and
+    added; the scales are summed.  -> (1,C1,h_s,w_s) (the caller up-samples it to the label size, :121-125)."""
+    with torch.no_grad():
+        x = F.interpolate(inputs, size=[size, size], mode="bilinear", align_corners=False)
+        _, _, h, w = x.shape
+        _x = F.interpolate(x, size=[h, w], mode="bilinear", align_corners=False)
+        segs = network_forward(p, torch.cat([_x, _x.flip(-1)], dim=0), cfg)[1]
+        seg = segs[:1] + segs[1:].flip(-1)
+        hs, ws = seg.shape[2:]
+        parts = [seg]
+        for sc in scales:
+            if sc != 1.0:
+                _x = F.interpolate(x, size=[int(h * sc), int(w * sc)], mode="bilinear", align_corners=False)
+                segs = network_forward(p, torch.cat([_x, _x.flip(-1)], dim=0), cfg)[1]
+                segs = F.interpolate(segs, size=(hs, ws), mode="bilinear", align_corners=False)
+                parts.append(segs[:1] + segs[1:].flip(-1))
+        return torch.sum(torch.stack(parts, dim=0), dim=0)
+
+
 # ----------------------------------------------------------------------------------------------
 # SURVEY 8f-3 (per-step part): the strong augmentation applied to every batch on the training path
 # (train_final_voc.py:191 -> utils/imutils.py:305-317 -> utils/randomaug.py:155-265)

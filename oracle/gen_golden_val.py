@@ -110,12 +110,53 @@ def main():
     seg_scores = {k: EV.scores(gts, preds[k], num_classes=NC) for k in (1, 2)}
     print("eval_seg: oracle == reference composition; mIoU", {k: round(float(seg_scores[k]['miou']), 4) for k in (1, 2)})
 
+    # ---- COCO-style inference (tools/eval_seg_coco_ddp.py:76-125): resize to a square, SUM over scales at logit size
+    coco_scales, csize = (1.0, 1.25, 1.5), 64
+    coco_pred, coco_logits = {1: [], 2: []}, {1: [], 2: []}
+    with torch.no_grad():
+        for inputs, labels, cls_label in samples:
+            x = F.interpolate(inputs, size=[csize, csize], mode="bilinear", align_corners=False)
+            _, _, h, w = x.shape
+            lists = {1: [], 2: []}
+            _inputs = F.interpolate(x, size=[h, w], mode="bilinear", align_corners=False)
+            res = sia(torch.cat([_inputs, _inputs.flip(-1)], dim=0))
+            for k in (1, 2):
+                segs = res[f"branch{k}"][1]
+                lists[k].append(segs[:1, ...] + segs[1:, ...].flip(-1))
+            h_s, w_s = lists[1][0].shape[2:]
+            for sc in coco_scales:
+                if sc != 1.0:
+                    _inputs = F.interpolate(x, size=[int(h * sc), int(w * sc)], mode="bilinear", align_corners=False)
+                    res = sia(torch.cat([_inputs, _inputs.flip(-1)], dim=0))
+                    for k in (1, 2):
+                        segs = F.interpolate(res[f"branch{k}"][1], size=(h_s, w_s), mode="bilinear", align_corners=False)
+                        lists[k].append(segs[:1, ...] + segs[1:, ...].flip(-1))
+            for k in (1, 2):
+                seg = torch.sum(torch.stack(lists[k], dim=0), dim=0)
+                coco_logits[k].append(seg)
+                rs = F.interpolate(seg, size=labels.shape[1:], mode="bilinear", align_corners=False)
+                coco_pred[k].append(torch.argmax(rs, dim=1)[0].numpy().astype(np.int16))
+    for k in (1, 2):
+        p = O.sub_params(pp, f"branch{k}.")
+        for (inputs, _, _), r in zip(samples, coco_logits[k]):
+            close(O.msc_seg_logits_coco(p, inputs, cfg, coco_scales, csize), r, 2e-5, f"coco msc seg branch{k}")
+    coco_scores = {k: EV.scores(gts, coco_pred[k], num_classes=NC) for k in (1, 2)}
+    coco_hist = {k: sum(EV._fast_hist(lt.flatten(), lp.flatten(), NC) for lt, lp in zip(gts, coco_pred[k])) for k in (1, 2)}
+    print("eval_seg_coco: oracle == reference composition; mIoU", {k: round(float(coco_scores[k]['miou']), 4) for k in (1, 2)})
+
     def iou_arr(s):
         return np.array(list(s["iou"].values()), dtype=np.float64)
 
     arrays = dict(crop_size=crop, scales=np.array(scales), cls_scores=np.array(cls_score),
                   msc_miou=np.array([seg_scores[1]["miou"], seg_scores[2]["miou"]]),
                   msc_iou_1=iou_arr(seg_scores[1]), msc_iou_2=iou_arr(seg_scores[2]))
+    arrays["coco_scales"], arrays["coco_size"] = np.array(coco_scales), csize
+    arrays["coco_miou"] = np.array([coco_scores[1]["miou"], coco_scores[2]["miou"]])
+    for k in (1, 2):
+        arrays[f"coco_hist.{k}"] = coco_hist[k].astype(np.int64)
+        for i, (m, pr) in enumerate(zip(coco_logits[k], coco_pred[k])):
+            arrays[f"coco_logits.{k}.{i}"] = m.contiguous()
+            arrays[f"coco_pred.{k}.{i}"] = pr.astype(np.uint8)
     for n in names:
         arrays[f"hist.{n}"] = ref_hist[n].astype(np.int64)
         arrays[f"miou.{n}"] = np.float64(ref_scores[n]["miou"])

@@ -93,3 +93,39 @@ def test_grad_allreduce_world2_gloo():
         assert ok_buckets, "buckets do not partition the trainable range"
         assert ok_mean, "all-reduce result != mean over ranks"
         assert ok_frozen, "frozen segment (pos_embed / head) was touched by the exchange"
+
+
+def _hist_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dupl_amd.utils import evaluate
+        rng = np.random.RandomState(5)
+        gts = [rng.randint(0, 23, size=(7, 9)) for _ in range(6)]
+        preds = [rng.randint(0, 21, size=(7, 9)) for _ in range(6)]
+        # round-robin shard of the "val set" per rank (tools/eval_seg_coco_ddp.py:239-245), per-rank histogram, SUM
+        h = torch.zeros((21, 21), dtype=torch.int64)
+        for i in range(rank, 6, world):
+            h += torch.from_numpy(evaluate._fast_hist(gts[i].flatten(), preds[i].flatten(), 21))
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        whole = evaluate.scores(gts, preds, 21)
+        mine = evaluate.scores_from_hist(h.numpy())
+        q.put((rank, abs(mine["miou"] - whole["miou"]) < 1e-12 and abs(mine["pAcc"] - whole["pAcc"]) < 1e-12))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eval_hist_exchange_world2_gloo():
+    """The evaluation path's only exchange: per-rank confusion matrices summed over ranks == the whole-set scores."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hist_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

@@ -154,3 +154,26 @@ def test_msc_seg_inference_and_checkpoint(dev, golden_dir, tmp_path):
         ref = float(g["msc_miou"][k - 1])
         print(f"branch{k}: msc mIoU {s['miou']:.6f} (reference {ref:.6f})")
         assert abs(s["miou"] - ref) < 2e-3
+
+
+def test_coco_style_msc_inference(dev, golden_dir):
+    """tools/eval_seg_coco_ddp.py:76-125 (resize to a square, sum over scales at logit size, up-sample the sum) vs the
+    reference composition in val_tiny.npz; 21-class tiny model, the ConfusionMatrix path of validate_coco."""
+    from dupl_amd.tools import eval_seg
+    g = np.load(os.path.join(golden_dir, "val_tiny.npz"))
+    model, _ = _tiny_model(dev)
+    loader = _loader()
+    scales = tuple(float(s) for s in g["coco_scales"])
+    size = int(g["coco_size"])
+    for i, data in enumerate(loader):
+        seg = eval_seg.msc_seg_logits_coco(model, data[1].to(dev), scales, size)
+        for k in (1, 2):
+            ref = torch.from_numpy(g[f"coco_logits.{k}.{i}"])
+            err = float((seg[k - 1].cpu() - ref).abs().max() / ref.abs().max())
+            assert err < 2e-4, (i, k, err)
+    args = types.SimpleNamespace(scales=scales, crop_size=size)
+    s1, s2 = eval_seg.validate_coco(model, loader, args, num_classes=21)
+    for k, s in ((1, s1), (2, s2)):
+        ref = float(g["coco_miou"][k - 1])
+        print(f"branch{k}: coco-style mIoU {s['miou']:.6f} (reference {ref:.6f})")
+        assert abs(s["miou"] - ref) < 2e-3
