@@ -1,5 +1,5 @@
 // The per-step strong augmentation on the device (reference: train_final_voc.py:191 -> utils/imutils.py:305-317 ->
-// utils/randomaug.py:155-265): the reference moves every batch GPU -> PIL -> GPU to run RandAugment(n, m) on the host.
+// utils/randomaug.py:62-115,161-265): the reference moves every batch GPU -> PIL -> GPU to run RandAugment(n, m) on the host.
 // RandAugment's active list is purely photometric (AutoContrast, Equalize, Posterize, Color, Contrast, Brightness,
 // Sharpness), all of it 8-bit integer / float32 arithmetic of Pillow with a fixed rounding behaviour, reproduced here
 // bit for bit on planar uint8 images (3, H, W):

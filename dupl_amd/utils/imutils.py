@@ -6,7 +6,7 @@ import torch
 from .. import ops
 from .._lib import lib as _L
 
-# randomaug.augment_list() (utils/randomaug.py:180-198): (op, minval, maxval)
+# randomaug.augment_list() (utils/randomaug.py:161-198): (op, minval, maxval)
 AUGMENT_LIST = (("AutoContrast", 0, 1), ("Equalize", 0, 1), ("Posterize", 0, 6), ("Color", 0.1, 1.9),
                 ("Contrast", 0.1, 1.9), ("Brightness", 0.1, 1.9), ("Sharpness", 0.1, 1.9))
 
@@ -24,7 +24,7 @@ def denormalize_img2(imgs=None):
 
 
 def rand_augment_ops(n, m):
-    """RandAugment.__call__'s draw (utils/randomaug.py:258-263) from Python's global `random` stream."""
+    """RandAugment.__call__'s draw (utils/randomaug.py:259-265) from Python's global `random` stream."""
     return [(name, (float(m) / 30) * float(hi - lo) + lo) for name, lo, hi in random.choices(AUGMENT_LIST, k=n)]
 
 

@@ -22,7 +22,7 @@ extern "C" {
 
 typedef void* dupl_stream_t;
 
-/* library / device info: returns the ABI version (1); fills arch name if buf != NULL */
+/* library info: returns the ABI version (1).  Infrastructure, no reference counterpart. */
 int dupl_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -55,14 +55,16 @@ typedef struct dupl_gemm_desc {
     float alpha;
     int32_t flags;
 } dupl_gemm_desc;
+/* the GEMM described above (vit.py:92-136, model_dupl.py:82-95, conv_head.py:32-41, losses.py:12 and their autograd) */
 int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
 /* Split-fp16 "3-pass" GEMM (v_mfma_f32_32x32x16_f16): same descriptor, fp32 in/out, operands split on the fly into
  * fp16 hi + lo and accumulated in fp32 as lo*hi + hi*lo + hi*hi (~1e-6 relative error).  Forward layouts/epilogues
  * only (no A_MCONTIG / B_NCONTIG / ACCUM / MUL_*).  Opt-in fast path for the nn.Linear forwards. */
 int dupl_gemm_h3(const dupl_gemm_desc* d, dupl_stream_t stream);
-/* tuning knob: force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic on the grid size) */
+/* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
 int dupl_set_gemm_tile(int32_t rows);
-/* tuning knob: row-tiles per group of the block -> C-tile order inside an XCD band (default 16; 4096 = plain row-major) */
+/* tuning knob (no reference counterpart): row-tiles per group of the block -> C-tile order inside an XCD band
+ * (default 16; 4096 = plain row-major) */
 int dupl_set_gemm_group(int32_t gm);
 
 /* ---------------------------------------------------------------------------------------------
@@ -73,11 +75,13 @@ int dupl_set_gemm_group(int32_t gm);
  *      dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (atomic accumulate: zero them first). */
 int dupl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s);
+/* LayerNorm backward (autograd of vit.py:157,159,323), optionally fused with the residual-stream gradient add */
 int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                        int64_t rows, int32_t D, dupl_stream_t s);
 
-/* column sums: out[n] (+)= sum_m x[m][n]  (bias gradients).  accumulate!=0 adds to out (atomic). */
+/* column sums: out[n] (+)= sum_m x[m][n]: the bias gradients autograd derives for nn.Linear (vit.py:92-102,115-122)
+ * and the patch-embed conv (vit.py:176-183).  accumulate!=0 adds to out (atomic). */
 int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int32_t ldx, int32_t accumulate,
                 dupl_stream_t s);
 
@@ -90,16 +94,18 @@ int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int32_t ldx, i
  * hd in {32, 64}. */
 int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H,
                        int32_t hd, float scale, dupl_stream_t s);
-/* backward: dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N] floats. */
+/* backward (what autograd derives for vit.py:123-135): dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N]. */
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,
                        float scale, dupl_stream_t s);
-/* tuning knob: 1 (default) = XCD-aware workgroup order of the attention kernels (whole heads per XCD), 0 = plain */
+/* tuning knob (no reference counterpart): 1 (default) = XCD-aware workgroup order of the attention kernels (whole
+ * heads per XCD), 0 = plain */
 int dupl_set_attention_remap(int32_t on);
 
 /* ---------------------------------------------------------------------------------------------
  * Token plumbing (vit.py:176-184, 289-306; model_dupl.py:64-67, 88-95). */
-/* im2row for the 16x16/s16 patch conv: x (B,3,H,W) -> rows [B*h*w][3*P*P] (c,py,px order = conv weight layout) */
+/* im2row for the 16x16/s16 patch conv PatchEmbed.proj (vit.py:176-183): x (B,3,H,W) -> rows [B*h*w][3*P*P] (c,py,px
+ * order = conv weight layout); trailing H % P rows / W % P columns are ignored like the strided conv does */
 int dupl_patch_im2row(const float* x, float* rows, int32_t B, int32_t H, int32_t W, int32_t P, dupl_stream_t s);
 /* inverse scatter is never needed (inputs get no grad). */
 /* bicubic (A=-0.75, align_corners=False) resize of the (g x g) pos-embed grid to (h x w); pos_embed (1,1+g*g,D)
@@ -108,15 +114,18 @@ int dupl_pos_embed_resize(const float* pos_embed, float* out, int32_t g, int32_t
 /* tokens[b][0] = cls + pos[0]; tokens[b][1+i] = patch[b][i] + pos[1+i]  (vit.py:300-304) */
 int dupl_assemble_tokens(const float* patch, const float* cls, const float* pos, float* tokens,
                          int32_t B, int32_t n, int32_t D, dupl_stream_t s);
-/* backward of the above wrt patch rows and cls token: dpatch[b][i] = dtok[b][1+i]; dcls += sum_b dtok[b][0] */
+/* backward of the above (autograd of vit.py:300-304) wrt patch rows and cls token: dpatch[b][i] = dtok[b][1+i];
+ * dcls += sum_b dtok[b][0] */
 int dupl_assemble_tokens_bwd(const float* dtok, float* dpatch, float* dcls, int32_t B, int32_t n, int32_t D, dupl_stream_t s);
-/* global max pool over the n patch tokens (skipping the cls row): tokens [B][1+n][D] -> out [B][D], idx [B][D] */
+/* F.adaptive_max_pool2d(x, (1,1)) of model_dupl.py:87-92 on token-major activations: max over the n patch tokens
+ * (skipping the cls row): tokens [B][1+n][D] -> out [B][D], idx [B][D] (first maximum, as torch) */
 int dupl_gmp_fwd(const float* tokens, float* out, int32_t* idx, int32_t B, int32_t n, int32_t D, dupl_stream_t s);
-/* dtokens[b][1+idx][d] += dout[b][d] */
+/* its adjoint (autograd of model_dupl.py:87-92): dtokens[b][1+idx][d] += dout[b][d] */
 int dupl_gmp_bwd(const float* dout, const int32_t* idx, float* dtokens, int32_t B, int32_t n, int32_t D, dupl_stream_t s);
 /* tokens [B][1+n][D] (skip cls) <-> NCHW (B,D,h,w): network.to_2D (model_dupl.py:64-67) and its adjoint
  * (adjoint ACCUMULATES into dtokens rows 1..n). */
 int dupl_tokens_to_nchw(const float* tokens, float* out, int32_t B, int32_t n, int32_t D, int32_t skip_cls, dupl_stream_t s);
+/* adjoint of network.to_2D (autograd of model_dupl.py:64-67) */
 int dupl_nchw_to_tokens_add(const float* dnchw, float* dtokens, int32_t B, int32_t n, int32_t D, int32_t skip_cls, dupl_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
@@ -178,13 +187,14 @@ int dupl_refine_merge(const float* lab_h, const float* lab_l, float* out, float 
  * sums[4] += {sum_pos |cos|, n_pos, sum_neg |cos|, n_neg} (zero first). */
 int dupl_ptc_reduce(const float* cos, const int64_t* label, const int64_t* mask, int32_t ignore_index, float* sums,
                     int32_t b, int32_t hw, dupl_stream_t s);
-/* in place: cos_signed -> d loss/d cos_signed = sign(cos) * (pos ? -0.5*g/(n_pos+1) : neg ? 0.5*g/(n_neg+1) : 0), g = gscale[0] */
+/* backward of get_masked_ptc_loss (autograd of losses.py:6-21), in place: cos_signed -> d loss/d cos_signed = sign(cos) * (pos ? -0.5*g/(n_pos+1) : neg ? 0.5*g/(n_neg+1) : 0), g = gscale[0] */
 int dupl_ptc_bwd_mask(float* cos_signed, const int64_t* label, const int64_t* mask, int32_t ignore_index,
                       const float* sums, const float* gscale, int32_t b, int32_t hw, dupl_stream_t s);
-/* F.normalize(p=2, dim=channel, eps) on token-major rows: row r of image i at x + i*img_stride + r*ldx;
+/* F.normalize(p=2, dim=channel, eps) of get_masked_ptc_loss (losses.py:11) and its adjoint, on token-major rows: row r of image i at x + i*img_stride + r*ldx;
  * xhat [rows][c] dense, norm [rows]. */
 int dupl_l2norm_rows_fwd(const float* x, float* xhat, float* norm, int64_t rows, int32_t c, int64_t ldx,
                          int32_t rows_per_img, int64_t img_stride, float eps, dupl_stream_t s);
+/* adjoint of the F.normalize above (autograd of losses.py:11) */
 int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const float* norm, float* dx, int64_t rows, int32_t c,
                          int64_t ldx, int32_t rows_per_img, int64_t img_stride, float eps, int32_t accumulate,
                          dupl_stream_t s);
@@ -213,6 +223,7 @@ int dupl_seg_pseudo_label(const float* logits, const float* other_label, int32_t
  * stats [B][DUPL_GMM_STATS] = {n selected, filtered?, mean0, mean1, cov0, cov1, weight0, weight1, EM iterations,
  * Lloyd iterations, mean log-likelihood, k-means centre0, centre1, #pixels relabelled, first seed index, second}. */
 #define DUPL_GMM_STATS 16
+/* (train_final_voc.py:363-394, see the comment above) */
 int dupl_gmm_noise_filter(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch, float* stats,
                           int32_t B, int32_t HW, int32_t ignore_index, float min_ce, int32_t min_count,
                           float valid_thre, float gamma, float reg_covar, float em_tol, int32_t em_iters, double u0,
@@ -229,12 +240,12 @@ int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t is_i64, in
  * token-major (element (i, t, c) at + i*img_stride + t*ld + c).  out [B][c]; stats [B][c][3] = {dot, |a|^2, |b|^2}. */
 int dupl_cos_sim_fwd(const float* a, const float* b, float* out, float* stats, int32_t B, int32_t n, int32_t c,
                      int64_t ld, int64_t img_stride, float eps, dupl_stream_t s);
-/* gradient wrt b only (a is detached): db (+)= g[0]*gmul * d cos / d b */
+/* autograd of train_final_voc.py:251-252 -- gradient wrt b only (a is detached): db (+)= g[0]*gmul * d cos / d b */
 int dupl_cos_sim_bwd(const float* a, const float* b, const float* stats, const float* g, float gmul, float* db, int32_t B,
                      int32_t n, int32_t c, int64_t ld, int64_t img_stride, float eps, int32_t accumulate, dupl_stream_t s);
-/* loss[0] += mul * sum(x[0..n)) */
+/* the .mean() of train_final_voc.py:251-252: loss[0] += mul * sum(x[0..n)) */
 int dupl_mean_accum(const float* x, float* loss, int64_t n, float mul, dupl_stream_t s);
-/* F.multilabel_soft_margin_loss (mean over classes then batch): loss[0] += value (if loss != NULL);
+/* F.multilabel_soft_margin_loss (train_final_voc.py:210-216; mean over classes then batch): loss[0] += value (if loss != NULL);
  * dlogits (if != NULL) = gscale[0] * d loss / d logits */
 int dupl_multilabel_soft_margin(const float* logits, const float* target, float* loss, float* dlogits, const float* gscale,
                                 int32_t b, int32_t C, dupl_stream_t s);
@@ -242,20 +253,25 @@ int dupl_multilabel_soft_margin(const float* logits, const float* target, float*
 /* ---------------------------------------------------------------------------------------------
  * LargeFOV helpers (conv_head.py:32-41): 3x3 dilated conv (zero padding = dilation) as im2col + GEMM with
  * token-major activations.  Column order is (c, tap) so conv weight (Cout,Cin,3,3) is the GEMM B operand in place. */
-/* x: pixel p, channel c of image b at x + b*img_stride + p*ld + c  ->  col [B*h*w][9*Cin] */
+/* conv6 / conv7 of LargeFOV.forward (conv_head.py:34-39): x: pixel p, channel c of image b at
+ * x + b*img_stride + p*ld + c  ->  col [B*h*w][9*Cin] */
 int dupl_im2col_dil3(const float* x, float* col, int32_t B, int32_t h, int32_t w, int32_t Cin, int32_t dil, int64_t ld,
                      int64_t img_stride, dupl_stream_t s);
-/* adjoint: dx (+)= gather of dcol, zeroed where relu_of (same layout as dx, post-ReLU activations) <= 0 if non-NULL */
+/* adjoint (autograd of conv_head.py:34-39): dx (+)= gather of dcol, zeroed where relu_of (same layout as dx, post-ReLU activations) <= 0 if non-NULL */
 int dupl_col2im_dil3(const float* dcol, float* dx, int32_t B, int32_t h, int32_t w, int32_t Cin, int32_t dil, int64_t ld,
                      int64_t img_stride, int32_t accumulate, const float* relu_of, dupl_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser (utils/optimizer.py:38-68 -> torch.optim.AdamW) and small element-wise helpers. */
-/* fused AdamW over one flat fp32 segment (16-byte aligned); bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t) (host, double) */
+/* PolyWarmupAdamW.step -> torch.optim.AdamW.step (utils/optimizer.py:38-68) fused over one flat fp32 segment (16-byte
+ * aligned); bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t) (host, double) */
 int dupl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float wd, float bc1, float bc2_sqrt, dupl_stream_t s);
+/* optimizer.zero_grad() (train_final_voc.py:470) and buffer initialisation: p[0..n) = v */
 int dupl_fill(float* p, float v, int64_t n, dupl_stream_t s);
-int dupl_axpy(float* y, const float* x, float a, int64_t n, dupl_stream_t s); /* y += a*x */
+/* y += a*x: the aux-branch gradient joining the residual stream (autograd of vit.py:316-326) */
+int dupl_axpy(float* y, const float* x, float a, int64_t n, dupl_stream_t s);
+/* y *= a: DDP's division of the all-reduced gradients by the world size (train_final_voc.py:155) */
 int dupl_scale(float* y, float a, int64_t n, dupl_stream_t s);
 
 /* ------------------------------------------------------------------ validation / evaluation */
@@ -268,7 +284,7 @@ int dupl_upsample_argmax(const float* logits, int64_t* out, int32_t B, int32_t C
  * over scales at label size), acc + v (mode 2: COCO's sum over scales at the scale-1 logit size). */
 int dupl_msc_seg_accum(const float* segs, float* acc, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W, int32_t mode,
                        dupl_stream_t s);
-/* argmax over the channel axis of x (B,C,HW) -> out (B,HW) int64, first maximum wins */
+/* torch.argmax(seg, dim=1) of tools/eval_seg_voc.py:77-78: x (B,C,HW) -> out (B,HW) int64, first maximum wins */
 int dupl_argmax_channels(const float* x, int64_t* out, int32_t B, int32_t C, int64_t HW, dupl_stream_t s);
 /* utils/evaluate.py:9-16 (_fast_hist) accumulated on the device: hist[t*nc + p] += 1 over the n pixels with
  * 0 <= gt < nc (predictions outside [0,nc) are skipped as well).  hist: nc*nc int64, zeroed by the caller. */
@@ -281,18 +297,19 @@ int dupl_multilabel_f1_accum(const float* logits, const float* label, int32_t B,
 /* ------------------------------------------------------------------ per-step strong augmentation
  * utils/imutils.py:305-317 augment_data_strong / utils/randomaug.py RandAugment on the device: planar uint8 images
  * (3,H,W), Pillow's exact 8-bit arithmetic (see csrc/augment.hip).  The op sequence per image is drawn on the host. */
-/* transforms.ToPILImage of a float tensor in [0,1]: out = (uint8)(x * 255) */
+/* transforms.ToPILImage of a float tensor in [0,1] (imutils.py:306,311): out = (uint8)(x * 255) */
 int dupl_aug_to_u8(const float* x, uint8_t* out, int64_t n, dupl_stream_t s);
-/* mode 0: PIL.ImageOps.autocontrast, 1: PIL.ImageOps.equalize, in place; hist_scratch 768 uint32, lut_scratch 768 bytes */
+/* mode 0: AutoContrast (randomaug.py:62-63), 1: Equalize (randomaug.py:70-71), in place; hist_scratch 768 uint32, lut_scratch 768 bytes */
 int dupl_aug_lut_op(uint8_t* img, int32_t H, int32_t W, int32_t mode, uint32_t* hist_scratch, uint8_t* lut_scratch,
                     dupl_stream_t s);
-/* PIL.ImageOps.posterize(img, bits), in place over n bytes */
+/* Posterize (randomaug.py:92-95): PIL.ImageOps.posterize(img, bits), in place over n bytes */
 int dupl_aug_posterize(uint8_t* img, int64_t n, int32_t bits, dupl_stream_t s);
-/* PIL.ImageEnhance.{Color (mode 0), Contrast (1), Brightness (2)}(img).enhance(factor), in place; sum_scratch: 1 uint64 */
+/* Color (mode 0, randomaug.py:103-105), Contrast (1, :98-100), Brightness (2, :108-110): PIL.ImageEnhance.*(img)
+ * .enhance(factor), in place; sum_scratch: 1 uint64 */
 int dupl_aug_enhance(uint8_t* img, int32_t H, int32_t W, int32_t mode, float factor, uint64_t* sum_scratch, dupl_stream_t s);
-/* PIL.ImageEnhance.Sharpness(img).enhance(factor): out != in */
+/* Sharpness (randomaug.py:113-115): PIL.ImageEnhance.Sharpness(img).enhance(factor); out != in */
 int dupl_aug_sharpness(const uint8_t* in, uint8_t* out, int32_t H, int32_t W, float factor, dupl_stream_t s);
-/* transforms.ToTensor + Normalize(ImageNet mean/std) + torch.flip(dims=[2]): out (3,H,W) float32 */
+/* transforms.ToTensor + Normalize(ImageNet mean/std) + torch.flip(dims=[2]) (imutils.py:307-315): out (3,H,W) float32 */
 int dupl_aug_finish(const uint8_t* img, float* out, int32_t H, int32_t W, dupl_stream_t s);
 
 #ifdef __cplusplus

@@ -786,15 +786,15 @@ def msc_seg_logits_coco(p: Dict[str, Tensor], inputs: Tensor, cfg: ViTConfig, sc
 
 # ----------------------------------------------------------------------------------------------
 # SURVEY 8f-3 (per-step part): the strong augmentation applied to every batch on the training path
-# (train_final_voc.py:191 -> utils/imutils.py:305-317 -> utils/randomaug.py:155-265)
+# (train_final_voc.py:191 -> utils/imutils.py:305-317 -> utils/randomaug.py:62-115,161-265)
 # ----------------------------------------------------------------------------------------------
-# randomaug.augment_list() (utils/randomaug.py:180-198): (op, minval, maxval), all photometric
+# randomaug.augment_list() (utils/randomaug.py:161-198): (op, minval, maxval), all photometric
 AUGMENT_LIST = (("AutoContrast", 0, 1), ("Equalize", 0, 1), ("Posterize", 0, 6), ("Color", 0.1, 1.9),
                 ("Contrast", 0.1, 1.9), ("Brightness", 0.1, 1.9), ("Sharpness", 0.1, 1.9))
 
 
 def rand_augment_ops(n: int, m: int, rng=None):
-    """RandAugment.__call__'s draw (randomaug.py:258-263): n ops with replacement from the list through
+    """RandAugment.__call__'s draw (randomaug.py:259-265): n ops with replacement from the list through
     random.choices, magnitude val = m/30 * (max - min) + min.  rng: the `random` module (default) or a random.Random."""
     import random as _random
     rng = rng or _random
@@ -803,7 +803,7 @@ def rand_augment_ops(n: int, m: int, rng=None):
 
 
 def apply_pil_op(img, name: str, val: float):
-    """One op of utils/randomaug.py:62-110 on a PIL image -- third-party dependency: Pillow (PIL.ImageOps /
+    """One op of utils/randomaug.py:62-115 on a PIL image -- third-party dependency: Pillow (PIL.ImageOps /
     PIL.ImageEnhance), called exactly as the reference calls it."""
     import PIL.ImageEnhance
     import PIL.ImageOps
