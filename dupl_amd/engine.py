@@ -292,6 +292,53 @@ def cam_logits(P: StudentParams, x: Tensor):
     return cam_aux, cam
 
 
+def cam_logits_multi(P: StudentParams, xs):
+    """cam_only logits of SEVERAL batches of different resolution in one encoder pass (no activation saving): the token
+    rows of all batches are concatenated, so every LayerNorm / Linear runs once over sum_i B_i*(1+n_i) rows (the 0.5x
+    ms-CAM scale alone is 1 576 rows = 150-600 GEMM blocks on 256 CUs; merged with the 1.5x scale it rides in a
+    15 696-row GEMM) and only attention, which mixes tokens of one image, runs per batch on its row slice.  Row-wise
+    ops make this bit-identical to separate passes.  Returns [(cam_aux_tok, cam_tok)] per batch (row-slice views)."""
+    cfg = P.cfg
+    D, H, hd = cfg.embed_dim, cfg.num_heads, cfg.head_dim
+    W = P.w
+    toks, groups = [], []
+    r0 = 0
+    for x in xs:
+        B, _, Himg, Wimg = x.shape
+        h, w = Himg // cfg.patch, Wimg // cfg.patch
+        n = h * w
+        rows = ops.patch_im2row(x, cfg.patch)
+        patch = ops.linear(rows, W["encoder.patch_embed.proj.weight"], W["encoder.patch_embed.proj.bias"])
+        toks.append(ops.assemble_tokens(patch, W["encoder.cls_token"], P.pos_embed_for(h, w), B, n, D))
+        groups.append((r0, B, n + 1))
+        r0 += B * (n + 1)
+    t = torch.cat(toks, dim=0) if len(toks) > 1 else toks[0]
+    del toks
+    aux_idx = cfg.aux_layer % cfg.depth
+    aux = None
+    scale = hd ** -0.5
+    for i in range(cfg.depth):
+        p = f"encoder.blocks.{i}."
+        ln1, _, _ = ops.layernorm_fwd(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, False)
+        qkv = ops.linear(ln1, W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"])
+        att = torch.empty((t.shape[0], D), device=t.device, dtype=torch.float32)
+        for (g0, B, N) in groups:
+            ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, out=att[g0:g0 + B * N])
+        x_mid = ops.linear(att, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], res=t)
+        ln2, _, _ = ops.layernorm_fwd(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, False)
+        h1 = ops.linear(ln2, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], gelu=True)
+        t = ops.linear(h1, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"], res=x_mid)
+        if i == aux_idx and i != cfg.depth - 1:
+            aux = t
+    tf, _, _ = ops.layernorm_fwd(t, W["encoder.norm.weight"], W["encoder.norm.bias"], cfg.ln_eps, False)
+    if aux is None:
+        aux = tf
+    C = P.num_classes - 1
+    cam = ops.linear(tf, W["classifier.weight"].view(C, -1))
+    cam_aux = ops.linear(aux, W["aux_classifier.weight"].view(C, -1))
+    return [(cam_aux[g0:g0 + B * N], cam[g0:g0 + B * N]) for (g0, B, N) in groups]
+
+
 @dataclass
 class HeadSaved:
     enc: EncoderSaved = None

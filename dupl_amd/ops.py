@@ -152,8 +152,12 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attention_fwd(qkv: Tensor, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool = False):
-    out = torch.empty((B * N, H * hd), device=qkv.device, dtype=torch.float32)
+def attention_fwd(qkv: Tensor, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool = False, out: Tensor = None):
+    """out: optional [B*N, H*hd] destination (a contiguous row slice of a larger token buffer)."""
+    if out is None:
+        out = torch.empty((B * N, H * hd), device=qkv.device, dtype=torch.float32)
+    else:
+        assert out.shape == (B * N, H * hd) and out.is_contiguous() and qkv.is_contiguous()
     lse = torch.empty((B, H, N), device=qkv.device, dtype=torch.float32) if need_lse else None
     L().dupl_attention_fwd(qkv.data_ptr(), out.data_ptr(), _p(lse), B, N, H, hd, scale, _stream())
     return out, lse

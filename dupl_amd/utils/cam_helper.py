@@ -24,43 +24,29 @@ def _student(model, branch):
 
 def _ms_cam(P, inputs, scales, share=None):
     """cam_helper.py:164-204 fused (`share`: optional dict that receives the encoder state of the un-flipped
-    scale-1.0 pass under key "enc" for reuse by the training forward of the same step): per scale one no-grad encoder pass over [x ; flip(x)] at that resolution and one
-    skinny GEMM per classifier; all scales are then up-sampled / flip-max'ed / ReLU'ed / summed and min-max
-    normalised by two streaming kernels (the low-resolution logits stay token-major)."""
+    scale-1.0 pass under key "enc" for reuse by the training forward of the same step): every scale's [x ; flip(x)]
+    batch goes through the encoder (all no-grad scales in ONE merged pass, engine.cam_logits_multi) and one skinny GEMM
+    per classifier; all scales are then up-sampled / flip-max'ed / ReLU'ed / summed and min-max normalised by two
+    streaming kernels (the low-resolution logits stay token-major)."""
     inputs = inputs.contiguous().float()
     b, _, h, w = inputs.shape
     C = P.num_classes - 1
     patch = P.cfg.patch
     order = [1.0] + [s for s in scales if s != 1.0]   # 1.0 first, then tuple order (cam_helper.py:169-196)
-    lows, lows_aux, sizes = [], [], []
-    # the scales are independent until the fusion: with scale streams enabled (siamese_network.enable_dual_stream)
-    # each scale's encoder pass runs on its own HIP stream so the small-grid 0.5x pass hides under the 1.5x pass
-    pool = P.store.scale_streams.get(P.student, []) if inputs.is_cuda else []
-    cur = torch.cuda.current_stream() if pool else None
     with torch.no_grad():
-        for i, s in enumerate(order):
-            hs, ws = (h, w) if s == 1.0 else (int(s * h), int(s * w))
-            st = pool[i % len(pool)] if pool else None
-            if st is not None:
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
-                    cam_aux_t, cam_t = engine.cam_logits(P, x2)
-                cam_t.record_stream(cur)
-                cam_aux_t.record_stream(cur)
-            elif share is not None and s == 1.0:
-                x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
-                cam_aux_t, cam_t, share["enc"] = engine.cam_logits_shared(P, x2, b)
-                share["x"] = x2[:b]
-            else:
-                x2 = ops.resize_bilinear(inputs, hs, ws, flip_cat=True)
-                cam_aux_t, cam_t = engine.cam_logits(P, x2)
-            lows.append(cam_t)
-            lows_aux.append(cam_aux_t)
-            sizes.append((hs // patch, ws // patch))
-        if pool:
-            for st in pool:
-                cur.wait_stream(st)
+        dims = [(h, w) if s == 1.0 else (int(s * h), int(s * w)) for s in order]
+        xs = [ops.resize_bilinear(inputs, hs, ws, flip_cat=True) for hs, ws in dims]
+        sizes = [(hs // patch, ws // patch) for hs, ws in dims]
+        if share is not None:
+            # scale 1.0 runs WITH activation saving and doubles as the training forward; the remaining scales share
+            # one merged no-grad pass (engine.cam_logits_multi)
+            cam_aux_t, cam_t, share["enc"] = engine.cam_logits_shared(P, xs[0], b)
+            share["x"] = xs[0][:b]
+            res = [(cam_aux_t, cam_t)] + (engine.cam_logits_multi(P, xs[1:]) if len(xs) > 1 else [])
+        else:
+            res = engine.cam_logits_multi(P, xs)
+        lows_aux = [r[0] for r in res]
+        lows = [r[1] for r in res]
         cam, mm = ops.cam_fuse(lows, sizes, b, C, h, w, row_off=1, ldc=C)
         ops.cam_normalise_(cam, mm)
         cam_aux, mm2 = ops.cam_fuse(lows_aux, sizes, b, C, h, w, row_off=1, ldc=C)
