@@ -128,7 +128,6 @@ class FlatStorage:
         # sticky "this segment has received a gradient at least once" flags == torch's `p.grad is None` skip
         self.seg_has_grad = [[False] * 5 for _ in range(n_students)]
         self.streams: List = []     # side streams the students run on (siamese_network.enable_dual_stream)
-        self.scale_streams: Dict[int, List] = {}   # per student: one stream per ms-CAM scale
 
     def wait_streams(self):
         """Make the current stream wait for everything queued on the student streams."""
@@ -136,9 +135,6 @@ class FlatStorage:
             cur = torch.cuda.current_stream()
             for s in self.streams:
                 cur.wait_stream(s)
-            for pool in self.scale_streams.values():
-                for s in pool:
-                    cur.wait_stream(s)
 
     def view(self, student: int, key: str, grad: bool = False) -> Tensor:
         off, n = self.layout[key]

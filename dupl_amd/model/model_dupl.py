@@ -263,7 +263,7 @@ class siamese_network(nn.Module):
         return self._store
 
     # ---- two-student concurrency --------------------------------------------------------------
-    def enable_dual_stream(self, on: bool = True, scale_streams: bool = False):
+    def enable_dual_stream(self, on: bool = True):
         """Run the two (independent) students on two HIP streams so that their kernels share the 256 CUs:
         a single student's N=768 GEMMs / attention grids do not fill the chip.  Autograd replays each student's
         backward on the stream its forward ran on; the optimiser and the gradient exchange wait on both."""
@@ -271,12 +271,8 @@ class siamese_network(nn.Module):
         if on and self._store.data.is_cuda and not self._store.streams:
             dev = self._store.data.device
             self._store.streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-            # one extra stream per ms-CAM scale: measured no gain on MI355X (24.03 vs 24.16 img/s) -> off by default
-            self._store.scale_streams = ({s: [torch.cuda.Stream(device=dev) for _ in range(3)] for s in range(2)}
-                                         if scale_streams else {})
         if not on:
             self._store.streams = []
-            self._store.scale_streams = {}
         return self
 
     def ms_cam_and_forward(self, inputs, scales, inputs_aug=None):
