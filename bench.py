@@ -45,8 +45,6 @@ def parse():
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline (0 = all logical CPUs)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--forward-precision", default="f32", choices=["f32", "h3"],
-                    help="f32: exact f32-MFMA everywhere (default); h3: split-fp16 3-pass MFMA for the Linear forwards")
     ap.add_argument("--no-share-encoder", action="store_true",
                     help="run the training forward's encoder pass separately from ms-CAM's identical scale-1.0 pass, exactly "
                          "like the reference does (default: computed once and shared; outputs are bit-identical)")
@@ -178,8 +176,6 @@ def main():
     from dupl_amd.ddp import DistributedDataParallel
     from dupl_amd import trainer
 
-    from dupl_amd import ops as _ops
-    _ops.set_forward_precision(args.forward_precision)
     C = 20 if args.dataset == "voc" else 80
     sargs = trainer.StepArgs() if args.dataset == "voc" else trainer.coco_step_args()
     sargs.share_encoder_pass = not args.no_share_encoder
@@ -266,7 +262,6 @@ def main():
                                       f"{args.batch} img/GPU, DDP world_size={world}",
                           "global_batch": world * args.batch, "img_per_gpu": args.batch, "num_classes": C + 1,
                           "n_iter": args.n_iter, "parallelism": f"dp{world}", "student_streams": 1 if args.single_stream else 2,
-                          "forward_precision": args.forward_precision,
                           "shared_scale1_encoder_pass": not args.no_share_encoder,
                           "loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}

@@ -37,26 +37,10 @@ def _chk(t: Tensor, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-_FORWARD_PRECISION = "f32"
-
-
-def set_forward_precision(mode: str):
-    """"f32": every GEMM on the exact f32-input MFMA (default, the parity reference).
-    "h3": nn.Linear-style forwards on the split-fp16 3-pass MFMA kernel (dupl_gemm_h3, ~1e-6 relative error);
-    backward GEMMs always stay f32."""
-    global _FORWARD_PRECISION
-    assert mode in ("f32", "h3")
-    _FORWARD_PRECISION = mode
-
-
-def forward_precision() -> str:
-    return _FORWARD_PRECISION
-
-
 def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, flags: int = 0,
              bias: Optional[int] = None, res: Optional[int] = None, ldr: int = 0, aux: Optional[int] = None,
              ldaux: int = 0, alpha: float = 1.0, batch: int = 1, zdiv: int = 1,
-             sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sX=(0, 0), sBias=(0, 0), h3: bool = False):
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sX=(0, 0), sBias=(0, 0)):
     """Pointer-level GEMM; strides are in elements.  z -> (z // zdiv, z % zdiv)."""
     d = GemmDesc()
     d.A, d.B, d.C = A, B, C
@@ -71,10 +55,7 @@ def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int,
     d.sX0, d.sX1 = sX
     d.sBias0, d.sBias1 = sBias
     d.alpha, d.flags = alpha, flags
-    if h3:
-        L().dupl_gemm_h3(ctypes.byref(d), _stream())
-    else:
-        L().dupl_gemm_f32(ctypes.byref(d), _stream())
+    L().dupl_gemm_f32(ctypes.byref(d), _stream())
 
 
 def linear(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, gelu: bool = False, relu: bool = False,
@@ -90,8 +71,7 @@ def linear(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, gelu: bool = 
         fl |= _lib.GEMM_STORE_PRE
     gemm_raw(x.data_ptr(), W.data_ptr(), y.data_ptr(), M, N, K, x.stride(0), K, y.stride(0), flags=fl,
              bias=_p(bias), res=_p(res), ldr=(res.stride(0) if res is not None else 0),
-             aux=_p(store_pre), ldaux=(store_pre.stride(0) if store_pre is not None else 0),
-             h3=(_FORWARD_PRECISION == "h3"))
+             aux=_p(store_pre), ldaux=(store_pre.stride(0) if store_pre is not None else 0))
     return y
 
 

@@ -57,10 +57,6 @@ typedef struct dupl_gemm_desc {
 } dupl_gemm_desc;
 /* the GEMM described above (vit.py:92-136, model_dupl.py:82-95, conv_head.py:32-41, losses.py:12 and their autograd) */
 int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
-/* Split-fp16 "3-pass" GEMM (v_mfma_f32_32x32x16_f16): same descriptor, fp32 in/out, operands split on the fly into
- * fp16 hi + lo and accumulated in fp32 as lo*hi + hi*lo + hi*hi (~1e-6 relative error).  Forward layouts/epilogues
- * only (no A_MCONTIG / B_NCONTIG / ACCUM / MUL_*).  Opt-in fast path for the nn.Linear forwards. */
-int dupl_gemm_h3(const dupl_gemm_desc* d, dupl_stream_t stream);
 /* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
 int dupl_set_gemm_tile(int32_t rows);
 /* tuning knob (no reference counterpart): row-tiles per group of the block -> C-tile order inside an XCD band
