@@ -122,3 +122,69 @@ def test_bench_contract_line(dev):
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert 0.3 < rf["frac"] < 1.0 and d["value"] > 10.0
+
+
+def test_ddp_two_ranks_on_one_gpu_gloo(dev, tmp_path):
+    """Real multi-rank semantics of dupl_amd.ddp on the GPU engine: two processes share cuda:0 and exchange through
+    gloo (RCCL refuses two ranks on one device; the 8-GPU RCCL run is the driver's).  Rank 1 starts from perturbed
+    weights (the constructor broadcast must equalise them), each rank draws its own batch, and the gradients left in
+    the flat buffer after backward must equal the mean of the two single-process gradients -- with the layer-granular
+    buckets issued from inside the backward, two student streams, phases B and C."""
+    script = tmp_path / "ddp2.py"
+    script.write_text(r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DUPL_ROOT"])
+from oracle import dupl_oracle as O
+from dupl_amd.model.model_dupl import siamese_network
+from dupl_amd.model.PAR import PAR
+from dupl_amd.ddp import DistributedDataParallel
+from dupl_amd import trainer
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+dev = torch.device("cuda:0")
+pp = O.make_siamese_params(O.VIT_TINY, 21, seed=2)
+par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+
+def batch(r, n_iter):
+    x, c, box = O.synthetic_batch(2, 20, 64, seed=5 + r)
+    aug = None
+    if n_iter >= 8000:
+        a, _, _ = O.synthetic_batch(2, 20, 64, seed=19 + r)
+        aug = torch.flip(0.7 * x + 0.3 * a, dims=[3]).contiguous().to(dev)
+    return x.to(dev), c, box, aug
+
+def grads(model, wrapped, r, n_iter):
+    x, c, box, aug = batch(r, n_iter)
+    model.flat_storage.grad.zero_()
+    loss, _ = trainer.compute_losses(wrapped, par, x, c.to(dev), box, n_iter, trainer.StepArgs(), c, inputs_aug=aug)
+    loss.sum().backward()
+    model.flat_storage.wait_streams(); torch.cuda.synchronize()
+    return model.flat_storage.grad.clone()
+
+for n_iter in (5000, 9000):
+    m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    m.load_state_dict({k: (v * (1.0 + 0.01 * rank)) for k, v in pp.items()}); m.to(dev); m.enable_dual_stream(True)
+    w = DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
+    assert all(torch.equal(m.state_dict()[k].cpu(), v) for k, v in pp.items()), "broadcast from rank 0"
+    got = grads(m, w, rank, n_iter)
+    ref_m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    ref_m.load_state_dict(pp); ref_m.to(dev); ref_m.enable_dual_stream(True)
+    ref = 0.5 * (grads(ref_m, ref_m, 0, n_iter) + grads(ref_m, ref_m, 1, n_iter))
+    for s in (0, 1):
+        lo, hi = m.flat_storage.trainable_range(s)
+        e = (got[lo:hi] - ref[lo:hi]).abs().max().item() / ref[lo:hi].abs().max().item()
+        print("DDP2_REL_ERR", rank, n_iter, s, e)
+        assert e < 1e-5, e
+        flo = s * m.flat_storage.student_numel
+        assert float(got[flo:flo + m.flat_storage.seg_bounds[0][1]].abs().max()) == 0.0   # frozen segment untouched
+dist.barrier()
+dist.destroy_process_group()
+print("DDP2_OK", rank)
+''')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DUPL_ROOT=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", str(script)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and out.count("DDP2_OK") == 2 and out.count("DDP2_REL_ERR") == 8, out[-5000:]
