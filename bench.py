@@ -200,7 +200,7 @@ def main():
     def barrier():
         if world > 1:
             import torch.distributed as dist
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     log(f"model on {dev}; starting {args.warmup} warm-up step(s)")
