@@ -16,7 +16,6 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --single-stream --steps 3 --warmup 1 --cpu-baseline skip"
 rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
-( cd $R && timeout 400 python bench.py 2> $OUT/bench.log | tail -1 > $OUT/${TAG}_bench.json )
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/k -o k -- $BENCH > $OUT/k.log 2>&1
 grep '^{' $OUT/k.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
 python $R/tools/rocpd_stats.py $(find /tmp/prof_$TAG/k -name '*.db' | head -1) > $OUT/${TAG}_kernel_stats.txt 2>&1
@@ -29,5 +28,8 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_$TAG/b -o b -
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_$TAG/c -o c -- $BENCH --no-roofline > $OUT/c.log 2>&1
 python $R/tools/rocpd_pmc.py $(find /tmp/prof_$TAG/b -name '*.db' | head -1) $(find /tmp/prof_$TAG/c -name '*.db' | head -1) > $OUT/${TAG}_pmc_hbm.txt 2>&1
 rm -rf /tmp/prof_$TAG
+# the un-profiled default bench line goes last: its roofline.traffic is read from the PMC summary just produced
+cp $OUT/${TAG}_pmc_hbm.txt $R/profiles/${TAG}_pmc_hbm.txt
+( cd $R && timeout 400 python bench.py 2> $OUT/bench.log | tail -1 > $OUT/${TAG}_bench.json )
 ls -la $OUT
 head -12 $OUT/${TAG}_kernel_stats.txt | cut -c1-160
