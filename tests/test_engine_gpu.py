@@ -335,3 +335,56 @@ def test_single_student_gradients_vs_oracle_autograd(dev, S, second):
         g = net._store.view(0, k, grad=True).cpu()
         worst = max(worst, ((g - v.grad).abs().max() / v.grad.abs().max().clamp_min(1e-20)).item())
     assert worst < 2e-5, worst
+
+
+def test_full_size_vitb_step_vs_oracle(dev):
+    """BASELINE config at FULL size: dual-student ViT-B/16, 448^2, phase B, one image -- the whole step (ms-CAM at three
+    scales, dual forward/backward, PAR refinement, all losses) against the CPU oracle run on this box's host cores
+    (~10-40 s).  Bars: CAM max-abs-diff < 1e-3 (north_star), identical pseudo-label maps, refined label maps equal up to
+    argmax near-ties, loss pieces 1e-4, gradients of a spread of tensors 2e-3."""
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd import trainer
+    from oracle import dupl_oracle as O
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cfg, NC = O.VIT_BASE, 21
+    pp = O.make_siamese_params(cfg, NC, seed=3)
+    inputs, cls_label, img_box = O.synthetic_batch(1, NC - 1, 448, seed=100)
+    model = siamese_network("deit_base_patch16_224", num_classes=NC, pretrained=False, aux_layer=-3)
+    model.load_state_dict(pp, strict=True)
+    model.to(dev)
+    model.enable_dual_stream(True)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    model.flat_storage.grad.zero_()
+    loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, 5000, trainer.StepArgs(),
+                                       cls_label_host=cls_label)
+    loss.sum().backward()
+    model.flat_storage.wait_streams()
+    torch.cuda.synchronize()
+    watch = ["branch1.encoder.blocks.0.attn.qkv.weight", "branch1.encoder.blocks.11.mlp.fc2.weight",
+             "branch2.encoder.blocks.5.norm1.weight", "branch2.encoder.patch_embed.proj.weight",
+             "branch1.decoder.conv6.weight", "branch2.classifier.weight", "branch1.encoder.cls_token",
+             "branch2.encoder.blocks.9.attn.proj.bias"]
+    leaf = {k: v.clone().requires_grad_(k in watch) for k, v in pp.items()}
+    ref_loss, pc = O.train_step_losses(leaf, inputs, cls_label, img_box, 5000, cfg, O.StepArgs())
+    ref_loss.backward()
+    for k in ("loss", "cls_loss", "ptc_loss", "seg_loss", "sim_loss"):
+        got, ref = float(out[k].reshape(-1)[0].item()), float(pc[k].reshape(-1)[0].item())
+        print(f"full-size {k}: oracle {ref:.6f} got {got:.6f}")
+        assert abs(got - ref) <= 1e-4 * max(1.0, abs(ref)), k
+    for k in ("cams_1", "cams_aux_1", "cams_2", "cams_aux_2"):
+        d = float((out[k].cpu() - pc[k]).abs().max())
+        print(f"full-size {k}: max-abs-diff {d:.2e}")
+        assert d < 1e-3, k
+    for k in ("pseudo_label_aux_1", "pseudo_label_aux_2"):
+        assert torch.equal(out[k].cpu().long(), pc[k].long()), k
+    for k in ("refined_1", "refined_2"):
+        mism = int((out[k].cpu().long() != pc[k].long()).sum())
+        print(f"full-size {k}: {mism} label mismatches of {pc[k].numel()}")
+        assert mism <= 20, k
+    for k in watch:
+        got = model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True).cpu()
+        ref = leaf[k].grad
+        e = float((got - ref).abs().max() / ref.abs().max())
+        print(f"full-size grad {k}: rel err {e:.2e}")
+        assert e < 2e-3, k
