@@ -337,17 +337,26 @@ def test_single_student_gradients_vs_oracle_autograd(dev, S, second):
     assert worst < 2e-5, worst
 
 
-def test_full_size_vitb_step_vs_oracle(dev):
-    """BASELINE config at FULL size: dual-student ViT-B/16, 448^2, phase B, one image -- the whole step (ms-CAM at three
-    scales, dual forward/backward, PAR refinement, all losses) against the CPU oracle run on this box's host cores
-    (~10-40 s).  Bars: CAM max-abs-diff < 1e-3 (north_star), identical pseudo-label maps, refined label maps equal up to
-    argmax near-ties, loss pieces 1e-4, gradients of a spread of tensors 2e-3."""
+@pytest.mark.parametrize("case", ["voc_B", "coco_B2", "voc_C"])
+def test_full_size_vitb_step_vs_oracle(dev, case):
+    """BASELINE configs at FULL size: dual-student ViT-B/16, 448^2, one image -- the whole step (ms-CAM at three scales,
+    dual forward/backward, PAR refinement, all losses; voc_C adds the on-device RandAugment view, the 336^2 aug
+    forward/backward, the GMM filter and the consistency loss; coco_B2 has 81 classes and the COCO schedule) against the
+    CPU oracle run on this box's host cores (~10-40 s per case).  Bars: CAM max-abs-diff < 1e-3 (north_star), identical
+    pseudo-label maps, refined label maps equal up to argmax near-ties, loss pieces 1e-4, gradients of a spread of
+    tensors 2e-3."""
+    import random
     from dupl_amd.model.model_dupl import siamese_network
     from dupl_amd.model.PAR import PAR
     from dupl_amd import trainer
     from oracle import dupl_oracle as O
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    cfg, NC = O.VIT_BASE, 21
+    cfg = O.VIT_BASE
+    coco = case.startswith("coco")
+    NC = 81 if coco else 21
+    n_iter = {"voc_B": 5000, "coco_B2": 20000, "voc_C": 9000}[case]
+    targs = trainer.coco_step_args() if coco else trainer.StepArgs()
+    oargs = O.coco_step_args() if coco else O.StepArgs()
     pp = O.make_siamese_params(cfg, NC, seed=3)
     inputs, cls_label, img_box = O.synthetic_batch(1, NC - 1, 448, seed=100)
     model = siamese_network("deit_base_patch16_224", num_classes=NC, pretrained=False, aux_layer=-3)
@@ -356,7 +365,8 @@ def test_full_size_vitb_step_vs_oracle(dev):
     model.enable_dual_stream(True)
     par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
     model.flat_storage.grad.zero_()
-    loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, 5000, trainer.StepArgs(),
+    random.seed(77)        # voc_C: the step draws RandAugment(5, 10) ops from the global `random` stream
+    loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, n_iter, targs,
                                        cls_label_host=cls_label)
     loss.sum().backward()
     model.flat_storage.wait_streams()
@@ -366,25 +376,33 @@ def test_full_size_vitb_step_vs_oracle(dev):
              "branch1.decoder.conv6.weight", "branch2.classifier.weight", "branch1.encoder.cls_token",
              "branch2.encoder.blocks.9.attn.proj.bias"]
     leaf = {k: v.clone().requires_grad_(k in watch) for k, v in pp.items()}
-    ref_loss, pc = O.train_step_losses(leaf, inputs, cls_label, img_box, 5000, cfg, O.StepArgs())
-    ref_loss.backward()
-    for k in ("loss", "cls_loss", "ptc_loss", "seg_loss", "sim_loss"):
+    aug = None
+    if case == "voc_C":
+        random.seed(77)
+        aug = O.augment_data_strong(O.denormalize_img2(inputs.clone()), n=5, m=10)     # PIL on the host
+    ref_loss, pc = O.train_step_losses(leaf, inputs, cls_label, img_box, n_iter, cfg, oargs, inputs_aug=aug)
+    ref_loss.sum().backward()
+    keys = ["loss", "cls_loss", "ptc_loss", "seg_loss", "sim_loss"] + (["reg_loss"] if case == "voc_C" else [])
+    for k in keys:
         got, ref = float(out[k].reshape(-1)[0].item()), float(pc[k].reshape(-1)[0].item())
-        print(f"full-size {k}: oracle {ref:.6f} got {got:.6f}")
+        print(f"full-size {case} {k}: oracle {ref:.6f} got {got:.6f}")
         assert abs(got - ref) <= 1e-4 * max(1.0, abs(ref)), k
     for k in ("cams_1", "cams_aux_1", "cams_2", "cams_aux_2"):
         d = float((out[k].cpu() - pc[k]).abs().max())
-        print(f"full-size {k}: max-abs-diff {d:.2e}")
+        print(f"full-size {case} {k}: max-abs-diff {d:.2e}")
         assert d < 1e-3, k
     for k in ("pseudo_label_aux_1", "pseudo_label_aux_2"):
         assert torch.equal(out[k].cpu().long(), pc[k].long()), k
-    for k in ("refined_1", "refined_2"):
+    for k in ("refined_1", "refined_2") + (("pseudo_seg_1", "pseudo_seg_2") if case == "voc_C" else ()):
         mism = int((out[k].cpu().long() != pc[k].long()).sum())
-        print(f"full-size {k}: {mism} label mismatches of {pc[k].numel()}")
+        print(f"full-size {case} {k}: {mism} label mismatches of {pc[k].numel()}")
         assert mism <= 20, k
+    if case == "voc_C":
+        print("GMM stats:", [st.cpu().numpy().round(3).tolist() for st in out["gmm_stats"]], "oracle hits", pc["gmm_hits"])
+        assert [int(st[:, 1].sum().item()) for st in out["gmm_stats"]] == list(pc["gmm_hits"])
     for k in watch:
         got = model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True).cpu()
         ref = leaf[k].grad
         e = float((got - ref).abs().max() / ref.abs().max())
-        print(f"full-size grad {k}: rel err {e:.2e}")
+        print(f"full-size {case} grad {k}: rel err {e:.2e}")
         assert e < 2e-3, k
