@@ -73,11 +73,14 @@ __device__ __forceinline__ void store_chunk(const float4 v, float* __restrict__ 
 }
 
 // BM = 128: wave tile 64x64 (2x2 MFMA tiles).  BM = 64: wave tile 32x64 (1x2) -- twice the blocks for small grids.
-template <bool A_MC, bool B_NC, int BM, int FAST>   // FAST: 0 guarded loader, 1 branch-free, 2 branch-free + k-range mask
+// NJ = 32-column MFMA tiles per wave along n: 2 -> 128-column block tile (default), 1 -> 64-column tile (twice the
+// blocks for N = 768 outputs on small-M grids: the data-gradient GEMMs of the training batch).
+template <bool A_MC, bool B_NC, int BM, int FAST, int NJ = 2>   // FAST: 0 guarded loader, 1 branch-free, 2 + k-range mask
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, const int g_gm) {
+    constexpr int BN = 64 * NJ;                 // shadows the 128-column default
     constexpr int MI = BM / 64;                 // 32-row MFMA tiles per wave along m
     constexpr int SA = A_MC ? (BM + 4) : (BM + 1);
-    constexpr int SB = B_NC ? 132 : 129;
+    constexpr int SB = B_NC ? (BN + 4) : (BN + 1);
     __shared__ __attribute__((aligned(16))) float smem[BK * SA + BK * SB];
     float* As = smem;
     float* Bs = smem + BK * SA;
@@ -113,11 +116,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
     const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
 
-    f32x16 acc[MI][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -134,10 +137,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
     // FAST (decided on the host, dupl_gemm_f32): every row 16-byte aligned (and K % 4 == 0 for k-contiguous
     // operands) -> branch-free clamped float4 loads with a multiplicative k-range mask; otherwise the guarded loader.
     const float* a_rd = As + wm * (BM / 2) + l31;
-    const float* b_rd = Bs + wn * 64 + l31;
+    const float* b_rd = Bs + wn * (32 * NJ) + l31;
 
     // ---- k-loop.  Staging registers are plain local float4 arrays filled by fully inlined code (no struct refs).
-    constexpr int NA = BM / 32, NB = BN / 32;   // float4 per thread per k-tile
+    constexpr int NA = BM / 32, NB = BN / 32;   // float4 per thread per k-tile (256 threads)
     float4 ra[NA], rb[NB];
     auto issue_loads = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
@@ -182,13 +185,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
         __syncthreads();
         if (t + 1 < nt) issue_loads(kbeg + (t + 1) * BK);
         // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
-        float fa[2][MI], fb[2][2];
+        float fa[2][MI], fb[2][NJ];
         {
             const int k = hf;
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[0][i] = a_rd[k * SA + 32 * i];
-            fb[0][0] = b_rd[k * SB];
-            fb[0][1] = b_rd[k * SB + 32];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[0][j] = b_rd[k * SB + 32 * j];
         }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
@@ -197,15 +200,15 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
                 const int k = 2 * (s + 1) + hf;
 #pragma unroll
                 for (int i = 0; i < MI; ++i) fa[nxt][i] = a_rd[k * SA + 32 * i];
-                fb[nxt][0] = b_rd[k * SB];
-                fb[nxt][1] = b_rd[k * SB + 32];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[nxt][j] = b_rd[k * SB + 32 * j];
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the next step's ds_reads ahead of this step's MFMAs
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][0], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][1], acc[i][1], 0, 0, 0);
-            }
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -215,8 +218,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
     const float* aux = p.aux ? p.aux + z0 * p.sX0 + z1 * p.sX1 : nullptr;
     const int fl = p.flags;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * (32 * NJ) + j * 32 + l31;
         if (col >= p.N) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
@@ -245,11 +248,18 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
 }  // namespace
 
 static int g_group_m = 16;        // row-tiles per group of the block order (dupl_set_gemm_group)
+static int g_ncols_override = 0;  // 0 = heuristic, 64 / 128 = forced column tile of the 64-row kernels (dupl_set_gemm_ncols)
 static int g_tile_override = 0;   // 0 = heuristic, 64 / 128 = forced (tuning knob, dupl_set_gemm_tile)
 
 extern "C" int dupl_set_gemm_group(int32_t gm) {
     if (gm < 1 || gm > 4096) return DUPL_ERR_ARG;
     g_group_m = gm;
+    return DUPL_OK;
+}
+
+extern "C" int dupl_set_gemm_ncols(int32_t cols) {
+    if (cols != 0 && cols != 64 && cols != 128) return DUPL_ERR_ARG;
+    g_ncols_override = cols;
     return DUPL_OK;
 }
 
@@ -264,20 +274,24 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     if (!d || !d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->zdiv <= 0)
         return DUPL_ERR_ARG;
     if ((d->flags & (DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK | DUPL_GEMM_STORE_PRE)) && !d->aux) return DUPL_ERR_ARG;
-    const int nbn = (d->N + BN - 1) / BN;
-    const long nb128 = (long)((d->M + 127) / 128) * nbn * d->batch;
-    // 256 CUs x 2 resident blocks: below ~3 full rounds of 128-row tiles the tail round dominates -> 64-row tiles
     const bool amc_ = d->flags & DUPL_GEMM_A_MCONTIG, bnc_ = d->flags & DUPL_GEMM_B_NCONTIG;
     // 64-row tiles (4 resident blocks / CU) measured >= 128-row tiles on every DuPL shape (profiles/r01_gemm_tiles.txt)
     bool small = true;
-    (void)nb128;
     if (g_tile_override) small = g_tile_override == 64;
     const int bm = small ? 64 : 128;
     const int nbm = (d->M + bm - 1) / bm;
+    const int pure = DUPL_GEMM_A_MCONTIG | DUPL_GEMM_B_NCONTIG | DUPL_GEMM_ACCUM;
+    const bool splitk_ok = (d->flags & ~pure) == 0 && (d->flags & DUPL_GEMM_ACCUM) && !d->bias && !d->res && d->alpha == 1.0f;
+    // 64-column tiles when 64 x 128 tiles leave most of the 1024 block slots empty and split-K does not apply (the
+    // N = 768 data gradients of a 3 140-token batch: 49 x 6 = 294 blocks -> 588)
+    int ncols = 128;
+    if (small && !splitk_ok && (long)nbm * ((d->N + 127) / 128) * d->batch < 640) ncols = 64;
+    if (g_ncols_override && small) ncols = g_ncols_override;
+    const bool n64 = ncols == 64;
+    const int nbn = (d->N + ncols - 1) / ncols;
     // split-K for pure accumulate GEMMs (weight gradients: tiny M x N, K = all tokens): fill >= ~4 blocks per CU
     int ksplit = 1;
-    const int pure = DUPL_GEMM_A_MCONTIG | DUPL_GEMM_B_NCONTIG | DUPL_GEMM_ACCUM;
-    if ((d->flags & ~pure) == 0 && (d->flags & DUPL_GEMM_ACCUM) && !d->bias && !d->res && d->alpha == 1.0f) {
+    if (splitk_ok) {
         const long blocks = (long)nbm * nbn * d->batch;
         if (blocks < 1024) {
             ksplit = (int)((1024 + blocks - 1) / blocks);
@@ -301,7 +315,10 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     const bool kfull = (d->K % BK) == 0;   // split-K chunks are multiples of BK, so only the global tail matters
 #define DUPL_GEMM_LAUNCH(AM, BNC)                                                                                  \
     do {                                                                                                           \
-        if (small && fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 1>), grid, block, 0, s, *d, g_group_m);  \
+        if (n64 && fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 1, 1>), grid, block, 0, s, *d, g_group_m); \
+        else if (n64 && fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 2, 1>), grid, block, 0, s, *d, g_group_m);     \
+        else if (n64) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 0, 1>), grid, block, 0, s, *d, g_group_m);             \
+        else if (small && fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 1>), grid, block, 0, s, *d, g_group_m);  \
         else if (small && fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 2>), grid, block, 0, s, *d, g_group_m);      \
         else if (small) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 0>), grid, block, 0, s, *d, g_group_m);              \
         else if (fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 1>), grid, block, 0, s, *d, g_group_m);     \

@@ -59,6 +59,8 @@ typedef struct dupl_gemm_desc {
 int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
 /* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
 int dupl_set_gemm_tile(int32_t rows);
+/* tuning knob (no reference counterpart): column tile of the 64-row GEMM kernels, 64 or 128 (0 = heuristic on the grid) */
+int dupl_set_gemm_ncols(int32_t cols);
 /* tuning knob (no reference counterpart): row-tiles per group of the block -> C-tile order inside an XCD band
  * (default 16; 4096 = plain row-major) */
 int dupl_set_gemm_group(int32_t gm);

@@ -21,9 +21,18 @@ def relerr(a, b):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+@pytest.fixture(params=[0, 64, 128], ids=["ncols-auto", "ncols-64", "ncols-128"])
+def gemm_ncols(request):
+    """Run a GEMM test with the column tile of the 64-row kernels forced to 64 / 128 and with the heuristic."""
+    from dupl_amd import ops
+    ops.L().dupl_set_gemm_ncols(request.param)
+    yield request.param
+    ops.L().dupl_set_gemm_ncols(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (257, 131, 70), (6280 // 8, 768, 768), (50, 20, 96), (300, 2304, 768)])
 @pytest.mark.parametrize("amc,bnc", [(False, False), (False, True), (True, False), (True, True)])
-def test_gemm_layouts(dev, M, N, K, amc, bnc):
+def test_gemm_layouts(dev, M, N, K, amc, bnc, gemm_ncols):
     from dupl_amd import ops, _lib
     A = rnd(M, K, seed=1)
     B = rnd(K, N, seed=2)   # logical (k, n)
@@ -37,7 +46,7 @@ def test_gemm_layouts(dev, M, N, K, amc, bnc):
     assert relerr(C, ref) < 2e-6
 
 
-def test_gemm_epilogues_and_batch(dev):
+def test_gemm_epilogues_and_batch(dev, gemm_ncols):
     from dupl_amd import ops, _lib
     M, N, K = 197, 96, 72
     x, W, b, r = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.2), rnd(N, seed=5), rnd(M, N, seed=6)
