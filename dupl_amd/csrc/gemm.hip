@@ -282,10 +282,11 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     const int nbm = (d->M + bm - 1) / bm;
     const int pure = DUPL_GEMM_A_MCONTIG | DUPL_GEMM_B_NCONTIG | DUPL_GEMM_ACCUM;
     const bool splitk_ok = (d->flags & ~pure) == 0 && (d->flags & DUPL_GEMM_ACCUM) && !d->bias && !d->res && d->alpha == 1.0f;
-    // 64-column tiles when 64 x 128 tiles leave most of the 1024 block slots empty and split-K does not apply (the
-    // N = 768 data gradients of a 3 140-token batch: 49 x 6 = 294 blocks -> 588)
+    // 64-column tiles when 64 x 128 tiles leave most of the 1024 block slots empty (the N = 768 data gradients of a
+    // 3 140-token batch: 49 x 6 = 294 blocks -> 588) and for every split-K weight gradient (half the k-splits, i.e.
+    // half the atomics, for the same number of blocks: +8..35 % measured)
     int ncols = 128;
-    if (small && !splitk_ok && (long)nbm * ((d->N + 127) / 128) * d->batch < 640) ncols = 64;
+    if (small && (splitk_ok || (long)nbm * ((d->N + 127) / 128) * d->batch < 640)) ncols = 64;
     if (g_ncols_override && small) ncols = g_ncols_override;
     const bool n64 = ncols == 64;
     const int nbn = (d->N + ncols - 1) / ncols;
