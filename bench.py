@@ -110,11 +110,15 @@ def pmc_traffic_per_launch(kernel_prefix="gemm_f32_kernel<false, false"):
     it counts L2->fabric requests, i.e. Infinity-Cache hits are included.  None if the file is absent."""
     path = os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.txt")
     try:
+        calls = fetch_kib = write_kib = 0.0
         for line in open(path):
-            if line.startswith(kernel_prefix):
+            if line.startswith(kernel_prefix):      # both column-tile instantiations (<..., 64, 1, 2> and <..., 64, 1, 1>)
                 parts = line.split()
-                calls, fetch_kib, write_kib = float(parts[-4]), float(parts[-2]), float(parts[-1])
-                return round((2.0 * fetch_kib + write_kib) * 1024.0 / calls)
+                calls += float(parts[-4])
+                fetch_kib += float(parts[-2])
+                write_kib += float(parts[-1])
+        if calls:
+            return round((2.0 * fetch_kib + write_kib) * 1024.0 / calls)
     except OSError:
         pass
     return None
@@ -237,7 +241,7 @@ def main():
         gms, gflops, gn, gbytes = timer.result()
         timer.remove()
         ach = gflops / (gms * 1e-3)
-        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<false,false> (v_mfma_f32_32x32x2_f32)", "achieved": round(ach / 1e12, 2),
+        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<false,false,64,1,*> (v_mfma_f32_32x32x2_f32; 128- and 64-column tile instantiations)", "achieved": round(ach / 1e12, 2),
                 "peak": round(PEAK_F32_MFMA / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4),
                 "traffic": pmc_traffic_per_launch(), "traffic_unit": "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, "
                 "profiles/r01_final_pmc_hbm.txt)", "algorithmic_bytes_per_launch": round(gbytes / max(gn, 1)),
