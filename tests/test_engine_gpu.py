@@ -406,3 +406,50 @@ def test_full_size_vitb_step_vs_oracle(dev, case):
         e = float((got - ref).abs().max() / ref.abs().max())
         print(f"full-size {case} grad {k}: rel err {e:.2e}")
         assert e < 2e-3, k
+
+
+@pytest.mark.parametrize("b,H,W", [(1, 96, 160), (3, 128, 96), (2, 80, 80)])
+def test_ragged_shapes_step_vs_oracle(dev, b, H, W):
+    """Shapes the reference loop never sees but its functions accept: non-square crops, odd batch sizes, a side that
+    is a multiple of 16 but not of 32 (ms-CAM scales 0.5 / 1.5 then give 40 / 120-pixel inputs = 2 / 7 patches).
+    Whole phase-B step on the tiny backbone vs the oracle: losses, CAMs, labels, a few gradients."""
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd import trainer
+    from oracle import dupl_oracle as O
+    cfg, NC = O.VIT_TINY, 21
+    pp = O.make_siamese_params(cfg, NC, seed=2)
+    S = max(H, W)
+    x, cls_label, _ = O.synthetic_batch(b, NC - 1, S, seed=61)
+    inputs = x[:, :, :H, :W].contiguous()
+    img_box = torch.tensor([[0, H, 0, W] if i % 2 == 0 else [H // 8, H - H // 8, W // 4, W - 3] for i in range(b)],
+                           dtype=torch.int16)
+    model = siamese_network("tiny_test", num_classes=NC, pretrained=False, aux_layer=-3)
+    model.load_state_dict(pp, strict=True)
+    model.to(dev)
+    model.enable_dual_stream(True)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    model.flat_storage.grad.zero_()
+    loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, 5000, trainer.StepArgs(),
+                                       cls_label_host=cls_label)
+    loss.sum().backward()
+    model.flat_storage.wait_streams()
+    torch.cuda.synchronize()
+    watch = ["branch1.encoder.blocks.0.attn.qkv.weight", "branch2.encoder.blocks.3.mlp.fc2.weight", "branch1.decoder.conv7.weight",
+             "branch2.encoder.patch_embed.proj.weight", "branch1.aux_classifier.weight"]
+    leaf = {k: v.clone().requires_grad_(k in watch) for k, v in pp.items()}
+    ref_loss, pc = O.train_step_losses(leaf, inputs, cls_label, img_box, 5000, cfg, O.StepArgs())
+    ref_loss.backward()
+    for k in ("loss", "cls_loss", "ptc_loss", "seg_loss", "sim_loss"):
+        got, ref = float(out[k].reshape(-1)[0].item()), float(pc[k].reshape(-1)[0].item())
+        assert abs(got - ref) <= 1e-4 * max(1.0, abs(ref)), (k, got, ref)
+    for k in ("cams_1", "cams_aux_2"):
+        assert float((out[k].cpu() - pc[k]).abs().max()) < 1e-4, k
+    for k in ("pseudo_label_aux_1", "pseudo_label_aux_2"):
+        assert torch.equal(out[k].cpu().long(), pc[k].long()), k
+    for k in ("refined_1", "refined_2"):
+        assert int((out[k].cpu().long() != pc[k].long()).sum()) <= 4, k
+    for k in watch:
+        got = model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True).cpu()
+        e = float((got - leaf[k].grad).abs().max() / leaf[k].grad.abs().max())
+        assert e < 2e-3, (k, e)
