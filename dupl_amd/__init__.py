@@ -5,3 +5,31 @@ step path is a hand-written HIP kernel in libdupl_hip.so reached through the C A
 include/dupl_hip.h.  There is no CPU fallback in this package.
 """
 __version__ = "0.1.0"
+
+
+def install_reference_aliases(override: bool = False):
+    """Make the reference's own import lines resolve to this package:
+
+        import dupl_amd; dupl_amd.install_reference_aliases()
+        from model.model_dupl import siamese_network          # train_final_voc.py:17-30, unchanged
+        from model.losses import get_masked_ptc_loss, get_seg_loss
+        from model.PAR import PAR
+        from utils import cam_helper, train_helper, imutils, evaluate
+
+    by registering `model`, `utils`, `datasets`, `tools` (and their sub-modules) in sys.modules as aliases of
+    dupl_amd.model, dupl_amd.utils, ...  (Putting dupl_amd/ itself on sys.path does NOT work: the modules use
+    package-relative imports.)  Existing top-level modules of those names are kept unless override=True."""
+    import importlib
+    import pkgutil
+    import sys
+
+    def alias(src: str, dst: str):
+        mod = importlib.import_module(src)
+        if override or dst not in sys.modules:
+            sys.modules[dst] = mod
+        if hasattr(mod, "__path__"):
+            for info in pkgutil.iter_modules(mod.__path__):
+                alias(f"{src}.{info.name}", f"{dst}.{info.name}")
+
+    for pkg in ("model", "utils", "datasets", "tools"):
+        alias(f"dupl_amd.{pkg}", pkg)

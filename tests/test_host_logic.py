@@ -137,3 +137,31 @@ def test_evaluate_scores_and_tables():
     m = pyutils.AverageMeter()
     m.add({"x": 1.0}); m.add({"x": 3.0})
     assert m.pop("x") == 2.0
+
+
+def test_reference_import_lines_resolve_after_alias_install():
+    """INTEGRATION.md level 1: the reference's import lines (train_final_voc.py:17-30) work unchanged after
+    dupl_amd.install_reference_aliases() and give the HIP-engine objects."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import dupl_amd
+dupl_amd.install_reference_aliases()
+from model.losses import get_masked_ptc_loss, get_seg_loss
+from model.model_dupl import siamese_network, network
+from model.PAR import PAR
+from utils import cam_helper, train_helper, imutils, evaluate
+from utils.optimizer import PolyWarmupAdamW
+from datasets import voc, coco
+from tools import eval_seg
+import dupl_amd.model.model_dupl as real
+assert siamese_network is real.siamese_network and PAR.__module__ == "dupl_amd.model.PAR"
+assert train_helper.validate_siamase.__module__ == "dupl_amd.utils.train_helper" and len(coco.class_list) == 81
+m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+assert len(m.state_dict()) == 2 * 61
+print("ALIASES_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and "ALIASES_OK" in r.stdout, r.stdout + r.stderr
