@@ -415,6 +415,25 @@ def test_seg_loss_variants(dev, h, H, flip, balanced):
     assert (cm.cpu().double() - ce).abs().max().item() < 2e-5
 
 
+def test_reference_form_seg_loss(dev):
+    """The reference's two-step form stays usable on the device: get_seg_loss(F.interpolate(segs, size), label)
+    (train_final_voc.py:345-352, losses.py:24-39) with the interpolation done by the caller (ATen), value and gradient
+    equal to the fused get_seg_loss_lowres."""
+    from dupl_amd.model import losses as LS
+    g = torch.Generator().manual_seed(9)
+    seg = torch.randn(2, 21, 8, 8, generator=g) * 3
+    lab = torch.randint(0, 21, (2, 128, 128), generator=g)
+    lab[torch.rand(2, 128, 128, generator=g) < 0.5] = 255
+    s1 = seg.clone().to(dev).requires_grad_(True)
+    up = F.interpolate(s1, size=(128, 128), mode="bilinear", align_corners=False)
+    l1 = LS.get_seg_loss(up, lab.to(dev).type(torch.long), ignore_index=255)
+    l1.backward()
+    s2 = seg.clone().to(dev).requires_grad_(True)
+    l2 = LS.get_seg_loss_lowres(s2, lab.to(dev), (128, 128), 255)
+    l2.backward()
+    assert abs(l1.item() - l2.item()) < 1e-5 and relerr(s1.grad, s2.grad) < 1e-4
+
+
 def test_seg_pseudo_label_and_mask_fill(dev):
     from dupl_amd.model import losses as LS
     g = torch.Generator().manual_seed(5)
