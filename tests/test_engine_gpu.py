@@ -1,10 +1,12 @@
 """-m gpu: the whole hot path (model API -> engine -> HIP kernels) against the golden vectors produced by
 the REAL reference (tests/golden/*.npz, written by oracle/gen_golden.py) and against the CPU oracle."""
 import os
+import types
 
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -453,3 +455,96 @@ def test_ragged_shapes_step_vs_oracle(dev, b, H, W):
         got = model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True).cpu()
         e = float((got - leaf[k].grad).abs().max() / leaf[k].grad.abs().max())
         assert e < 2e-3, (k, e)
+
+
+def test_reference_style_loop_through_aliases(dev, golden_dir):
+    """Drop-in check at the reference's own API level: the phase-B iteration written the way train_final_voc.py writes it
+    (model(inputs), cam_helper.multi_scale_cam2_siamese, cam_to_label_dynamic_cls, label_to_aff_mask +
+    get_masked_ptc_loss, refine_cams_with_dynamic_thres, F.interpolate + get_seg_loss, nn.CosineSimilarity,
+    F.multilabel_soft_margin_loss, loss.backward(), PolyWarmupAdamW.step()) with `model.*` / `utils.*` imported through
+    dupl_amd.install_reference_aliases() -- no dupl_amd.trainer involved -- against tests/golden/tiny_step_B.npz."""
+    import torch.nn as nn
+    import dupl_amd
+    dupl_amd.install_reference_aliases()
+    from model.losses import get_masked_ptc_loss, get_seg_loss
+    from model.model_dupl import siamese_network
+    from model.PAR import PAR
+    from utils import cam_helper, train_helper, imutils
+    from oracle import dupl_oracle as O
+    g = load(golden_dir, "tiny_step_B")
+    args = types.SimpleNamespace(cam_scales=(1.0, 0.5, 1.5), bkg_thre=0.5, high_thre=0.7, low_thre=0.25, ignore_index=255,
+                                 cam_iters=2000, max_iters=20000, w_ptc=0.2, w_seg=0.2, samples_per_gpu=2, optimizer="PolyWarmupAdamW",
+                                 lr=6e-5, wt_decay=1e-2, betas=(0.9, 0.999), warmup_iters=1500, warmup_lr=1e-6, power=0.9)
+    model = siamese_network(backbone="tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    model.load_state_dict(O.make_siamese_params(O.VIT_TINY, 21, seed=2), strict=True)
+    param_groups = model.get_param_groups()
+    model.to(dev)
+    optim = train_helper.get_optimizer(param_groups, args).bind(model.flat_storage)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    inputs, cls_label, img_box = (torch.from_numpy(g[k]) for k in ("inputs", "cls_label", "img_box"))
+    inputs, cls_label = inputs.to(dev), cls_label.to(dev)
+    n_iter = int(g["n_iter"])
+    high_thres_start = torch.ones(20) * args.high_thre
+    high_thres_target = torch.tensor(O.VOC_HIGH_TARGET)
+
+    optim.zero_grad()
+    inputs_denorm = imutils.denormalize_img2(inputs.clone())
+    high_thres = train_helper.cosine_descent(high_thres_start, high_thres_target, n_iter - args.cam_iters, args.max_iters - args.cam_iters)
+    b, _, h, w = inputs.shape
+    hl, hm = [], []
+    for i in range(args.samples_per_gpu):
+        t = torch.max(high_thres[torch.nonzero(cls_label[i].cpu()).squeeze(-1)])
+        hl.append(t)
+        hm.append(torch.ones((h, w), device=dev) * t)
+    high_thres = torch.stack(hl, dim=0)
+    high_thres_mask = torch.stack(hm, dim=0).unsqueeze(1)
+    cams_1, cams_aux_1 = cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=1)
+    cams_2, cams_aux_2 = cam_helper.multi_scale_cam2_siamese(model, inputs=inputs, scales=args.cam_scales, branch=2)
+    res = model(inputs)
+    cls_1, segs_1, fmap_1, cls_aux_1 = res["branch1"]
+    cls_2, segs_2, fmap_2, cls_aux_2 = res["branch2"]
+    msm = F.multilabel_soft_margin_loss
+    cls_loss = msm(cls_1, cls_label) + msm(cls_aux_1, cls_label) + msm(cls_2, cls_label) + msm(cls_aux_2, cls_label)
+    ptc_loss = 0
+    for ca, fm in ((cams_aux_1, fmap_1), (cams_aux_2, fmap_2)):
+        rc = F.interpolate(ca, size=fm.shape[2:], mode="bilinear", align_corners=False)
+        _, pl = cam_helper.cam_to_label_dynamic_cls(rc.detach(), cls_label=cls_label, img_box=img_box, ignore_mid=True,
+                                                    bkg_thre=args.bkg_thre, high_thre=high_thres, low_thre=args.low_thre,
+                                                    ignore_index=args.ignore_index)
+        ptc_loss = ptc_loss + get_masked_ptc_loss(fm, cam_helper.label_to_aff_mask(pl))
+    rep = cls_label.unsqueeze(-1).unsqueeze(-1).repeat([1, 1, h, w])
+    r1 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_1.detach() * rep, cls_labels=cls_label,
+                                                   high_thre_map=high_thres_mask, low_thre=args.low_thre,
+                                                   ignore_index=args.ignore_index, img_box=img_box)
+    r2 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_2.detach() * rep, cls_labels=cls_label,
+                                                   high_thre_map=high_thres_mask, low_thre=args.low_thre,
+                                                   ignore_index=args.ignore_index, img_box=img_box)
+    s1 = F.interpolate(segs_1, size=r1.shape[1:], mode="bilinear", align_corners=False)
+    s2 = F.interpolate(segs_2, size=r2.shape[1:], mode="bilinear", align_corners=False)
+    seg_loss = get_seg_loss(s1, r2.type(torch.long), ignore_index=args.ignore_index) + \
+        get_seg_loss(s2, r1.type(torch.long), ignore_index=args.ignore_index)
+    f1 = fmap_1.view(fmap_1.shape[0], fmap_1.shape[1], -1)
+    f2 = fmap_2.view(fmap_2.shape[0], fmap_2.shape[1], -1)
+    cs = nn.CosineSimilarity(dim=-1, eps=1e-6)
+    sim_loss = (1 + cs(f1.detach(), f2).mean()) + (1 + cs(f2.detach(), f1).mean())
+    loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + args.w_seg * seg_loss + 0.1 * sim_loss
+    loss.backward()
+    optim.step()
+    torch.cuda.synchronize()
+    for k, v in (("loss", loss), ("cls_loss", cls_loss), ("ptc_loss", ptc_loss), ("seg_loss", seg_loss), ("sim_loss", sim_loss)):
+        ref = float(np.asarray(g[k]).reshape(-1)[0])
+        print(f"reference-style loop {k}: golden {ref:.6f} got {float(v.item()):.6f}")
+        assert abs(float(v.item()) - ref) <= 2e-4 * max(1.0, abs(ref)), k
+    for k, t in (("refined_1", r1), ("refined_2", r2)):
+        assert int((t.cpu().numpy().astype(np.uint8) != g[k]).sum()) <= 2, k
+    worst = 0.0
+    for k in g.files:
+        if k.startswith("grad."):
+            name = k[5:]
+            got = model.flat_storage.view(0 if name.startswith("branch1.") else 1, name.split(".", 1)[1], grad=True).cpu().numpy()
+            ref = g[k]
+            if ref.shape != got.shape:
+                got = got.reshape(-1)[::7]
+            worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)))
+    print(f"reference-style loop: worst rel grad err {worst:.2e}")
+    assert worst < 2e-3
