@@ -165,3 +165,16 @@ print("ALIASES_OK")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
     assert r.returncode == 0 and "ALIASES_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_header_is_valid_c():
+    """include/dupl_hip.h is a plain-C header (the ABI has no C++ / torch types): gcc -std=c99 -fsyntax-only."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(root, "include", "dupl_hip.h")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr

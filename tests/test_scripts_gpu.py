@@ -188,3 +188,21 @@ print("DDP2_OK", rank)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and out.count("DDP2_OK") == 2 and out.count("DDP2_REL_ERR") == 8, out[-5000:]
+
+
+def test_c_abi_from_plain_c(dev, tmp_path):
+    """The drop-in boundary without Python or torch: tests/c/abi_smoke.c includes include/dupl_hip.h, allocates with the
+    HIP runtime, and calls dupl_fill / dupl_gemm_f32 / dupl_layernorm_fwd / dupl_colsum through the C ABI."""
+    import shutil
+    gcc = shutil.which("gcc")
+    assert gcc is not None
+    exe = str(tmp_path / "abi_smoke")
+    lib_dir = os.path.join(ROOT, "dupl_amd")
+    r = subprocess.run([gcc, "-std=c99", "-O1", os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-I", os.path.join(ROOT, "include"),
+                        "-I", "/opt/rocm/include", "-L", lib_dir, "-ldupl_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+                        f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert r.returncode == 0 and "abi_smoke:" in r.stdout, r.stdout + r.stderr
