@@ -49,6 +49,9 @@ def parse():
                     help="run the training forward's encoder pass separately from ms-CAM's identical scale-1.0 pass, exactly "
                          "like the reference does (default: computed once and shared; outputs are bit-identical)")
     ap.add_argument("--single-stream", action="store_true", help="run the two students back to back on one stream")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only exists so that the "
+                         "multi-rank control flow can be exercised by two ranks sharing one GPU in the tests)")
     return ap.parse_args()
 
 
@@ -60,8 +63,10 @@ def build_world(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("DUPL_BENCH_RANKS_SHARE_GPU0") == "1":    # test hook: every rank on device 0 (needs --backend gloo)
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=args.backend)
     else:
         torch.cuda.set_device(0)
     return world, rank, local
@@ -204,7 +209,7 @@ def main():
     def barrier():
         if world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     log(f"model on {dev}; starting {args.warmup} warm-up step(s)")

@@ -206,3 +206,21 @@ def test_c_abi_from_plain_c(dev, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(r.stdout)
     assert r.returncode == 0 and "abi_smoke:" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_multi_rank_control_flow(dev):
+    """bench.py's world_size > 1 branch end to end (process group, DDP wrapper with per-layer gradient buckets, barrier,
+    max-over-ranks timing, rank-0-only JSON with the aggregate value) with two ranks sharing cuda:0 over gloo -- the
+    RCCL run on 2/4/8 GPUs is the driver's."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DUPL_BENCH_RANKS_SHARE_GPU0="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "1", "--backend", "gloo", "--cpu-baseline", "skip"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 0.05 * d["value"] and d["cpu_baseline"] is None
