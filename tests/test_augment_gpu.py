@@ -72,6 +72,9 @@ def test_batch_matches_reference_and_oracle(dev, golden_dir):
     random.seed(123)
     out = imutils.augment_data_strong(batch.to(dev), n=5, m=10)
     assert torch.equal(out.cpu(), torch.from_numpy(g["batch_out"]))
+    # denormalize_img2 (imutils.py:17-31) on off-lattice inputs vs the reference function's own output, bit for bit
+    from dupl_amd.utils import imutils as IM
+    assert torch.equal(IM.denormalize_img2(torch.from_numpy(g["denorm_in"]).to(dev)).cpu(), torch.from_numpy(g["denorm_out"]))
     # fresh sequences at the training size, every op several times, vs the oracle (PIL on the host)
     big, _, _ = O.synthetic_batch(3, 20, 448, seed=45)
     big = O.denormalize_img2(big.clone())

@@ -203,3 +203,5 @@ def test_strong_augmentation_vs_reference(golden_dir):
     batch, _, _ = O.synthetic_batch(2, 20, 64, seed=44)
     random.seed(123)
     assert torch.equal(O.augment_data_strong(O.denormalize_img2(batch.clone()), n=5, m=10), torch.from_numpy(d["batch_out"]))
+    # denormalize_img2 against the reference function itself (executed from /root/reference at generation time)
+    assert torch.equal(O.denormalize_img2(torch.from_numpy(d["denorm_in"])), torch.from_numpy(d["denorm_out"]))
