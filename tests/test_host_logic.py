@@ -178,3 +178,14 @@ def test_header_is_valid_c():
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(root, "include", "dupl_hip.h")],
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
+
+
+def test_cosine_descent_and_high_thresholds_vs_reference(golden_dir):
+    """utils.train_helper.cosine_descent and trainer.per_image_high_thres (train_final_voc.py:263-275) against the
+    reference function's outputs stored in aug_strong.npz."""
+    from dupl_amd.utils.train_helper import cosine_descent
+    d = np.load(os.path.join(golden_dir, "aug_strong.npz"))
+    hi, lo = np.ones(20, dtype=np.float32) * np.float32(0.7), np.asarray(O.VOC_HIGH_TARGET, dtype=np.float32)
+    for s, ref in zip(d["cosine_steps"], d["cosine_out"]):
+        got = np.asarray(cosine_descent(hi, lo, int(s), 18000), dtype=np.float32)
+        assert np.abs(got - ref).max() < 1e-7, int(s)

@@ -203,5 +203,9 @@ def test_strong_augmentation_vs_reference(golden_dir):
     batch, _, _ = O.synthetic_batch(2, 20, 64, seed=44)
     random.seed(123)
     assert torch.equal(O.augment_data_strong(O.denormalize_img2(batch.clone()), n=5, m=10), torch.from_numpy(d["batch_out"]))
+    # cosine_descent (train_helper.py:340-349) against the reference function's outputs
+    hi, lo = torch.ones(20) * 0.7, torch.tensor(O.VOC_HIGH_TARGET)
+    for s, ref in zip(d["cosine_steps"], d["cosine_out"]):
+        assert torch.equal(torch.as_tensor(O.cosine_descent(hi, lo, int(s), 18000)).float(), torch.from_numpy(ref))
     # denormalize_img2 against the reference function itself (executed from /root/reference at generation time)
     assert torch.equal(O.denormalize_img2(torch.from_numpy(d["denorm_in"])), torch.from_numpy(d["denorm_out"]))
