@@ -6,7 +6,9 @@ torchvision, joblib are absent), so -- as oracle/gen_golden.py does for the trai
 pieces (siamese_network.forward, cam_helper.multi_scale_cam2_siamese, cam_helper.cam_to_label, utils.evaluate.scores /
 multilabel_score; F.interpolate / argmax) are composed exactly as validate_siamase (train_helper.py:90-185) and
 eval_seg_voc._validate (tools/eval_seg_voc.py:38-91) compose them, and the oracle's restatement is asserted equal.
-Writes tests/golden/val_tiny.npz (data only)."""
+In addition the reference's validate_siamase FUNCTION ITSELF is extracted from utils/train_helper.py with `ast` and
+executed as it stands (presentation-only names bound to inert stand-ins, see below); its return values must equal the
+composition's.  Writes tests/golden/val_tiny.npz (data only)."""
 from __future__ import annotations
 
 import os
@@ -144,12 +146,64 @@ def main():
     coco_hist = {k: sum(EV._fast_hist(lt.flatten(), lp.flatten(), NC) for lt, lp in zip(gts, coco_pred[k])) for k in (1, 2)}
     print("eval_seg_coco: oracle == reference composition; mIoU", {k: round(float(coco_scores[k]['miou']), 4) for k in (1, 2)})
 
+    # ---- the reference's validate_siamase ITSELF (utils/train_helper.py:90-185), extracted with `ast` and executed as it
+    # stands: the module cannot be imported (texttable / imageio / torchvision), so its names are bound here to the
+    # reference's own objects where they exist (cam_helper, evaluate, AverageMeter and format_tabs also ast-extracted from
+    # utils/pyutils.py) and to inert stand-ins where they are presentation only (tqdm = identity, Texttable = a row
+    # collector whose draw() returns text; Tensor.cuda = identity since this container has no GPU)
+    import ast
+    import types as _types
+    th_src = open(os.path.join(REF, "utils", "train_helper.py")).read()
+    pu_src = open(os.path.join(REF, "utils", "pyutils.py")).read()
+
+    class Texttable:
+        def __init__(self):
+            self.rows = []
+
+        def header(self, h):
+            self.rows.append(list(h))
+
+        def add_row(self, r):
+            self.rows.append(list(r))
+
+        def draw(self):
+            return "\n".join(" | ".join(str(c) for c in r) for r in self.rows)
+
+    ns = {"torch": torch, "np": np, "F": F, "evaluate": EV, "cam_helper": CH, "tqdm": lambda it, **k: it, "Texttable": Texttable,
+          "voc": _types.SimpleNamespace(class_list=[f"c{i}" for i in range(NC)])}
+    for node in ast.parse(pu_src).body:
+        if (isinstance(node, ast.ClassDef) and node.name == "AverageMeter") or (isinstance(node, ast.FunctionDef) and node.name == "format_tabs"):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "ref_pyutils", "exec"), ns)
+    for node in ast.parse(th_src).body:
+        if isinstance(node, ast.FunctionDef) and node.name == "validate_siamase":
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "ref_train_helper", "exec"), ns)
+    vargs = _types.SimpleNamespace(crop_size=crop, cam_scales=args.cam_scales, bkg_thre=args.bkg_thre, high_thre=args.high_thre,
+                                   low_thre=args.low_thre, ignore_index=args.ignore_index)
+    loader = [((f"img{i}",), x, lab, cls) for i, (x, lab, cls) in enumerate(samples)]
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r_c1, r_c2, r_tab, r_items = ns["validate_siamase"](model=sia, data_loader=loader, args=vargs, return_item=True)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    sia.eval()
+    assert abs(r_c1 - cls_score[0]) < 1e-12 and abs(r_c2 - cls_score[1]) < 1e-12
+    mine_items = [float(np.mean(np.array(list(ref_scores[n]["iou"].values())) * 100)) for n in names]
+    assert np.allclose(np.array(r_items, dtype=np.float64), np.array(mine_items), equal_nan=True), (r_items, mine_items)
+    print("validate_siamase (the reference function itself, ast-extracted) == the composition above: cls", r_c1, r_c2,
+          "items", [round(float(v), 4) for v in r_items])
+    ref_items = np.array(r_items, dtype=np.float64)
+
     def iou_arr(s):
         return np.array(list(s["iou"].values()), dtype=np.float64)
 
     arrays = dict(crop_size=crop, scales=np.array(scales), cls_scores=np.array(cls_score),
                   msc_miou=np.array([seg_scores[1]["miou"], seg_scores[2]["miou"]]),
                   msc_iou_1=iou_arr(seg_scores[1]), msc_iou_2=iou_arr(seg_scores[2]))
+    arrays["validate_items"] = ref_items
     arrays["coco_scales"], arrays["coco_size"] = np.array(coco_scales), csize
     arrays["coco_miou"] = np.array([coco_scores[1]["miou"], coco_scores[2]["miou"]])
     for k in (1, 2):

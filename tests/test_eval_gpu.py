@@ -116,7 +116,8 @@ def test_validate_siamase_matches_reference(dev, golden_dir, dual):
         print(f"{n}: confusion-matrix L1 difference {diff} of {int(ref.sum())} px")
         assert captured[i].sum() == ref.sum()
         assert diff <= 2 * ties[n] + 4, n     # every differing pixel moves one count between two bins
-        ref_item = float(np.mean(g[f"iou.{n}"] * 100))
+        ref_item = float(g["validate_items"][i])         # return value of the reference's validate_siamase itself
+        assert np.isclose(ref_item, float(np.mean(g[f"iou.{n}"] * 100)), equal_nan=True)
         if np.isnan(ref_item):
             assert np.isnan(items[i])
         else:

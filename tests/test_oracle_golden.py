@@ -169,6 +169,8 @@ def test_validation_and_msc_seg_vs_reference(golden_dir):
         assert abs(o["scores"][n]["miou"] - float(g[f"miou.{n}"])) < 1e-3
         for i, m in enumerate(o["maps"][n]):
             assert int((m.astype(np.uint8) != g[f"map.{n}.{i}"]).sum()) <= 2, (n, i)
+    items = [float(np.mean(np.array(list(o["scores"][n]["iou"].values())) * 100)) for n in ("CAM_1", "aux_CAM_1", "Seg_1", "CAM_2", "aux_CAM_2", "Seg_2")]
+    assert np.allclose(items, g["validate_items"], atol=0.05, equal_nan=True)      # the reference function's own return value
     scales = tuple(float(s) for s in g["scales"])
     x, lab, _ = samples[0]
     for k in (1, 2):
