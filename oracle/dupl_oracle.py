@@ -5,9 +5,12 @@ named by BASELINE.json:north_star.  It is the
 HIP kernels are compared with; nothing under ``dupl_amd/`` may import it.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` use it.
 
-Parity status: PINNED.  ``oracle/gen_golden.py`` imports the real reference from /root/reference
-(with a timm shim) in the authoring container, loads identical hash-generated weights into both and
-checks every function below against it; it then writes the fixtures in ``tests/golden/`` which
+Parity status: PINNED.  ``oracle/gen_golden.py`` (training step, VOC phases A/B/C), ``gen_golden_coco.py`` (COCO
+schedule), ``gen_golden_val.py`` (validation, mIoU, multi-scale seg inference) and ``gen_golden_aug.py`` (RandAugment,
+denormalisation, threshold schedule) import the real reference from /root/reference (with a timm shim) in the authoring
+container, load identical hash-generated weights into both and check every function below against it; reference
+functions whose modules cannot be imported there (torchvision / texttable at module top) are extracted with ``ast`` and
+executed as they stand.  The generators then write the fixtures in ``tests/golden/`` which
 ``tests/test_oracle_golden.py`` replays on any machine.
 
 All citations are relative to /root/reference.  The code is written functionally over a flat
