@@ -189,3 +189,20 @@ def test_cosine_descent_and_high_thresholds_vs_reference(golden_dir):
     for s, ref in zip(d["cosine_steps"], d["cosine_out"]):
         got = np.asarray(cosine_descent(hi, lo, int(s), 18000), dtype=np.float32)
         assert np.abs(got - ref).max() < 1e-7, int(s)
+
+
+def test_pretrained_from_local_checkpoint(tmp_path):
+    """deit.py:97-109 loads {"model": timm state_dict} from a URL; here the same file format is read from a local path
+    (no network): both students' encoders take the weights, heads keep their init, pretrained=True raises."""
+    from dupl_amd.model.model_dupl import siamese_network
+    sp = O.make_student_params(O.VIT_TINY, 21, seed=9)
+    enc = {k[len("encoder."):]: v for k, v in sp.items() if k.startswith("encoder.")}
+    path = str(tmp_path / "deit_tiny.pth")
+    torch.save({"model": enc}, path)
+    m = siamese_network("tiny_test", num_classes=21, pretrained=path, aux_layer=-3)
+    sd = m.state_dict()
+    for k, v in enc.items():
+        assert torch.equal(sd["branch1.encoder." + k], v) and torch.equal(sd["branch2.encoder." + k], v), k
+    assert not torch.equal(sd["branch1.classifier.weight"], sp["classifier.weight"])
+    with pytest.raises(RuntimeError):
+        siamese_network("tiny_test", num_classes=21, pretrained=True, aux_layer=-3)
