@@ -3,15 +3,18 @@
 // Why f32-input MFMA: the parity bar is CAM max-abs-diff < 1e-3 *and identical label
 // maps*; the f32 MFMA is bit-for-bit an fmaf chain, runs at the f32 vector peak (157 TF/s) and
 // leaves the VALU free for the fused epilogues.  The kernel is MFMA-bound by construction: per
-// k-step of 2 a wave issues 4 MFMAs (4 x 64 cycles) against 4 ds_read_b32.
+// k-step of 2 a wave issues MI x NJ MFMAs (64 cycles each) against MI + NJ ds_read_b32.
 //
-// Block = 256 threads = 4 waves (2 x 2), tile 128 x 128 x 32, each wave 64 x 64 = 2 x 2 MFMA tiles
-// (64 accumulator VGPRs).  Both operand tiles live in LDS k-major ([k][m], [k][n]) so the MFMA
-// fragment reads (lane -> consecutive m / n) are bank-conflict free; the global->LDS stage goes
-// through registers (prefetch of tile t+1 overlaps the MFMAs of tile t) and transposes on the LDS
-// write when the operand is k-contiguous in memory (row stride 129: conflict-free scatter).
-// Grid: one block per output tile, remapped so that each XCD (private L2) owns a contiguous band of
-// row-tiles; blockIdx.y = batch.
+// Block = 256 threads = 4 waves (2 x 2).  Tile instantiations (BM x 64*NJ x 32):
+//   64 x 128  default: wave tile 32 x 64 (1 x 2 MFMA tiles), 4 resident blocks / CU;
+//   64 x  64  small grids and every split-K weight gradient: wave tile 32 x 32, twice the blocks;
+//  128 x 128  wave tile 64 x 64 (2 x 2), kept for the tuning knob (measured slower on the DuPL shapes).
+// Both operand tiles live in LDS k-major ([k][m], [k][n]) so the MFMA fragment reads (lane -> consecutive m / n) are
+// bank-conflict free; the global->LDS stage goes through registers (prefetch of tile t+1 overlaps the MFMAs of tile t)
+// and transposes on the LDS write when the operand is k-contiguous in memory (odd row stride: conflict-free scatter).
+// Grid: one block per output tile; XCD x (private L2) owns a contiguous band of tiles, ordered inside the band in groups
+// of 16 row-tiles x all column tiles (row-tile fastest); blockIdx.y = batch, blockIdx.z = k-split of pure accumulate
+// GEMMs (weight gradients), combined with f32 atomics.
 #include <type_traits>
 
 #include "common.h"
