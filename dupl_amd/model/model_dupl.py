@@ -10,7 +10,8 @@ reference's training loop drives it unchanged.  What differs is underneath:
 * forward/backward are explicit HIP kernel schedules (engine.network_forward / network_backward);
   autograd sees one node per student forward, whose backward accumulates parameter gradients
   directly into the flat gradient buffer (they are not returned through autograd);
-* `cam_with_grad` (model_dupl.py:100-104) is not on the path (no script calls it) and raises.
+* `cam_with_grad` (model_dupl.py:100-104): the CAM logits of the detached classifier are a batched HIP GEMM on the
+  x4 output of the student's autograd node (`_CamGradFn`), so their gradient reaches the encoder through `dx4`.
 * need_sp: the reference first runs both students on the full 2b batch and discards the result
   (model_dupl.py:191-192); that dead forward is skipped here -- outputs are identical.
 """
@@ -23,7 +24,7 @@ import torch.nn as nn
 
 from .. import engine, ops
 from ..engine import EncoderConfig, FlatStorage, StudentParams
-from .backbone import encoder_config
+from .backbone import encoder_config, load_pretrained_encoder
 from .decoder.conv_head import LargeFOV
 
 
@@ -74,6 +75,33 @@ class _NetworkFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class _CamGradFn(torch.autograd.Function):
+    """F.conv2d(x4, classifier.weight.detach()) of model_dupl.py:101 as a batched MFMA GEMM on NCHW operands:
+    cam[b] (C x hw) = W (C x D) . x4[b] (D x hw); backward dx4[b] = W^T . dcam[b] (the weight is detached: no dW)."""
+
+    @staticmethod
+    def forward(ctx, x4, W):
+        B, D, h, w = x4.shape
+        C = W.shape[0]
+        x4 = x4.contiguous()
+        cam = torch.empty((B, C, h, w), device=x4.device, dtype=torch.float32)
+        ops.gemm_raw(W.data_ptr(), x4.data_ptr(), cam.data_ptr(), C, h * w, D, D, h * w, h * w,
+                     flags=ops._lib.GEMM_B_NCONTIG, batch=B, sB=(D * h * w, 0), sC=(C * h * w, 0))
+        ctx.save_for_backward(W)
+        ctx.dims = (B, D, h, w, C)
+        return cam
+
+    @staticmethod
+    def backward(ctx, dcam):
+        (W,) = ctx.saved_tensors
+        B, D, h, w, C = ctx.dims
+        dcam = dcam.contiguous()
+        dx4 = torch.empty((B, D, h, w), device=dcam.device, dtype=torch.float32)
+        ops.gemm_raw(W.data_ptr(), dcam.data_ptr(), dx4.data_ptr(), D, h * w, C, D, h * w, h * w,
+                     flags=ops._lib.GEMM_A_MCONTIG | ops._lib.GEMM_B_NCONTIG, batch=B, sB=(C * h * w, 0), sC=(D * h * w, 0))
+        return dx4, None
+
+
 class network(nn.Module):
     def __init__(self, backbone, num_classes=None, pretrained=None, aux_layer=None, add_mlp=False,
                  _store: Optional[FlatStorage] = None, _student: int = 0):
@@ -97,8 +125,7 @@ class network(nn.Module):
             self._rebind()
         self.in_channels = [cfg.embed_dim] * 4
         if pretrained and not isinstance(pretrained, bool):
-            sd = torch.load(pretrained, map_location="cpu")
-            self.load_state_dict(sd.get("model", sd), strict=False)
+            load_pretrained_encoder(self.encoder, pretrained, cfg.patch)
         elif pretrained:
             raise RuntimeError("pretrained=True needs network access (torch.hub / timm URLs in the reference); pass a "
                                "local state_dict path or pretrained=False")
@@ -148,10 +175,14 @@ class network(nn.Module):
         self._P._pos_version = None
 
     def _apply(self, fn, recurse=True):
-        if self._owns_store:
-            self._store.apply(fn)
-            assert self._store.data.dtype == torch.float32, "dupl_amd is an fp32-storage engine"
-            self._rebind()
+        if not self._owns_store:
+            # a student of a siamese_network is a view into the pair's flat buffer: moving / casting one student alone
+            # would silently do nothing -- refuse instead
+            raise RuntimeError("this student's parameters live in its siamese_network's flat storage: call "
+                               ".to() / .cuda() / .float() on the siamese_network, not on branch1 / branch2")
+        self._store.apply(fn)
+        assert self._store.data.dtype == torch.float32, "dupl_amd is an fp32-storage engine"
+        self._rebind()
         return self
 
     # ---- reference API ------------------------------------------------------------------------
@@ -190,13 +221,21 @@ class network(nn.Module):
             cam = ops.tokens_to_nchw(cam_t, B, h * w, C, h, w, skip_cls=True)
             cam_aux = ops.tokens_to_nchw(cam_aux_t, B, h * w, C, h, w, skip_cls=True)
             return cam_aux, cam
-        if cam_with_grad:
-            raise NotImplementedError("cam_with_grad (model_dupl.py:100-104) is not used by any training script")
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in (self.classifier.weight,))
         if need_grad:
-            return _NetworkFn.apply(self._anchor_for(x.device), x, self)
-        outs, _ = engine.network_forward(self._P, x, save=False)
-        return outs
+            outs = _NetworkFn.apply(self._anchor_for(x.device), x, self)
+        else:
+            outs, _ = engine.network_forward(self._P, x, save=False)
+        if val or not cam_with_grad:
+            return outs
+        # model_dupl.py:100-104: CAM of the DETACHED classifier on x4, min-shifted and max-normalised; note the
+        # reference's operator precedence: (cam / max) + 1e-5
+        cls_x4, seg, x4, cls_aux = outs
+        C = self.num_classes - 1
+        cam_grad = _CamGradFn.apply(x4, self.classifier.weight.detach().view(C, -1))
+        cam_grad = cam_grad - cam_grad.amin(dim=(2, 3), keepdim=True)
+        cam_grad = cam_grad / cam_grad.amax(dim=(2, 3), keepdim=True) + 1e-5
+        return cls_x4, seg, x4, cls_aux, cam_grad
 
 
 def _trunc_normal_(t: torch.Tensor, std: float):
@@ -241,10 +280,8 @@ class siamese_network(nn.Module):
             _reference_init(self._store, s)
         self._rebind()
         if pretrained and not isinstance(pretrained, bool):
-            sd = torch.load(pretrained, map_location="cpu")
-            sd = sd.get("model", sd)
-            self.branch1.encoder.load_state_dict(sd, strict=False)
-            self.branch2.encoder.load_state_dict(sd, strict=False)
+            load_pretrained_encoder(self.branch1.encoder, pretrained, cfg.patch)
+            load_pretrained_encoder(self.branch2.encoder, pretrained, cfg.patch)
         elif pretrained:
             raise RuntimeError("pretrained=True needs network access; pass a local state_dict path or pretrained=False")
 
@@ -356,7 +393,11 @@ class siamese_network(nn.Module):
                 return cam_aux_1, cam_1, cam_aux_2, cam_2
             return self.branch1(x, cam_only=cam_only) if branch == 1 else self.branch2(x, cam_only=cam_only)
         if cam_with_grad:
-            raise NotImplementedError("cam_with_grad (model_dupl.py:171-179) is not used by any training script")
+            if branch is None:
+                res["branch1"], res["branch2"] = self.per_student(lambda: self.branch1(x, cam_with_grad=True),
+                                                                  lambda: self.branch2(x, cam_with_grad=True))
+                return res
+            return self.branch1(x, cam_with_grad=True) if branch == 1 else self.branch2(x, cam_with_grad=True)
         if branch is None:
             if need_sp:
                 x, x_aug = x.chunk(2)

@@ -382,9 +382,14 @@ def par_forward(imgs: Tensor, masks: Tensor, dilations=PAR_DILATIONS, num_iter: 
 # ----------------------------------------------------------------------------------------------
 def refine_cams(images: Tensor, cams: Tensor, cls_labels: Tensor, high_thre, low_thre: float,
                 ignore_index: int, img_box, down_scale: int = 2,
-                dilations=PAR_DILATIONS, num_iter: int = 10) -> Tensor:
+                dilations=PAR_DILATIONS, num_iter: int = 10, return_margin: bool = False):
     """refine_cams_with_bkg_v2 (scalar high_thre) / refine_cams_with_dynamic_thres (high_thre a
-    (b,1,h,w) map), cam_helper.py:338-440 -> (b,h,w) float32 labels in {0..C, 255}."""
+    (b,1,h,w) map), cam_helper.py:338-440 -> (b,h,w) float32 labels in {0..C, 255}.
+    return_margin: also return the per-pixel decision margin (b,h,w): the top-1 minus top-2 value of the propagated,
+    upsampled mask stack behind the label (the high-threshold stack; where that one says background, the smaller of
+    the high- and low-threshold margins, since the merge consults both).  +inf outside the box or with a single key.
+    A label map that differs from this one ONLY at pixels whose margin is at fp32 round-off level is the same
+    argmax up to ties (tests/parity_util.py)."""
     b, _, h, w = images.shape
     hs, ws = h // down_scale, w // down_scale
     _images = F.interpolate(images, size=[hs, ws], mode="bilinear", align_corners=False)
@@ -396,26 +401,37 @@ def refine_cams(images: Tensor, cams: Tensor, cls_labels: Tensor, high_thre, low
     cl = torch.cat((torch.ones(b, 1), cls_labels), dim=1)
     lab_h = torch.ones(b, h, w) * ignore_index
     lab_l = lab_h.clone()
+    mar_h = torch.full((b, h, w), float("inf"))
+    mar_l = mar_h.clone()
     ch = F.interpolate(torch.cat((bkg_h, cams), dim=1), size=[hs, ws], mode="bilinear", align_corners=False)
     cl_ = F.interpolate(torch.cat((bkg_l, cams), dim=1), size=[hs, ws], mode="bilinear", align_corners=False)
 
     def one(img, m, keys):
         r = par_forward(img, m, dilations, num_iter)
         r = F.interpolate(r, size=(h, w), mode="bilinear", align_corners=False)
-        return keys[r.argmax(dim=1)]
+        if r.shape[1] > 1:
+            t2 = r.topk(2, dim=1).values
+            mar = t2[:, 0] - t2[:, 1]
+        else:
+            mar = torch.full_like(r[:, 0], float("inf"))
+        return keys[r.argmax(dim=1)], mar
 
     for i, bx in enumerate(img_box):
         y0, y1, x0, x1 = (int(v) for v in bx)
         keys = torch.nonzero(cl[i])[:, 0]
         vh = ch[i, keys].unsqueeze(0).softmax(dim=1)
         vl = cl_[i, keys].unsqueeze(0).softmax(dim=1)
-        rh = one(_images[[i]], vh, keys)
-        rl = one(_images[[i]], vl, keys)
+        rh, mh = one(_images[[i]], vh, keys)
+        rl, ml = one(_images[[i]], vl, keys)
         lab_h[i, y0:y1, x0:x1] = rh[0, y0:y1, x0:x1].float()
         lab_l[i, y0:y1, x0:x1] = rl[0, y0:y1, x0:x1].float()
+        mar_h[i, y0:y1, x0:x1] = mh[0, y0:y1, x0:x1]
+        mar_l[i, y0:y1, x0:x1] = ml[0, y0:y1, x0:x1]
     out = lab_h.clone()
     out[lab_h == 0] = ignore_index
     out[(lab_h + lab_l) == 0] = 0
+    if return_margin:
+        return out, torch.where(lab_h == 0, torch.minimum(mar_h, mar_l), mar_h)
     return out
 
 
@@ -607,11 +623,18 @@ def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tens
         rep = cls_label[:, :, None, None]
         if coco and n_iter <= args.coco_switch_iter:
             # train_final_coco.py:312-322: refine_cams_with_bkg_v2 (scalar high threshold) on the AUX CAMs
-            r1 = refine_cams(inputs_denorm, cams_aux_1 * rep, cls_label, args.high_thre, args.low_thre, args.ignore_index, img_box)
-            r2 = refine_cams(inputs_denorm, cams_aux_2 * rep, cls_label, args.high_thre, args.low_thre, args.ignore_index, img_box)
+            r1, m1 = refine_cams(inputs_denorm, cams_aux_1 * rep, cls_label, args.high_thre, args.low_thre, args.ignore_index,
+                                 img_box, return_margin=True)
+            r2, m2 = refine_cams(inputs_denorm, cams_aux_2 * rep, cls_label, args.high_thre, args.low_thre, args.ignore_index,
+                                 img_box, return_margin=True)
         else:
-            r1 = refine_cams(inputs_denorm, cams_1 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box)
-            r2 = refine_cams(inputs_denorm, cams_2 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box)
+            r1, m1 = refine_cams(inputs_denorm, cams_1 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box,
+                                 return_margin=True)
+            r2, m2 = refine_cams(inputs_denorm, cams_2 * rep, cls_label, hmap, args.low_thre, args.ignore_index, img_box,
+                                 return_margin=True)
+        # decision margins of the refined maps (test infrastructure: tie proofs, tests/parity_util.py); taken before the
+        # phase-C noise filter rewrites r1 / r2 in place
+        pieces["refined_margin_1"], pieces["refined_margin_2"] = m1, m2
         s1 = F.interpolate(segs_1, size=(h, w), mode="bilinear", align_corners=False)
         s2 = F.interpolate(segs_2, size=(h, w), mode="bilinear", align_corners=False)
         if n_iter < args.gmm_iters:
@@ -646,6 +669,11 @@ def train_step_losses(params: Dict[str, Tensor], inputs: Tensor, cls_label: Tens
                 reg_2 = F.cross_entropy(sa2, ps2, ignore_index=args.ignore_index, reduction="none").sum() / un2.sum()
             reg = reg_1 + reg_2
             pieces["pseudo_seg_1"], pieces["pseudo_seg_2"] = ps1, ps2
+            # decision margins behind pseudo_seg_k: top-2 gap of the upsampled logits, distance of the confidence from
+            # the 0.9 gate; the other student's refined-map margin gates the "uncertain" region (tests/parity_util.py)
+            t1, t2 = s1.detach().topk(2, dim=1).values, s2.detach().topk(2, dim=1).values
+            pieces["pseudo_seg_margin_1"] = torch.minimum(torch.minimum(t1[:, 0] - t1[:, 1], (cf1 - 0.9).abs()), m2)
+            pieces["pseudo_seg_margin_2"] = torch.minimum(torch.minimum(t2[:, 0] - t2[:, 1], (cf2 - 0.9).abs()), m1)
             pieces["n_uncertain"] = (int(un1.sum()), int(un2.sum()))
         pieces["refined_1"], pieces["refined_2"] = r1, r2
     sim = sim_loss(fmap_1, fmap_2)

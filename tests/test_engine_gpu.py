@@ -8,6 +8,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from parity_util import assert_labels_equal_up_to_ties
+
 pytestmark = pytest.mark.gpu
 
 TOL_FWD = 2e-4   # relative to the tensor's max-abs; fp32 MFMA path vs ATen CPU fp32 (different summation orders)
@@ -87,10 +89,11 @@ def test_tiny_train_step_matches_reference(dev, golden_dir, tag, dual):
         d = np.abs(out[k][:, ::4].cpu().numpy() - g[k]).max()
         assert d < 2e-5, (k, d)
     if tag == "B":
+        # refined label maps == the reference's, except at proven argmax ties (oracle decision margin < 1e-5)
+        _, pc = O.train_step_losses(O.make_siamese_params(O.VIT_TINY, 21, seed=2), inputs, cls_label, img_box,
+                                    int(g["n_iter"]), O.VIT_TINY, O.StepArgs())
         for k in ("refined_1", "refined_2"):
-            mism = int((out[k].cpu().numpy().astype(np.uint8) != g[k]).sum())
-            print(f"{k}: {mism} label mismatches of {g[k].size}")
-            assert mism <= 2, k
+            assert_labels_equal_up_to_ties(out[k], g[k].astype(np.int64), pc["refined_margin_" + k[-1]], f"phase B {k}")
     worst, nchk = 0.0, 0
     sd_grad = {k: model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True)
                for k in model.state_dict().keys()}
@@ -113,6 +116,54 @@ def test_tiny_train_step_matches_reference(dev, golden_dir, tag, dual):
     for name, t in sd_grad.items():
         if ("grad." + name) not in g.files:
             assert float(t.abs().max().item()) == 0.0, name
+
+
+def test_cam_with_grad_matches_reference(dev, golden_dir):
+    """forward(x, cam_with_grad=True) (model_dupl.py:100-104,171-179) vs the reference's own outputs and gradients
+    (tests/golden/tiny_camgrad.npz, oracle/gen_golden_camgrad.py): five outputs per student, the gradient of the
+    normalised detached-classifier CAM reaches the encoder through x4; branch=1 and single-`network` routes."""
+    from dupl_amd.model.model_dupl import siamese_network
+    from oracle import dupl_oracle as O
+    g = load(golden_dir, "tiny_camgrad")
+    NC = 21
+    model = siamese_network("tiny_test", num_classes=NC, pretrained=False, aux_layer=-3)
+    model.load_state_dict(O.make_siamese_params(O.VIT_TINY, NC, seed=6), strict=True)
+    model.to(dev)
+    model.enable_dual_stream(True)
+    x = torch.from_numpy(g["x"]).to(dev)
+    h = x.shape[2] // 16
+    shapes = ((2, NC - 1), (2, NC, h, h), (2, 96, h, h), (2, NC - 1), (2, NC - 1, h, h))
+    R = [O.hash_normal(f"camgrad_r{i}", shp, seed=22).to(dev) for i, shp in enumerate(shapes)]
+    model.flat_storage.grad.zero_()
+    res = model(x, cam_with_grad=True)
+    assert len(res["branch1"]) == 5 and len(res["branch2"]) == 5
+    for i, o in enumerate(res["branch1"]):
+        e = relerr(o, g[f"out{i}"])
+        print(f"cam_with_grad out{i}: rel err {e:.2e}")
+        assert e < TOL_FWD, i
+    assert relerr(res["branch2"][4], g["cam_grad_2"]) < TOL_FWD
+    total = sum((o * r).sum() for o, r in zip(res["branch1"], R)) + (res["branch2"][4] * R[4]).sum()
+    total.backward()
+    model.flat_storage.wait_streams()
+    torch.cuda.synchronize()
+    assert abs(total.item() - float(g["total"])) <= 1e-4 * abs(float(g["total"]))
+    worst, nchk = 0.0, 0
+    for k in g.files:
+        if not k.startswith("grad."):
+            continue
+        name = k[5:]
+        got = model.flat_storage.view(0 if name.startswith("branch1.") else 1, name.split(".", 1)[1], grad=True).cpu().numpy()
+        ref = g[k]
+        if ref.shape != got.shape:
+            got = got.reshape(-1)[::7]
+        worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)))
+        nchk += 1
+    print(f"cam_with_grad: {nchk} gradient tensors, worst rel err {worst:.2e}")
+    assert nchk >= 100 and worst < 2e-3
+    with torch.no_grad():
+        r1 = model(x, cam_with_grad=True, branch=1)
+        assert len(r1) == 5 and relerr(r1[4], g["out4"]) < TOL_FWD
+        assert len(model.branch2(x, cam_with_grad=True, val=True)) == 4      # val wins over cam_with_grad (:97-98)
 
 
 def test_vitb_forward_matches_reference(dev, golden_dir):
@@ -217,10 +268,9 @@ def test_coco_schedule_step_matches_reference(dev, golden_dir, tag):
     if tag != "A":
         for k in ("pseudo_label_aux_1", "pseudo_label_aux_2"):
             assert np.array_equal(out[k].cpu().numpy().astype(np.uint8), g[k]), k
+        _, pc = O.train_step_losses(pp, inputs, cls_label, img_box, int(g["n_iter"]), O.VIT_TINY, O.coco_step_args())
         for k in ("refined_1", "refined_2"):
-            mism = int((out[k].cpu().numpy().astype(np.uint8) != g[k]).sum())
-            print(f"coco {tag} {k}: {mism} label mismatches of {g[k].size}")
-            assert mism <= 2, k
+            assert_labels_equal_up_to_ties(out[k], g[k].astype(np.int64), pc["refined_margin_" + k[-1]], f"coco {tag} {k}")
     worst, nchk = 0.0, 0
     for k in g.files:
         name = k.split(".", 1)[1] if "." in k else k
@@ -272,12 +322,22 @@ def test_tiny_phase_c_matches_reference(dev, golden_dir, fused):
     hits = [int(st[:, 1].sum().item()) for st in out["gmm_stats"]]
     print("device GMM stats:", [st.cpu().numpy().round(4).tolist() for st in out["gmm_stats"]])
     assert hits == list(g["gmm_hits"]) == [1, 1]
-    for k in ("refined_1", "refined_2", "pseudo_seg_1", "pseudo_seg_2"):
-        mism = int((out[k].cpu().numpy().astype(np.uint8) != g[k]).sum())
-        print(f"{k}: {mism} mismatches of {g[k].size}")
-        assert mism <= 6, k     # argmax / threshold near-ties only
+    # label maps == the reference's except at proven ties: refined maps by the PAR decision margin, pseudo-seg maps by the
+    # logit top-2 gap / the distance of the confidence from the 0.9 gate / the gating refined map's margin
+    import random
+    random.seed(0)
+    _, pc = O.train_step_losses(pp, inputs, cls_label, img_box, int(g["n_iter"]), O.VIT_TINY, O.StepArgs(), inputs_aug=aug)
+    nmis = {}
+    for k in ("refined_1", "refined_2"):
+        # compare BEFORE the noise filter's relabelling is irrelevant: the filter rewrites whole-class regions identically
+        nmis[k], _ = assert_labels_equal_up_to_ties(out[k], g[k].astype(np.int64), pc["refined_margin_" + k[-1]],
+                                                    f"phase C {k}")
+    for k in ("pseudo_seg_1", "pseudo_seg_2"):
+        nmis[k], _ = assert_labels_equal_up_to_ties(out[k], g[k].astype(np.int64), pc["pseudo_seg_margin_" + k[-1]],
+                                                    f"phase C {k}", tol=1e-4)   # logits are O(10): 1e-5 relative
     nu = [int(out["n_uncertain"][0].item()), int(out["n_uncertain"][1].item())]
-    assert abs(nu[0] - int(g["n_uncertain"][0])) <= 6 and abs(nu[1] - int(g["n_uncertain"][1])) <= 6
+    assert abs(nu[0] - int(g["n_uncertain"][0])) <= nmis["pseudo_seg_1"] and \
+        abs(nu[1] - int(g["n_uncertain"][1])) <= nmis["pseudo_seg_2"]
     for k in ("loss", "cls_loss", "ptc_loss", "seg_loss", "sim_loss", "reg_loss"):
         ref = float(np.asarray(g[k]).reshape(-1)[0])
         got = float(out[k].reshape(-1)[0].item())
@@ -339,14 +399,17 @@ def test_single_student_gradients_vs_oracle_autograd(dev, S, second):
     assert worst < 2e-5, worst
 
 
-@pytest.mark.parametrize("case", ["voc_B", "coco_B2", "voc_C"])
+@pytest.mark.parametrize("case", ["voc_B", "coco_B2", "voc_C", "voc_B_bs4", "coco_B2_bs2_vit21k"])
 def test_full_size_vitb_step_vs_oracle(dev, case):
-    """BASELINE configs at FULL size: dual-student ViT-B/16, 448^2, one image -- the whole step (ms-CAM at three scales,
-    dual forward/backward, PAR refinement, all losses; voc_C adds the on-device RandAugment view, the 336^2 aug
+    """BASELINE configs at FULL size: dual-student ViT-B/16, 448^2 -- the whole step (ms-CAM at three scales, dual
+    forward/backward, PAR refinement, all losses; voc_C adds the on-device RandAugment view, the 336^2 aug
     forward/backward, the GMM filter and the consistency loss; coco_B2 has 81 classes and the COCO schedule) against the
-    CPU oracle run on this box's host cores (~10-40 s per case).  Bars: CAM max-abs-diff < 1e-3 (north_star), identical
-    pseudo-label maps, refined label maps equal up to argmax near-ties, loss pieces 1e-4, gradients of a spread of
-    tensors 2e-3."""
+    CPU oracle run on this box's host cores (~10-40 s per image).  voc_B_bs4 is EXACTLY the bench workload (BASELINE
+    configs[1]: 4 images on one GPU, the batch at which the GEMM launcher picks its production tile / split-K
+    instantiations); coco_B2_bs2_vit21k is the per-GPU batch of configs[3]/[4] (2 images, 81 classes) built through the
+    `vit_base_patch16_224` factory of configs[4].  Bars: CAM max-abs-diff < 1e-3 (north_star), identical pseudo-label
+    maps, refined label maps identical except at PROVEN argmax ties (oracle decision margin < 1e-5 at every
+    mismatching pixel), loss pieces 1e-4, gradients of a spread of tensors 2e-3."""
     import random
     from dupl_amd.model.model_dupl import siamese_network
     from dupl_amd.model.PAR import PAR
@@ -356,12 +419,14 @@ def test_full_size_vitb_step_vs_oracle(dev, case):
     cfg = O.VIT_BASE
     coco = case.startswith("coco")
     NC = 81 if coco else 21
-    n_iter = {"voc_B": 5000, "coco_B2": 20000, "voc_C": 9000}[case]
+    n_iter = {"voc_B": 5000, "coco_B2": 20000, "voc_C": 9000, "voc_B_bs4": 5000, "coco_B2_bs2_vit21k": 20000}[case]
+    nimg = {"voc_B_bs4": 4, "coco_B2_bs2_vit21k": 2}.get(case, 1)
+    backbone = "vit_base_patch16_224" if case.endswith("vit21k") else "deit_base_patch16_224"
     targs = trainer.coco_step_args() if coco else trainer.StepArgs()
     oargs = O.coco_step_args() if coco else O.StepArgs()
     pp = O.make_siamese_params(cfg, NC, seed=3)
-    inputs, cls_label, img_box = O.synthetic_batch(1, NC - 1, 448, seed=100)
-    model = siamese_network("deit_base_patch16_224", num_classes=NC, pretrained=False, aux_layer=-3)
+    inputs, cls_label, img_box = O.synthetic_batch(nimg, NC - 1, 448, seed=100)
+    model = siamese_network(backbone, num_classes=NC, pretrained=False, aux_layer=-3)
     model.load_state_dict(pp, strict=True)
     model.to(dev)
     model.enable_dual_stream(True)
@@ -395,10 +460,11 @@ def test_full_size_vitb_step_vs_oracle(dev, case):
         assert d < 1e-3, k
     for k in ("pseudo_label_aux_1", "pseudo_label_aux_2"):
         assert torch.equal(out[k].cpu().long(), pc[k].long()), k
-    for k in ("refined_1", "refined_2") + (("pseudo_seg_1", "pseudo_seg_2") if case == "voc_C" else ()):
-        mism = int((out[k].cpu().long() != pc[k].long()).sum())
-        print(f"full-size {case} {k}: {mism} label mismatches of {pc[k].numel()}")
-        assert mism <= 20, k
+    for k in ("refined_1", "refined_2"):
+        assert_labels_equal_up_to_ties(out[k], pc[k], pc["refined_margin_" + k[-1]], f"full-size {case} {k}")
+    if case == "voc_C":
+        for k in ("pseudo_seg_1", "pseudo_seg_2"):
+            assert_labels_equal_up_to_ties(out[k], pc[k], pc["pseudo_seg_margin_" + k[-1]], f"full-size {case} {k}", tol=1e-4)
     if case == "voc_C":
         print("GMM stats:", [st.cpu().numpy().round(3).tolist() for st in out["gmm_stats"]], "oracle hits", pc["gmm_hits"])
         assert [int(st[:, 1].sum().item()) for st in out["gmm_stats"]] == list(pc["gmm_hits"])

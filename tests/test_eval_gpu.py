@@ -149,8 +149,16 @@ def test_msc_seg_inference_and_checkpoint(dev, golden_dir, tmp_path):
             ref = torch.from_numpy(g[f"msc_logits.{k}.{i}"])
             err = float((got[:, :, ::3, ::3] - ref).abs().max() / ref.abs().max())
             assert err < 2e-4, (i, k, err)
-            mism = int((got.argmax(1)[0].numpy().astype(np.uint8) != g[f"msc_pred.{k}.{i}"]).sum())
-            assert mism <= 3, (i, k, mism)
+            # predictions == the reference's except at proven ties: where they differ, the top-2 gap of the logits must be
+            # within twice the measured logit deviation (the golden keeps the reference logits on a 1/3 sub-grid only)
+            pred = got.argmax(1)[0]
+            t2 = got.topk(2, dim=1).values
+            gap = (t2[:, 0] - t2[:, 1])[0]
+            bad = torch.from_numpy(pred.numpy().astype(np.uint8) != g[f"msc_pred.{k}.{i}"])
+            tol = 2.0 * float((got[:, :, ::3, ::3] - ref).abs().max()) + 1e-6
+            worst = float(gap[bad].max()) if bad.any() else 0.0
+            print(f"img{i} branch{k}: {int(bad.sum())} prediction mismatches, largest top-2 gap among them {worst:.2e} (bar {tol:.2e})")
+            assert worst <= tol and int(bad.sum()) <= 1e-3 * bad.numel(), (i, k, worst, tol)
     for k, s in ((1, s1), (2, s2)):
         ref = float(g["msc_miou"][k - 1])
         print(f"branch{k}: msc mIoU {s['miou']:.6f} (reference {ref:.6f})")

@@ -206,3 +206,33 @@ def test_pretrained_from_local_checkpoint(tmp_path):
     assert not torch.equal(sd["branch1.classifier.weight"], sp["classifier.weight"])
     with pytest.raises(RuntimeError):
         siamese_network("tiny_test", num_classes=21, pretrained=True, aux_layer=-3)
+
+
+def test_vit21k_flat_checkpoint_and_strictness(tmp_path):
+    """vit.py:1092-1101 (`vit_base_patch16_224`, the ImageNet-21k init of BASELINE configs[4]): timm's load_pretrained
+    with filter_fn=_conv_filter reads a FLAT state_dict whose patch embedding may be stored manually patchified
+    (D, 3*p*p); both reference routes load STRICTLY, so a file with a missing key must raise, not train from random init.
+    Also: a student of a siamese pair cannot be moved alone (its parameters are views of the pair's storage)."""
+    from dupl_amd.model.model_dupl import siamese_network, network
+    sp = O.make_student_params(O.VIT_TINY, 21, seed=9)
+    enc = {k[len("encoder."):]: v for k, v in sp.items() if k.startswith("encoder.")}
+    flat = dict(enc)
+    flat["patch_embed.proj.weight"] = enc["patch_embed.proj.weight"].reshape(enc["patch_embed.proj.weight"].shape[0], -1)
+    path = str(tmp_path / "jx_vit_tiny.pth")
+    torch.save(flat, path)
+    m = siamese_network("tiny_test", num_classes=21, pretrained=path, aux_layer=-3)
+    n = network("tiny_test", num_classes=21, pretrained=path, aux_layer=-3)
+    for k, v in enc.items():
+        assert torch.equal(m.state_dict()["branch1.encoder." + k], v), k
+        assert torch.equal(m.state_dict()["branch2.encoder." + k], v), k
+        assert torch.equal(n.state_dict()["encoder." + k], v), k
+    bad = dict(flat)
+    bad.pop("norm.bias")
+    torch.save(bad, str(tmp_path / "bad.pth"))
+    with pytest.raises(RuntimeError):
+        siamese_network("tiny_test", num_classes=21, pretrained=str(tmp_path / "bad.pth"), aux_layer=-3)
+    torch.save({"module." + k: v for k, v in flat.items()}, str(tmp_path / "prefixed.pth"))
+    with pytest.raises(RuntimeError):
+        network("tiny_test", num_classes=21, pretrained=str(tmp_path / "prefixed.pth"), aux_layer=-3)
+    with pytest.raises(RuntimeError):
+        m.branch1.to("cpu")

@@ -278,12 +278,17 @@ def test_par_and_refine(dev, golden_dir):
     r_dyn = refine_cams_with_dynamic_thres(par, img_dn.to(dev), cams=(cams * rep).to(dev), cls_labels=cls_label.to(dev),
                                            high_thre_map=hm.to(dev), low_thre=0.25, ignore_index=255, img_box=img_box)
     assert r_dyn.dtype == torch.float32 and tuple(r_dyn.shape) == (b, S, S)
-    nd = int((r_dyn.cpu().numpy().astype(np.uint8) != lab["refine_dyn"]).sum())
     r_v2 = refine_cams_with_bkg_v2(par, img_dn.to(dev), cams=(cams * rep).to(dev), cls_labels=cls_label.to(dev), high_thre=0.65,
                                    low_thre=0.25, ignore_index=255, img_box=img_box)
-    nv = int((r_v2.cpu().numpy().astype(np.uint8) != lab["refine_v2"]).sum())
-    print(f"refine label mismatches vs reference: dynamic {nd}, v2 {nv} of {b * S * S}")
-    assert nd <= 8 and nv <= 8   # argmax near-ties at fp32 round-off only (oracle vs reference itself: 1)
+    # identical to the REFERENCE's label maps except at proven argmax ties: every mismatching pixel must have an oracle
+    # decision margin (top-1 - top-2 of the propagated, upsampled stack) at fp32 round-off level
+    from parity_util import assert_labels_equal_up_to_ties
+    o_dyn, m_dyn = O.refine_cams(img_dn, cams * rep, cls_label, hm, 0.25, 255, img_box, return_margin=True)
+    o_v2, m_v2 = O.refine_cams(img_dn, cams * rep, cls_label, 0.65, 0.25, 255, img_box, return_margin=True)
+    assert_labels_equal_up_to_ties(o_dyn, lab["refine_dyn"].astype(np.int64), m_dyn, "oracle vs reference, dynamic")
+    assert_labels_equal_up_to_ties(o_v2, lab["refine_v2"].astype(np.int64), m_v2, "oracle vs reference, v2")
+    assert_labels_equal_up_to_ties(r_dyn, lab["refine_dyn"].astype(np.int64), m_dyn, "refine dynamic vs reference")
+    assert_labels_equal_up_to_ties(r_v2, lab["refine_v2"].astype(np.int64), m_v2, "refine v2 vs reference")
     # PAR module forward parity
     outm = par(half_d[:1], m0.to(dev))
     assert np.abs(outm.cpu().numpy()[:, :, ::2, ::2] - gold["out_sub"]).max() < 2e-5
@@ -446,8 +451,12 @@ def test_seg_pseudo_label_and_mask_fill(dev):
     conf = torch.softmax(up, dim=1).max(1)[0]
     un = (other == 255) & (conf > 0.9)
     ref[~un] = 255
-    mism = int((ps.cpu() != ref).sum())
-    assert mism <= 3 and abs(int(cnt.item()) - int(un.sum())) <= 3     # conf == 0.9 / argmax ties at fp32 round-off
+    # identical except at proven ties: top-2 logit gap or distance of the confidence from the 0.9 gate at round-off level
+    from parity_util import assert_labels_equal_up_to_ties
+    t2 = up.topk(2, dim=1).values
+    margin = torch.minimum(t2[:, 0] - t2[:, 1], (conf - 0.9).abs())
+    n, _ = assert_labels_equal_up_to_ties(ps, ref, margin, "seg_pseudo_label", tol=1e-5)
+    assert abs(int(cnt.item()) - int(un.sum())) <= n
     lab = other.clone().to(dev)
     mask = (torch.rand(2, 128, 128, generator=g) < 0.3)
     LS.mask_fill_(lab, mask.to(dev), 255.0)
