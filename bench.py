@@ -3,16 +3,25 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
 
-A "step" is one full phase-B iteration of the reference loop (train_final_voc.py:174-472) on a synthetic
-batch that is already resident in HBM: ms-CAM for both students (3 scales x flip), dual-student
-forward/backward, CAM->label, PTC, PAR refinement (high+low) for both students, cross seg loss,
-discrepancy loss, gradient all-reduce (N > 1) and the PolyWarmupAdamW update.  Nothing is skipped or cached
-across steps.  Workload = BASELINE.json configs[1]: VOC 448^2, dual-student ViT-B/16, 4 images per GPU
-(weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+A "step" is one full iteration of the reference loop (train_final_voc.py:174-472 / train_final_coco.py:170-462) on a
+synthetic batch that is already resident in HBM: ms-CAM for both students (3 scales x flip), dual-student
+forward/backward, CAM->label, PTC, PAR refinement (high+low) for both students, cross seg loss, discrepancy loss,
+gradient all-reduce (N > 1) and the PolyWarmupAdamW update.  Nothing is skipped or cached across steps.
+
+Workload by N (BASELINE.json `configs`; the reference's "bs" is the GLOBAL batch):
+    N = 1   configs[1]  VOC2012  448^2, deit_base_patch16_224, 4 img/GPU
+    N = 2   configs[2]  VOC2012  448^2, deit_base_patch16_224, 2 img/GPU (global 4)
+    N = 4   configs[3]  MSCOCO14 448^2, 81 classes,            2 img/GPU (global 8)
+    N = 8   configs[4]  MSCOCO14 448^2, vit_base_patch16_224,  2 img/GPU (global 16)
+(other N: the COCO 2 img/GPU workload).  `value` is that configuration's whole-job img/s.  For N > 1 the line also
+carries `weak_4img_per_gpu`: the N = 1 workload (VOC, 4 img/GPU) run on all N ranks right after, i.e. the clean
+weak-scaling point against the N = 1 `value`.  --dataset / --batch / --backbone override the table.  Rank 0 prints
+ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,21 +39,35 @@ FLOP_PHASE_C_AUG = 6 * (0.0828e12 + 0.0052e12)   # phase C: fwd+bwd of both stud
 FLOP_PHASE_C_DEAD = 4 * (0.1570e12 + 0.0093e12)  # phase C: the reference's discarded 2b forward (never executed here)
 PEAK_F32_MFMA = 157.3e12              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (f32 in / f32 acc)
 
+CONFIG_BY_N = {1: ("voc", 4, "deit_base_patch16_224", "configs[1]"),
+               2: ("voc", 2, "deit_base_patch16_224", "configs[2]"),
+               4: ("coco", 2, "deit_base_patch16_224", "configs[3]"),
+               8: ("coco", 2, "vit_base_patch16_224", "configs[4]")}
+DEFAULT_N_ITER = {"voc": 5000, "coco": 20000}    # phase B of either schedule (PTC + PAR refinement + cross seg loss)
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU (VOC config: 4)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: BASELINE's configuration for this N)")
     ap.add_argument("--size", type=int, default=448)
-    ap.add_argument("--dataset", default="voc", choices=["voc", "coco"])
-    ap.add_argument("--backbone", default="deit_base_patch16_224")
-    ap.add_argument("--n-iter", type=int, default=5000, help="iteration index the step pretends to be (5000 = phase B)")
+    ap.add_argument("--dataset", default=None, choices=["voc", "coco"])
+    ap.add_argument("--backbone", default=None)
+    ap.add_argument("--n-iter", type=int, default=None, help="iteration index the step pretends to be (default: phase B)")
+    ap.add_argument("--no-weak4", action="store_true", help="N > 1: skip the second (VOC 4 img/GPU weak-scaling) measurement")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--cpu-size", type=int, default=448)
-    ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline (0 = all logical CPUs)")
+    ap.add_argument("--cpu-batch", type=int, default=1, help="images per CPU-oracle step (stated in the JSON)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads for the timed CPU steps (0 = pick the fastest of the recorded sweep over "
+                         "{physical cores, 64, 32})")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps after one warm-up step")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pmc-profile", default=os.environ.get("DUPL_PMC_PROFILE", "profiles/r02_final_pmc_hbm.txt"),
+                    help="PMC summary (tools/profile_round.sh) roofline.traffic is read from; ignored (traffic = null) "
+                         "unless its '# csrc_sha256:' header matches the kernel sources of THIS build")
     ap.add_argument("--no-share-encoder", action="store_true",
                     help="run the training forward's encoder pass separately from ms-CAM's identical scale-1.0 pass, exactly "
                          "like the reference does (default: computed once and shared; outputs are bit-identical)")
@@ -72,61 +95,107 @@ def build_world(args):
     return world, rank, local
 
 
-def make_batch(args, rank, dev, C):
-    from dupl_amd.synthetic import synthetic_batch
-    inputs, cls_label, img_box = synthetic_batch(args.batch, C, args.size, seed=100 + rank)
-    return inputs.to(dev), cls_label.to(dev), img_box, cls_label
+def physical_cores() -> int:
+    """Physical cores of the host (unique (socket, core) pairs of /proc/cpuinfo), limited to this process's affinity."""
+    try:
+        pairs, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((phys, line.split(":")[1].strip()))
+        n = len(pairs)
+    except OSError:
+        n = 0
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n or logical, logical))
 
 
-def cpu_baseline(args, C):
+def cpu_baseline(args, dataset, C):
     """The oracle (torch-CPU restatement of the reference, kind 'port') timed on this box's host cores on a BOUNDED
-    sample: one phase-B step at b=1 (same 448^2 dual-student workload, 1/`batch` of a GPU step)."""
+    sample, SURVEY 8(d) protocol: one warm-up step, a recorded thread-count sweep (one step each at {physical cores,
+    64, 32}), then `--cpu-steps` (>= 3) timed steps at the fastest count; one process, fp32, same 448^2 dual-student
+    phase-B step incl. backward and the AdamW update, `--cpu-batch` images per step (stated)."""
     from oracle import dupl_oracle as O
-    cores = min(os.cpu_count() or 1, args.cpu_threads) if args.cpu_threads > 0 else (os.cpu_count() or 1)
-    torch.set_num_threads(cores)
     cfg = O.VIT_BASE
     NC = C + 1
+    b = max(1, args.cpu_batch)
     pp = O.make_siamese_params(cfg, NC, seed=3, randomize_affine=False)
-    leaf = {k: v.clone().requires_grad_(k.split(".", 1)[1] not in ("encoder.pos_embed",)) for k, v in pp.items()}
-    inputs, cls_label, img_box = O.synthetic_batch(1, C, args.cpu_size, seed=100)
-    sargs = O.StepArgs() if args.dataset == "voc" else O.StepArgs(cam_iters=8000, gmm_iters=32000, max_iters=80000,
-                                                                   bkg_thre=0.45, high_thre=0.65,
-                                                                   high_target=tuple([0.55] * 80))
-    t0 = time.perf_counter()
-    loss, _ = O.train_step_losses(leaf, inputs, cls_label, img_box, 5000, cfg, sargs)   # always the phase-B headline step
-    loss.backward()
-    mom = {}
-    for k, p in leaf.items():
-        if p.grad is None:
-            continue
-        m, v = torch.zeros_like(p), torch.zeros_like(p)
-        with torch.no_grad():
-            O.adamw_update(p, p.grad, m, v, 1, 6e-5 if O.param_group_index(k) < 2 else 6e-4)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"1 phase-B step of oracle/dupl_oracle.py (dual ViT-B/16, {args.cpu_size}^2, b=1, fp32, "
-                      f"torch {torch.__version__} CPU, {cores} threads): {dt:.1f} s"}
+    inputs, cls_label, img_box = O.synthetic_batch(b, C, args.cpu_size, seed=100)
+    sargs = O.StepArgs() if dataset == "voc" else O.coco_step_args()
+    n_iter = DEFAULT_N_ITER[dataset]
+
+    def one_step(threads):
+        torch.set_num_threads(threads)
+        leaf = {k: v.clone().requires_grad_(k.split(".", 1)[1] not in ("encoder.pos_embed",)) for k, v in pp.items()}
+        t0 = time.perf_counter()
+        loss, _ = O.train_step_losses(leaf, inputs, cls_label, img_box, n_iter, cfg, sargs)
+        loss.backward()
+        for k, p in leaf.items():
+            if p.grad is None:
+                continue
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            with torch.no_grad():
+                O.adamw_update(p, p.grad, m, v, 1, 6e-5 if O.param_group_index(k) < 2 else 6e-4)
+        return time.perf_counter() - t0
+
+    phys = physical_cores()
+    cand = [args.cpu_threads] if args.cpu_threads > 0 else sorted({phys, min(64, phys), min(32, phys)}, reverse=True)
+    one_step(cand[0])                                   # warm-up (allocator, thread pool, page-in)
+    sweep = {}
+    if len(cand) > 1:
+        for t in cand:
+            sweep[str(t)] = round(b / one_step(t), 5)
+        best = int(max(sweep, key=sweep.get))
+    else:
+        best = cand[0]
+    times = [one_step(best) for _ in range(max(1, args.cpu_steps))]
+    dt = sum(times) / len(times)
+    return {"value": round(b / dt, 5), "unit": "img/s", "cores": best, "kind": "port", "physical_cores": phys,
+            "logical_cpus": os.cpu_count(), "batch": b, "warmup_steps": 1, "timed_steps": len(times),
+            "step_seconds": [round(t, 2) for t in times], "threads_sweep_img_per_s": sweep,
+            "sample": f"{len(times)} timed phase-B steps (after 1 warm-up) of oracle/dupl_oracle.py: dual ViT-B/16, "
+                      f"{args.cpu_size}^2, {dataset.upper()} {NC} classes, b={b} image(s)/step incl. backward + AdamW, fp32, "
+                      f"torch {torch.__version__} CPU, {best} threads (fastest of the sweep; {phys} physical cores): "
+                      f"{dt:.1f} s/step"}
 
 
-def pmc_traffic_per_launch(kernel_prefix="gemm_f32_kernel<false, false"):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_final_pmc_hbm.txt:
-    separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same workload, summarised by
-    tools/rocpd_pmc.py).  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md 'HBM');
-    it counts L2->fabric requests, i.e. Infinity-Cache hits are included.  None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.txt")
+def csrc_digest() -> str:
+    from dupl_amd.build import source_digest
+    return source_digest()
+
+
+def pmc_traffic_per_launch(path, kernel_prefix="gemm_f32_kernel<false, false"):
+    """HBM-side bytes per launch of the dominant kernel from a PMC summary written by tools/profile_round.sh (separate
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same workload, tools/rocpd_pmc.py).  FETCH_SIZE is
+    doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md 'HBM'); it counts L2->fabric requests, i.e.
+    Infinity-Cache hits are included.  The summary is only trusted if its '# csrc_sha256:' header equals the digest of
+    the kernel sources of THIS build; otherwise (or if absent) -> (None, reason)."""
+    full = path if os.path.isabs(path) else os.path.join(ROOT, path)
     try:
-        calls = fetch_kib = write_kib = 0.0
-        for line in open(path):
-            if line.startswith(kernel_prefix):      # both column-tile instantiations (<..., 64, 1, 2> and <..., 64, 1, 1>)
-                parts = line.split()
-                calls += float(parts[-4])
-                fetch_kib += float(parts[-2])
-                write_kib += float(parts[-1])
-        if calls:
-            return round((2.0 * fetch_kib + write_kib) * 1024.0 / calls)
+        lines = open(full).read().splitlines()
     except OSError:
-        pass
-    return None
+        return None, f"no PMC summary at {path}"
+    tag = {}
+    for line in lines:
+        if line.startswith("# ") and ":" in line:
+            k, v = line[2:].split(":", 1)
+            tag[k.strip()] = v.strip()
+    have = csrc_digest()
+    if tag.get("csrc_sha256") != have:
+        return None, (f"{path} is stale or untagged (its csrc_sha256 {tag.get('csrc_sha256', 'missing')[:12]} != "
+                      f"{have[:12]} of this build): re-run tools/profile_round.sh")
+    calls = fetch_kib = write_kib = 0.0
+    for line in lines:
+        if line.startswith(kernel_prefix):      # every column-tile instantiation of the NT kernel
+            parts = line.split()
+            calls += float(parts[-4])
+            fetch_kib += float(parts[-2])
+            write_kib += float(parts[-1])
+    if not calls:
+        return None, f"{path}: no row for {kernel_prefix}"
+    return round((2.0 * fetch_kib + write_kib) * 1024.0 / calls), \
+        f"PMC FETCH_SIZE*2 + WRITE_SIZE per launch, {path} (tag {tag.get('tag', '?')}, git {tag.get('git_head', '?')[:10]})"
 
 
 class GemmTimer:
@@ -175,104 +244,174 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+class Workload:
+    """One (dataset, per-GPU batch, backbone) configuration: model, optimiser, resident synthetic batch, step()."""
+
+    def __init__(self, args, world, rank, local, dataset, batch, backbone, n_iter):
+        from dupl_amd.model.model_dupl import siamese_network
+        from dupl_amd.model.PAR import PAR
+        from dupl_amd.utils.optimizer import PolyWarmupAdamW
+        from dupl_amd.ddp import DistributedDataParallel
+        from dupl_amd.synthetic import synthetic_batch
+        from dupl_amd import trainer
+        self.args, self.world, self.local = args, world, local
+        self.dataset, self.batch, self.backbone, self.n_iter = dataset, batch, backbone, n_iter
+        self.dev = dev = torch.device("cuda", local)
+        self.C = C = 20 if dataset == "voc" else 80
+        self.sargs = trainer.StepArgs() if dataset == "voc" else trainer.coco_step_args()
+        self.sargs.share_encoder_pass = not args.no_share_encoder
+        torch.manual_seed(0)
+        self.model = model = siamese_network(backbone, num_classes=C + 1, pretrained=False, aux_layer=-3)
+        groups = model.get_param_groups()
+        model.to(dev)
+        if not args.single_stream:
+            model.enable_dual_stream(True)
+        self.ddp = DistributedDataParallel(model) if world > 1 else model
+        self.optim = PolyWarmupAdamW(params=[{"params": groups[i], "lr": 6e-5 * (1 if i < 2 else 10), "weight_decay": 1e-2}
+                                             for i in range(4)], lr=6e-5, weight_decay=1e-2, betas=(0.9, 0.999),
+                                     warmup_iter=1500, max_iter=self.sargs.max_iters, warmup_ratio=1e-6,
+                                     power=0.9).bind(model.flat_storage)
+        self.par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+        inputs, cls_label, img_box = synthetic_batch(batch, C, args.size, seed=100 + rank)
+        self.inputs, self.cls_label, self.img_box, self.cls_host = inputs.to(dev), cls_label.to(dev), img_box, cls_label
+        last = n_iter + args.warmup + args.steps
+        self.phase = "A" if last < self.sargs.cam_iters else ("B" if last < self.sargs.gmm_iters else "C")
+        self._trainer = trainer
+        lo, hi = model.flat_storage.trainable_range(0)
+        self.grad_bytes = 4 * (hi - lo) * model.flat_storage.n_students
+
+    def step(self, i):
+        # phase C: the strongly augmented view (train_final_voc.py:191) is computed inside the step, on the device
+        return self._trainer.train_step(self.ddp, self.optim, self.par, self.inputs, self.cls_label, self.img_box,
+                                        self.n_iter + i, self.sargs, cls_label_host=self.cls_host)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier(device_ids=[self.local]) if self.args.backend == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
+
+    def measure(self, label):
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize, max over ranks."""
+        args, world = self.args, self.world
+        log(f"[{label}] {self.dataset} {self.batch} img/GPU {self.backbone} on {self.dev}; {args.warmup} warm-up step(s)")
+        for i in range(args.warmup):
+            tw = time.perf_counter()
+            self.step(i)
+            torch.cuda.synchronize()
+            log(f"[{label}] warm-up step {i}: {time.perf_counter() - tw:.3f} s")
+        red = self.ddp.reducer if world > 1 else None
+        if red is not None:
+            red.pop_stats()
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = self.step(args.warmup + i)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        comm = {"world": world, "backend": (args.backend + ("(RCCL)" if args.backend == "nccl" else "")) if world > 1 else "none",
+                "grad_bytes_per_rank": self.grad_bytes, "allreduce_bytes": 0, "allreduce_calls": 0, "comm_exposed_ms": 0.0}
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            st = red.pop_stats()
+            comm["allreduce_bytes"] = st["allreduce_bytes"] // max(1, args.steps)      # per step, this rank
+            comm["allreduce_calls"] = st["allreduce_calls"] // max(1, args.steps)
+            # exposed communication: one extra step with the step's compute drained before the waits of finish()
+            # (profiling inserts a stream join, so it runs outside the timed region)
+            red.profile = True
+            self.step(args.warmup + args.steps)
+            torch.cuda.synchronize()
+            red.profile = False
+            ex = red.pop_stats()["exposed_ms"]
+            e = torch.tensor([sum(ex)], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+            comm["comm_exposed_ms"] = round(float(e.item()), 3)
+        ms = dt / args.steps * 1e3
+        value = world * self.batch * args.steps / dt
+        log(f"[{label}] timed region: {args.steps} steps in {dt:.3f} s -> {value:.2f} img/s")
+        return {"value": value, "ms": ms, "loss": float(out["loss"].sum().item()), "comm": comm}
+
+    def describe(self):
+        name = "VOC2012" if self.dataset == "voc" else "MSCOCO2014"
+        return (f"{name} {self.args.size}^2 dual-student {self.backbone} + ms-CAM(1.0,0.5,1.5) + PAR + cross seg loss, "
+                f"phase {self.phase}, {self.batch} img/GPU, DDP world_size={self.world}")
+
+
 def main():
     args = parse()
     world, rank, local = build_world(args)
-    dev = torch.device("cuda", local)
-    from dupl_amd.model.model_dupl import siamese_network
-    from dupl_amd.model.PAR import PAR
-    from dupl_amd.utils.optimizer import PolyWarmupAdamW
-    from dupl_amd.ddp import DistributedDataParallel
-    from dupl_amd import trainer
+    d_ds, d_b, d_bb, d_cfg = CONFIG_BY_N.get(world, ("coco", 2, "deit_base_patch16_224", "COCO 2 img/GPU (no BASELINE entry for this N)"))
+    dataset = args.dataset or d_ds
+    batch = args.batch or d_b
+    backbone = args.backbone or d_bb
+    listed = (dataset, batch, backbone) == (d_ds, d_b, d_bb)
+    n_iter = args.n_iter if args.n_iter is not None else DEFAULT_N_ITER[dataset]
 
-    C = 20 if args.dataset == "voc" else 80
-    sargs = trainer.StepArgs() if args.dataset == "voc" else trainer.coco_step_args()
-    sargs.share_encoder_pass = not args.no_share_encoder
-    torch.manual_seed(0)
-    model = siamese_network(args.backbone, num_classes=C + 1, pretrained=False, aux_layer=-3)
-    groups = model.get_param_groups()
-    model.to(dev)
-    if not args.single_stream:
-        model.enable_dual_stream(True)
-    ddp = DistributedDataParallel(model) if world > 1 else model
-    optim = PolyWarmupAdamW(params=[{"params": groups[i], "lr": 6e-5 * (1 if i < 2 else 10), "weight_decay": 1e-2}
-                                    for i in range(4)], lr=6e-5, weight_decay=1e-2, betas=(0.9, 0.999),
-                            warmup_iter=1500, max_iter=sargs.max_iters, warmup_ratio=1e-6, power=0.9).bind(model.flat_storage)
-    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
-    inputs, cls_label, img_box, cls_host = make_batch(args, rank, dev, C)
-    phase = "A" if args.n_iter + args.warmup + args.steps < sargs.cam_iters else ("B" if args.n_iter + args.warmup + args.steps < sargs.gmm_iters else "C")
-    # phase C: the strongly augmented view (train_final_voc.py:191, RandAugment(5, 10) + flip) is computed inside the step
-
-    def step(i):
-        return trainer.train_step(ddp, optim, par, inputs, cls_label, img_box, args.n_iter + i, sargs, cls_label_host=cls_host)
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
-        torch.cuda.synchronize()
-
-    log(f"model on {dev}; starting {args.warmup} warm-up step(s)")
-    for i in range(args.warmup):
-        tw = time.perf_counter()
-        step(i)
-        torch.cuda.synchronize()
-        log(f"warm-up step {i}: {time.perf_counter() - tw:.3f} s")
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss_val = float(out["loss"].sum().item())
-    ms = dt / args.steps * 1e3
-    imgs_per_s = world * args.batch * args.steps / dt
-    log(f"timed region: {args.steps} steps in {dt:.3f} s -> {imgs_per_s:.2f} img/s")
+    wl = Workload(args, world, rank, local, dataset, batch, backbone, n_iter)
+    res = wl.measure("main")
+    ms, imgs_per_s, phase, C = res["ms"], res["value"], wl.phase, wl.C
 
     flop_ref = FLOP_PER_IMG_PHASE_AB + (FLOP_PHASE_C_AUG + FLOP_PHASE_C_DEAD if phase == "C" else 0.0)
     flop_exec = FLOP_PER_IMG_PHASE_AB - (0.0 if args.no_share_encoder else FLOP_SHARED_PASS) + \
         (FLOP_PHASE_C_AUG if phase == "C" else 0.0)
     roof = None
     if not args.no_roofline:
-        model.enable_dual_stream(False)   # per-kernel durations are only meaningful without a co-running stream
+        wl.model.enable_dual_stream(False)   # per-kernel durations are only meaningful without a co-running stream
         timer = GemmTimer()
         timer.install()
-        step(args.warmup + args.steps)
+        wl.step(args.warmup + args.steps + 1)
         gms, gflops, gn, gbytes = timer.result()
         timer.remove()
+        if not args.single_stream:
+            wl.model.enable_dual_stream(True)
         ach = gflops / (gms * 1e-3)
-        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<false,false,64,1,*> (v_mfma_f32_32x32x2_f32; 128- and 64-column tile instantiations)", "achieved": round(ach / 1e12, 2),
+        traffic, tnote = pmc_traffic_per_launch(args.pmc_profile) if (dataset, batch) == ("voc", 4) else \
+            (None, "the committed PMC passes are of the VOC 4 img/GPU workload")
+        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<false,false,...> (v_mfma_f32_32x32x2_f32; every Linear forward, all tile instantiations)",
+                "achieved": round(ach / 1e12, 2),
                 "peak": round(PEAK_F32_MFMA / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4),
-                "traffic": pmc_traffic_per_launch(), "traffic_unit": "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, "
-                "profiles/r01_final_pmc_hbm.txt)", "algorithmic_bytes_per_launch": round(gbytes / max(gn, 1)),
+                "traffic": traffic, "traffic_source": tnote, "csrc_sha256": csrc_digest()[:16],
+                "algorithmic_bytes_per_launch": round(gbytes / max(gn, 1)),
                 "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
                 "kernel_share_of_step": round(gms / ms, 3),
                 "step_frac_of_peak": round(imgs_per_s / world * flop_exec / PEAK_F32_MFMA, 4),
                 "step_flop_per_img": {"reference_algorithm": flop_ref, "executed": flop_exec},
                 "note": "HIP event pairs around every launch of the kernel during one extra step run right after the timed "
                         "region (same stream, same workload); algorithmic flops = 2*M*N*K per launch"}
+
+    weak4 = None
+    if world > 1 and not args.no_weak4 and (dataset, batch) != ("voc", 4):
+        del wl
+        torch.cuda.empty_cache()
+        w4 = Workload(args, world, rank, local, "voc", 4, "deit_base_patch16_224", DEFAULT_N_ITER["voc"])
+        r4 = w4.measure("weak-4img")
+        weak4 = {"value": round(r4["value"], 3), "unit": "img/s", "ms_per_step": round(r4["ms"], 2), "workload": w4.describe(),
+                 "comm": r4["comm"], "note": "the N = 1 workload (configs[1]) on every rank: weak-scaling point against the "
+                                             "N = 1 `value`"}
+        wl = w4
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline == "auto":
-        log("timing the CPU oracle on the host cores (bounded sample)")
-        cpu = cpu_baseline(args, C)
+        log("timing the CPU oracle on the host cores (bounded sample: warm-up + thread sweep + timed steps)")
+        cpu = cpu_baseline(args, dataset, C)
         log(f"cpu baseline: {cpu}")
     if rank == 0:
-        rec = {"metric": f"training img/s at 448^2, {'VOC' if args.dataset == 'voc' else 'COCO'} dual-student ViT-B/16, phase {phase} step",
+        rec = {"metric": f"training img/s at 448^2, {'VOC' if dataset == 'voc' else 'COCO'} dual-student ViT-B/16, phase {phase} step",
                "value": round(imgs_per_s, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{'VOC2012' if args.dataset == 'voc' else 'MSCOCO2014'} {args.size}^2 dual-student "
-                                      f"{args.backbone} + ms-CAM(1.0,0.5,1.5) + PAR + cross seg loss, phase {phase}, "
-                                      f"{args.batch} img/GPU, DDP world_size={world}",
-                          "global_batch": world * args.batch, "img_per_gpu": args.batch, "num_classes": C + 1,
-                          "n_iter": args.n_iter, "parallelism": f"dp{world}", "student_streams": 1 if args.single_stream else 2,
+               "config": {"workload": (f"VOC2012 {args.size}^2" if dataset == "voc" else f"MSCOCO2014 {args.size}^2") +
+                                      f" dual-student {backbone} + ms-CAM(1.0,0.5,1.5) + PAR + cross seg loss, phase {phase}, "
+                                      f"{batch} img/GPU, DDP world_size={world}",
+                          "baseline_config": d_cfg if listed else "custom (--dataset/--batch/--backbone)",
+                          "global_batch": world * batch, "img_per_gpu": batch, "num_classes": C + 1,
+                          "n_iter": n_iter, "parallelism": f"dp{world}", "student_streams": 1 if args.single_stream else 2,
                           "shared_scale1_encoder_pass": not args.no_share_encoder,
-                          "loss": round(loss_val, 5)},
+                          "loss": round(res["loss"], 5)},
+               "comm": res["comm"], "weak_4img_per_gpu": weak4,
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec))
     if world > 1:

@@ -25,6 +25,18 @@ def _deps():
     return hdr
 
 
+def source_digest() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/dupl_hip.h): the build identity that profile
+    summaries are tagged with (tools/profile_round.sh) and that bench.py checks before quoting a PMC number."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(_sources() + _deps()):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale(target: str, srcs) -> bool:
     if not os.path.exists(target):
         return True

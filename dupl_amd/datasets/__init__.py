@@ -1,3 +1,3 @@
-"""Dataset constants the evaluation tables need (the category names of datasets/voc.py:14 and datasets/coco.py:14).
-The loaders / augmentation themselves are outside the hot path."""
+"""Datasets of the training loops (datasets/voc.py, datasets/coco.py) in a raw-item form: workers decode and draw the
+random geometry, the device does the pixel work (device_loader.py, csrc/loader.hip)."""
 from . import voc, coco  # noqa: F401

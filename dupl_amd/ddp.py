@@ -37,6 +37,13 @@ class GradReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket_elems = max(1, int(bucket_mb * 1024 * 1024 / 4))
         self._pending: List = []
+        # per-step exchange accounting (bench.py: comm_exposed_ms / allreduce_bytes): bytes handed to all_reduce since the
+        # last pop_stats(), and -- when `profile` is on -- how long the stream that finalises the step is blocked in the
+        # waits of finish() AFTER all compute of the step has drained (what the overlap failed to hide)
+        self.profile = False
+        self._bytes = 0
+        self._calls = 0
+        self._exposed = []       # (event, event) pairs on CUDA, float ms on CPU tensors
         # layer-granular plan: per student [(lo, hi, trigger event)], in the order the backward finalises them
         self.plan = [store.grad_buckets(s, blocks_per_bucket) for s in range(store.n_students)]
         self._issued = [set() for _ in range(store.n_students)]
@@ -61,6 +68,8 @@ class GradReducer:
             t = self.store.grad[lo:lo + n]
             work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._pending.append((work, t))
+            self._bytes += 4 * n
+            self._calls += 1
             lo += n
 
     def grad_ready(self, student: int, event):
@@ -86,8 +95,25 @@ class GradReducer:
         if not self._pending:
             return
         inv = 1.0 / self.world
-        for work, t in self._pending:
+        cuda = self._pending[0][1].is_cuda
+        if self.profile:
+            import time
+            if cuda:
+                # drain the student streams first so that the interval below is communication only
+                self.store.wait_streams()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            else:
+                t0 = time.perf_counter()
+        for work, _ in self._pending:
             work.wait()
+        if self.profile:
+            if cuda:
+                e1.record()
+                self._exposed.append((e0, e1))
+            else:
+                self._exposed.append((time.perf_counter() - t0) * 1e3)
+        for _, t in self._pending:
             if t.is_cuda:
                 from . import ops
                 ops.scale_(t, inv)
@@ -96,6 +122,20 @@ class GradReducer:
         self._pending.clear()
         for s in self._issued:
             s.clear()
+
+    def pop_stats(self):
+        """{allreduce_bytes, allreduce_calls, exposed_ms (list, one per finish() while profile was on)} since the last
+        call; synchronises the device when CUDA events are pending."""
+        exp = []
+        for e in self._exposed:
+            if isinstance(e, tuple):
+                e[1].synchronize()
+                exp.append(e[0].elapsed_time(e[1]))
+            else:
+                exp.append(e)
+        out = {"allreduce_bytes": self._bytes, "allreduce_calls": self._calls, "exposed_ms": exp}
+        self._bytes, self._calls, self._exposed = 0, 0, []
+        return out
 
     def reduce_all(self):
         for s in range(self.store.n_students):

@@ -1,7 +1,8 @@
 """Shared body of train_final_voc.py / train_final_coco.py: the reference's launch surface (argparse flag names and
 defaults, LOCAL_RANK env, torchrun launch, DDP wrap, PolyWarmupAdamW, PAR, per-iteration loop, periodic checkpoint
-with the DDP `module.` key prefix) on the HIP engine.  Datasets / augmentation / validation are outside the hot
-path (SURVEY 2 "OUT"): batches are synthetic unless a DataLoader-like iterable is passed to `train(loader=...)`."""
+with the DDP `module.` key prefix) on the HIP engine.  Data: the reference's datasets in raw-item form + the device input
+pipeline (datasets/, csrc/loader.hip) when the dataset folder exists, a DataLoader-like iterable passed to
+`train(loader=...)`, or synthetic batches (no dataset is mounted in the authoring / GPU containers)."""
 from __future__ import annotations
 
 import argparse
@@ -66,10 +67,83 @@ def build_parser(dataset: str) -> argparse.ArgumentParser:
     p.add_argument("--gmm_valid_thre", default=1.0, type=float)
     p.add_argument("--gamma", default=0.95, type=float)
     # additions of this build
-    p.add_argument("--synthetic", default=True, type=bool, help="synthetic batches (the only data source in this build)")
-    p.add_argument("--start_iter", default=0, type=int, help="first n_iter (lets a short run exercise phase B)")
+    p.add_argument("--synthetic", default="auto", type=_tristate,
+                   help="auto (default): synthetic batches unless the dataset folder exists; 1 / 0 force it")
+    p.add_argument("--start_iter", default=0, type=int,
+                   help="first n_iter (lets a short run exercise phase B); the LR schedule starts there too")
     p.add_argument("--single_stream", action="store_true")
     return p
+
+
+def _tristate(v: str):
+    v = str(v).lower()
+    if v in ("auto", ""):
+        return "auto"
+    if v in ("1", "true", "yes", "on"):
+        return True
+    if v in ("0", "false", "no", "off"):
+        return False
+    raise argparse.ArgumentTypeError(f"expected auto / 1 / 0, got {v!r}")
+
+
+def build_loaders(args, dataset: str, device, world: int, rank: int):
+    """The reference's dataset / sampler / loader construction (train_final_voc.py:120-141, train_final_coco.py:118-141)
+    over this build's raw-item datasets + the device pipeline: DistributedSampler(shuffle=True), batch_size =
+    samples_per_gpu, drop_last, prefetch_factor 4; val loader batch_size 1.  Returns (train_loader, val_loader)."""
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from .datasets import voc as voc_ds, coco as coco_ds
+    from .datasets.device_loader import DeviceLoader, DeviceValLoader, raw_collate
+    if dataset == "voc":
+        train_dataset = voc_ds.VOC12ClsDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.train_set,
+                                               stage="train", aug=True, rescale_range=args.scales, crop_size=args.crop_size,
+                                               img_fliplr=True, ignore_index=args.ignore_index, num_classes=args.num_classes)
+        val_dataset = voc_ds.VOC12SegDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.val_set,
+                                             stage="val", aug=False, ignore_index=args.ignore_index,
+                                             num_classes=args.num_classes)
+    else:
+        train_dataset = coco_ds.CocoClsDataset(img_dir=args.img_folder, label_dir=args.label_folder,
+                                               name_list_dir=args.list_folder, split=args.train_set, stage="train", aug=True,
+                                               rescale_range=args.scales, crop_size=args.crop_size, img_fliplr=True,
+                                               ignore_index=args.ignore_index, num_classes=args.num_classes)
+        val_dataset = coco_ds.CocoSegDataset(img_dir=args.img_folder, label_dir=args.label_folder,
+                                             name_list_dir=args.list_folder, split=args.val_set, stage="val", aug=False,
+                                             ignore_index=args.ignore_index, num_classes=args.num_classes)
+    train_sampler = DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True)
+    kw = dict(prefetch_factor=4) if args.num_workers > 0 else {}
+    train_loader = DataLoader(train_dataset, batch_size=args.samples_per_gpu, shuffle=False, num_workers=args.num_workers,
+                              pin_memory=False, drop_last=True, sampler=train_sampler, collate_fn=raw_collate, **kw)
+    val_loader = DataLoader(val_dataset, batch_size=1, shuffle=False, num_workers=args.num_workers, pin_memory=False,
+                            drop_last=False, collate_fn=raw_collate)
+    return DeviceLoader(train_loader, device), DeviceValLoader(val_loader, device)
+
+
+class _EpochIterator:
+    """The reference's iterator handling (train_final_voc.py:132-133,177-182): `set_epoch(np.random.randint(max_iters))`
+    on the sampler before the first pass and again whenever the loader runs dry, then a fresh iterator."""
+
+    def __init__(self, loader, max_iters: int):
+        self.loader, self.max_iters = loader, max_iters
+        self.epochs = 0
+        self._restart()
+
+    def _restart(self):
+        sampler = getattr(self.loader, "sampler", None)
+        if sampler is not None and hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(np.random.randint(self.max_iters))
+        self.it = iter(self.loader)
+        self.epochs += 1
+
+    def next(self):
+        try:
+            return next(self.it)
+        except StopIteration:
+            self._restart()
+            try:
+                return next(self.it)
+            except StopIteration:
+                raise RuntimeError("the training loader is empty after a restart (a one-shot generator, or fewer items "
+                                   "than samples_per_gpu * world with drop_last)") from None
 
 
 def setup_seed(seed):
@@ -117,12 +191,21 @@ def train(args, dataset: str, loader=None, val_loader=None):
                                        bkg_thre=args.bkg_thre, high_thre=args.high_thre, low_thre=args.low_thre,
                                        ignore_index=args.ignore_index, cam_scales=tuple(args.cam_scales),
                                        samples_per_gpu=args.samples_per_gpu)
-    it = iter(loader) if loader is not None else None
+    world = dist.get_world_size() if distributed else 1
+    synthetic = getattr(args, "synthetic", "auto")
+    if loader is None and synthetic is not True:
+        folder = args.data_folder if voc else args.img_folder
+        if synthetic is False or os.path.isdir(folder):
+            loader, built_val = build_loaders(args, dataset, device, world, rank)
+            val_loader = val_loader if val_loader is not None else built_val
+    it = _EpochIterator(loader, args.max_iters) if loader is not None else None
+    optim.global_step = args.start_iter       # a run that starts at n_iter = k is at step k of the LR schedule too
     t0 = time.time()
     acc = {}
     for n_iter in range(args.start_iter, args.max_iters):
         if it is not None:
-            _, inputs, cls_label, img_box, _ = next(it)
+            _, inputs, cls_label, img_box, _ = it.next()
+            cls_label = cls_label.float()
             cls_host = cls_label
             inputs, cls_label = inputs.to(device), cls_label.to(device)
         else:

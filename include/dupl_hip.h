@@ -310,6 +310,24 @@ int dupl_aug_sharpness(const uint8_t* in, uint8_t* out, int32_t H, int32_t W, fl
 /* transforms.ToTensor + Normalize(ImageNet mean/std) + torch.flip(dims=[2]) (imutils.py:307-315): out (3,H,W) float32 */
 int dupl_aug_finish(const uint8_t* img, float* out, int32_t H, int32_t W, dupl_stream_t s);
 
+/* ------------------------------------------------------------------ loader-side input pipeline (SURVEY 8f-3 ii)
+ * The geometric part of VOC12ClsDataset / CocoClsDataset.__getitem__ (datasets/voc.py:134-186) on interleaved
+ * uint8 images (H,W,3) as decoded, bit-exact with Pillow / numpy (see csrc/loader.hip).  The random draws and the
+ * fixed-point coefficient tables of Pillow's resize are made on the host (dupl_amd/datasets/transforms.py). */
+/* horizontal pass of PIL.Image.resize(..., BILINEAR) inside transforms._img_rescaling (transforms.py:63-76):
+ * in (h,w,3) -> out (h,w2,3); coef (w2,ksize) int32 22-bit fixed point, bounds (w2,2) = (first input column, taps) */
+int dupl_loader_resample_h(const uint8_t* in, uint8_t* out, const int32_t* coef, const int32_t* bounds, int32_t ksize,
+                           int32_t h, int32_t w, int32_t w2, dupl_stream_t s);
+/* vertical pass of the same resize fused with transforms.random_fliplr (transforms.py:103-116) and transforms.random_crop
+ * (transforms.py:147-204; mean_rgb = 0): tmp (h,w2,3) -> out (crop,crop,3); the rescaled (h2,w2) image sits at
+ * (h_pad,w_pad) of the zero canvas, the crop window starts at (h_start,w_start); coef (h2,ksize), bounds (h2,2) */
+int dupl_loader_resample_v_crop(const uint8_t* tmp, uint8_t* out, const int32_t* coef, const int32_t* bounds, int32_t ksize,
+                                int32_t w2, int32_t h2, int32_t flip, int32_t h_pad, int32_t w_pad, int32_t h_start,
+                                int32_t w_start, int32_t crop, dupl_stream_t s);
+/* in (H,W,3) uint8 -> out (3,H,W) float32.  mode 0: T.ToTensor + T.Normalize(ImageNet) of the train items
+ * (datasets/voc.py:96-99,165); mode 1: transforms.normalize_img of the val items (transforms.py:45-52, voc.py:248) */
+int dupl_loader_normalize(const uint8_t* in, float* out, int32_t H, int32_t W, int32_t mode, dupl_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -873,3 +873,49 @@ def augment_data_strong(images: Tensor, n: int = 4, m: int = 20, rng=None, ops_p
         t = (t - mean) / std                                                        # transforms.Normalize
         out[i] = torch.flip(t, dims=[2])
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# loader-side geometry of the train items, normalisation of train / val items
+# ----------------------------------------------------------------------------------------------
+def loader_train_item(image: np.ndarray, rescale_range=(0.5, 2.0), crop_size: int = 448, img_fliplr: bool = True):
+    """VOC12ClsDataset / CocoClsDataset `__transforms` with aug=True (datasets/voc.py:134-148), geometric part + the
+    final normalisation; the photometric views in between (torchvision ColorJitter / RandomGrayscale + GaussianBlur,
+    voc.py:101-114,145-146) are outside this restatement (torchvision is absent here; they would also consume random
+    numbers, so only the draws of ONE item after a re-seed are comparable).  image: uint8 (h,w,3).
+    Random numbers come from the global `random` / `np.random` streams in the reference's order: transforms.py:59
+    (uniform), :104 (random), :162-163 (np.random.randint x2), :172-174 (randrange x2).
+    Third-party: PIL.Image.resize(BILINEAR) is called like the reference calls it (transforms.py:70).
+    Returns (inputs (3,S,S) float32, img_box int16 (4,), crop uint8 (S,S,3))."""
+    import random
+    from PIL import Image
+    h, w, _ = image.shape
+    ratio = random.uniform(rescale_range[0], rescale_range[1])
+    img = np.asarray(Image.fromarray(image.astype(np.uint8)).resize([int(ratio * w), int(ratio * h)],
+                                                                    resample=Image.BILINEAR)).astype(np.float32)
+    if img_fliplr and random.random() > 0.5:
+        img = np.fliplr(img)
+    h, w, _ = img.shape
+    H, W = max(crop_size, h), max(crop_size, w)
+    pad = np.zeros((H, W, 3), dtype=np.uint8)
+    hp, wp = int(np.random.randint(H - h + 1)), int(np.random.randint(W - w + 1))
+    pad[hp:hp + h, wp:wp + w, :] = img
+    hs = random.randrange(0, H - crop_size + 1, 1)
+    ws = random.randrange(0, W - crop_size + 1, 1)
+    crop = pad[hs:hs + crop_size, ws:ws + crop_size, :]
+    box = np.asarray([max(hp - hs, 0), min(crop_size, h + hp - hs), max(wp - ws, 0), min(crop_size, w + wp - ws)],
+                     dtype=np.int16)
+    mean = torch.tensor((0.485, 0.456, 0.406), dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225), dtype=torch.float32).view(3, 1, 1)
+    t = torch.from_numpy(np.ascontiguousarray(crop)).permute(2, 0, 1).to(torch.float32).div(255)      # T.ToTensor
+    return (t - mean) / std, box, np.ascontiguousarray(crop)                                             # T.Normalize
+
+
+def normalize_img(img: np.ndarray, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375)) -> np.ndarray:
+    """datasets/transforms.py:45-52 (val items): float32 array of (uint8 - mean) / std, computed by numpy in float64 and
+    rounded once on assignment; HWC in, HWC out (the caller transposes, voc.py:250)."""
+    arr = np.asarray(img)
+    out = np.empty(arr.shape, np.float32)
+    for c in range(3):
+        out[..., c] = (arr[..., c] - mean[c]) / std[c]
+    return out

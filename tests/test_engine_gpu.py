@@ -156,7 +156,9 @@ def test_cam_with_grad_matches_reference(dev, golden_dir):
         ref = g[k]
         if ref.shape != got.shape:
             got = got.reshape(-1)[::7]
-        worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)))
+        # floor 1e-5: the gradient of encoder.norm.bias through a min/max-normalised CAM alone (branch 2) is zero up to
+        # round-off (2e-7) -- a per-channel offset nearly cancels in (cam - min) / max
+        worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-5)))
         nchk += 1
     print(f"cam_with_grad: {nchk} gradient tensors, worst rel err {worst:.2e}")
     assert nchk >= 100 and worst < 2e-3

@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -211,3 +212,90 @@ def test_strong_augmentation_vs_reference(golden_dir):
         assert torch.equal(torch.as_tensor(O.cosine_descent(hi, lo, int(s), 18000)).float(), torch.from_numpy(ref))
     # denormalize_img2 against the reference function itself (executed from /root/reference at generation time)
     assert torch.equal(O.denormalize_img2(torch.from_numpy(d["denorm_in"])), torch.from_numpy(d["denorm_out"]))
+
+
+# ------------------------------------------------------------------------------------------ loader pipeline (f-3 ii, a19)
+def test_loader_oracle_and_host_draws_match_reference_golden(golden_dir):
+    """tests/golden/loader.npz holds the outputs of the REFERENCE's own `__transforms` / transforms.* (ast-extracted,
+    oracle/gen_golden_loader.py).  The oracle restatement reproduces crop, img_box and normalised tensor bit-exactly on
+    the same seeds; the product's host side (datasets/transforms.py::draw_geometry) draws the same random numbers in the
+    same order (same img_box, and a geometry from which the crop follows); normalize_img == the val golden."""
+    import random
+    from PIL import Image
+    from dupl_amd.datasets.transforms import draw_geometry, resample_coeffs
+    g = np.load(os.path.join(golden_dir, "loader.npz"))
+    flips = 0
+    for i in range(int(g["n_cases"])):
+        img, seed, S, rr = g[f"img.{i}"], int(g[f"seed.{i}"]), int(g[f"crop_size.{i}"]), tuple(g[f"rescale.{i}"])
+        random.seed(seed)
+        np.random.seed(seed)
+        t, box, crop = O.loader_train_item(img, rr, S)
+        assert np.array_equal(crop, g[f"crop.{i}"]) and np.array_equal(box, g[f"img_box.{i}"])
+        assert np.array_equal(t[:, ::7, ::5].numpy(), g[f"inputs_sub.{i}"])
+        random.seed(seed)
+        np.random.seed(seed)
+        geo = draw_geometry(img.shape[0], img.shape[1], rr, S)
+        assert np.array_equal(geo.img_box, g[f"img_box.{i}"]) and geo.img_box.dtype == np.int16
+        flips += int(geo.flip)
+        # the geometry + Pillow-exact coefficient tables give the reference's crop (numpy emulation of csrc/loader.hip)
+        if img.shape[0] * img.shape[1] <= 50000:
+            cx, bx, _ = resample_coeffs(geo.w, geo.w2)
+            cy, by, _ = resample_coeffs(geo.h, geo.h2)
+            tmp = np.zeros((geo.h, geo.w2, 3), np.uint8)
+            for x in range(geo.w2):
+                x0, n = bx[x]
+                tmp[:, x] = np.clip(((img[:, x0:x0 + n].astype(np.int64) * cx[x, :n][None, :, None]).sum(1) + (1 << 21)) >> 22, 0, 255)
+            res = np.zeros((geo.h2, geo.w2, 3), np.uint8)
+            for y in range(geo.h2):
+                y0, n = by[y]
+                res[y] = np.clip(((tmp[y0:y0 + n].astype(np.int64) * cy[y, :n][:, None, None]).sum(0) + (1 << 21)) >> 22, 0, 255)
+            assert np.array_equal(res, np.asarray(Image.fromarray(img).resize([geo.w2, geo.h2], resample=Image.BILINEAR)))
+            if geo.flip:
+                res = res[:, ::-1]
+            H, W = max(S, geo.h2), max(S, geo.w2)
+            pad = np.zeros((H, W, 3), np.uint8)
+            pad[geo.h_pad:geo.h_pad + geo.h2, geo.w_pad:geo.w_pad + geo.w2] = res
+            assert np.array_equal(pad[geo.h_start:geo.h_start + S, geo.w_start:geo.w_start + S], g[f"crop.{i}"])
+    assert 0 < flips < int(g["n_cases"])        # both flip branches are in the fixture
+    assert np.array_equal(O.normalize_img(g["val_ramp"]), g["val_ramp_norm"])
+
+
+def test_epoch_iterator_follows_reference_sampler_protocol():
+    """train_final_voc.py:127,132-133,177-182: DistributedSampler(shuffle=True), set_epoch(np.random.randint(max_iters))
+    before the first pass and at every restart, a fresh iterator when the loader runs dry.  5 items, batch 2, drop_last:
+    2 batches per epoch; 7 iterations span 4 epochs, every epoch a permutation drawn from ITS set_epoch value."""
+    import torch
+    from torch.utils.data import DataLoader, Dataset
+    from torch.utils.data.distributed import DistributedSampler
+    from dupl_amd.train_main import _EpochIterator
+
+    class Five(Dataset):
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return i
+
+    ds = Five()
+    sampler = DistributedSampler(ds, num_replicas=1, rank=0, shuffle=True)
+    epochs = []
+    orig = sampler.set_epoch
+    sampler.set_epoch = lambda e: (epochs.append(int(e)), orig(e))[1]
+    loader = DataLoader(ds, batch_size=2, shuffle=False, drop_last=True, sampler=sampler)
+    np.random.seed(0)
+    it = _EpochIterator(loader, max_iters=20000)
+    seen = [it.next().tolist() for _ in range(7)]
+    np.random.seed(0)
+    want_epochs = [int(np.random.randint(20000)) for _ in range(4)]
+    assert epochs == want_epochs and it.epochs == 4
+    for e, ep in enumerate(want_epochs):
+        gen = torch.Generator()
+        gen.manual_seed(ep)                       # DistributedSampler: seed (0) + epoch
+        perm = torch.randperm(5, generator=gen).tolist()
+        got = sum(seen[2 * e:2 * e + 2], [])
+        assert got == perm[:len(got)], (e, got, perm)
+    # a one-shot generator cannot be restarted: loud error instead of StopIteration escaping the training loop
+    one = _EpochIterator((x for x in [1]), max_iters=10)
+    assert one.next() == 1
+    with pytest.raises(RuntimeError, match="empty after a restart"):
+        one.next()

@@ -122,6 +122,37 @@ def test_bench_contract_line(dev):
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert 0.3 < rf["frac"] < 1.0 and d["value"] > 10.0
+    # roofline.traffic is only quoted from a PMC summary tagged with THIS build's kernel-source digest
+    from dupl_amd.build import source_digest
+    assert rf["csrc_sha256"] == source_digest()[:16] and "traffic_source" in rf
+    if rf["traffic"] is None:
+        assert "stale" in rf["traffic_source"] or "no PMC summary" in rf["traffic_source"], rf["traffic_source"]
+    else:
+        assert rf["traffic"] > rf["algorithmic_bytes_per_launch"] * 0.5
+    # a 1-GPU line carries the exchange fields too (no exchange: zeros), N = 1 runs BASELINE configs[1]
+    cm = d["comm"]
+    assert cm["world"] == 1 and cm["backend"] == "none" and cm["allreduce_bytes"] == 0 and cm["comm_exposed_ms"] == 0.0
+    assert cm["grad_bytes_per_rank"] > 7.0e8 and d["weak_4img_per_gpu"] is None
+    assert d["config"]["baseline_config"] == "configs[1]" and d["config"]["img_per_gpu"] == 4
+
+
+def test_bench_stale_pmc_profile_is_refused(tmp_path):
+    """bench.pmc_traffic_per_launch: a summary whose csrc_sha256 tag is missing or differs from the build's -> None."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from dupl_amd.build import source_digest
+    row = "gemm_f32_kernel<false, false, 64, 1, 2>   10   1.0   1000   500\n"
+    good, stale, untagged = tmp_path / "good.txt", tmp_path / "stale.txt", tmp_path / "untagged.txt"
+    good.write_text(f"# tag: t\n# csrc_sha256: {source_digest()}\n# git_head: abc\nkernel calls ms FETCH_SIZE WRITE_SIZE\n" + row)
+    stale.write_text("# tag: t\n# csrc_sha256: " + "0" * 64 + "\n" + row)
+    untagged.write_text(row)
+    v, why = bench.pmc_traffic_per_launch(str(good))
+    assert v == round((2 * 1000 + 500) * 1024 / 10) and "tag t" in why
+    assert bench.pmc_traffic_per_launch(str(stale))[0] is None and "stale" in bench.pmc_traffic_per_launch(str(stale))[1]
+    assert bench.pmc_traffic_per_launch(str(untagged))[0] is None
+    assert bench.pmc_traffic_per_launch(str(tmp_path / "absent.txt"))[0] is None
 
 
 def test_ddp_two_ranks_on_one_gpu_gloo(dev, tmp_path):
@@ -216,14 +247,25 @@ def test_bench_multi_rank_control_flow(dev):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DUPL_BENCH_RANKS_SHARE_GPU0="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "1", "--backend", "gloo", "--cpu-baseline", "skip"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+           "--backend", "gloo", "--cpu-baseline", "skip", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
-    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 0.05 * d["value"] and d["cpu_baseline"] is None
+    # N = 2 defaults to BASELINE configs[2]: VOC, 2 img/GPU (global batch 4)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["img_per_gpu"] == 2
+    assert d["config"]["baseline_config"] == "configs[2]" and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) < 0.05 * d["value"] and d["cpu_baseline"] is None
+    # the line explains its own exchange: backend, world, bytes all-reduced per step (= the trainable gradient range of
+    # both students), how many calls, and the communication time the overlap left exposed
+    cm = d["comm"]
+    assert cm["world"] == 2 and cm["backend"] == "gloo" and cm["allreduce_bytes"] == cm["grad_bytes_per_rank"] > 7.0e8
+    assert cm["allreduce_calls"] >= 16 and cm["comm_exposed_ms"] >= 0.0
+    # second field: the N = 1 workload (VOC, 4 img/GPU) on both ranks = the weak-scaling point
+    w4 = d["weak_4img_per_gpu"]
+    assert w4 is not None and w4["comm"]["world"] == 2 and "4 img/GPU" in w4["workload"]
+    assert abs(w4["value"] - 8 * 1000.0 / w4["ms_per_step"]) < 0.05 * w4["value"]
 
 
 def test_train_loop_with_external_loaders(dev, tmp_path):
