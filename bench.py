@@ -38,7 +38,14 @@ FLOP_SHARED_PASS = 2 * 0.1570e12      # the scale-1.0 un-flipped ms-CAM encoder 
 FLOP_PHASE_C_AUG = 6 * (0.0828e12 + 0.0052e12)   # phase C: fwd+bwd of both students on the 336^2 strong-aug batch
 FLOP_PHASE_C_DEAD = 4 * (0.1570e12 + 0.0093e12)  # phase C: the reference's discarded 2b forward (never executed here)
 PEAK_F32_MFMA = 157.3e12              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (f32 in / f32 acc)
+PEAK_F16_MFMA = 2500e12               # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
+KERNEL_F16X3 = ("gemm_f16x3_kernel (csrc/gemm_split.hip): every Linear forward as an fp32-equivalent split product -- operands as "
+                "fp16 hi / lo planes, 3 v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulate; peak = dense f16 MFMA peak / 3")
+KERNEL_F32 = "gemm_f32_kernel<false,false,...> (v_mfma_f32_32x32x2_f32; every Linear forward, all tile instantiations)"
 
+DTYPE = {"f16x3": "f32 storage / accumulation / results; forward Linear GEMMs as fp32-equivalent f16x3 split products on the f16 MFMA "
+                  "(error vs fp64 <= the f32 MFMA kernel's); attention, backward GEMMs and everything else in f32",
+         "f32": "f32"}
 CONFIG_BY_N = {1: ("voc", 4, "deit_base_patch16_224", "configs[1]"),
                2: ("voc", 2, "deit_base_patch16_224", "configs[2]"),
                4: ("coco", 2, "deit_base_patch16_224", "configs[3]"),
@@ -199,45 +206,51 @@ def pmc_traffic_per_launch(path, kernel_prefix="gemm_f32_kernel<false, false"):
 
 
 class GemmTimer:
-    """Event-pairs around every launch of the dominant kernel (the k-contiguous x k-contiguous 'NT' GEMM that every
-    forward Linear maps to) on the stream it is launched on, plus its algorithmic FLOPs (2*M*N*K per launch)."""
+    """Event-pairs around every launch of the dominant kernel -- the k-contiguous x k-contiguous 'NT' GEMM that every
+    forward Linear maps to: dupl_gemm_f16x3 (f16x3 mode) or the NT instantiation of dupl_gemm_f32 (f32 mode) -- on the
+    stream it is launched on, plus its algorithmic FLOPs (2*M*N*K per launch)."""
 
     def __init__(self):
-        self.pairs = []
-        self.flops = 0.0
-        self.bytes = 0.0
-        self.n = 0
+        self.pairs = {"f16x3": [], "f32": []}
+        self.flops = {"f16x3": 0.0, "f32": 0.0}
+        self.bytes = {"f16x3": 0.0, "f32": 0.0}
+
+    def _timed(self, kind, fn, M, N, K, batch=1):
+        s = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        r = fn()
+        e1.record(s)
+        self.pairs[kind].append((e0, e1))
+        self.flops[kind] += 2.0 * M * N * K * batch
+        self.bytes[kind] += 4.0 * (M * K + N * K + M * N) * batch      # two fp16 planes = 4 bytes per element as well
+        return r
 
     def install(self):
         from dupl_amd import ops
-        self._orig = ops.gemm_raw
+        self._orig, self._orig16 = ops.gemm_raw, ops.linear16
         timer = self
 
         def timed(A, B, C, M, N, K, lda, ldb, ldc, **kw):
-            fl = kw.get("flags", 0)
-            if fl & 3:    # other operand layouts = other kernel instantiations
+            if kw.get("flags", 0) & 3:    # other operand layouts = other kernel instantiations
                 return timer._orig(A, B, C, M, N, K, lda, ldb, ldc, **kw)
-            s = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s)
-            r = timer._orig(A, B, C, M, N, K, lda, ldb, ldc, **kw)
-            e1.record(s)
-            timer.pairs.append((e0, e1))
-            timer.flops += 2.0 * M * N * K * kw.get("batch", 1)
-            timer.bytes += 4.0 * (M * K + N * K + M * N) * kw.get("batch", 1)
-            timer.n += 1
-            return r
+            return timer._timed("f32", lambda: timer._orig(A, B, C, M, N, K, lda, ldb, ldc, **kw), M, N, K, kw.get("batch", 1))
 
-        ops.gemm_raw = timed
+        def timed16(x, W, *a, **kw):
+            return timer._timed("f16x3", lambda: timer._orig16(x, W, *a, **kw), x.rows, W.rows, x.cols)
+
+        ops.gemm_raw, ops.linear16 = timed, timed16
 
     def remove(self):
         from dupl_amd import ops
-        ops.gemm_raw = self._orig
+        ops.gemm_raw, ops.linear16 = self._orig, self._orig16
 
     def result(self):
+        """(kind, ms, flops, launches, bytes) of the kind with the larger total time."""
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
-        return ms, self.flops, self.n, self.bytes
+        ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.pairs.items()}
+        kind = max(ms, key=ms.get)
+        return kind, ms[kind], self.flops[kind], len(self.pairs[kind]), self.bytes[kind]
 
 
 def log(msg):
@@ -350,6 +363,8 @@ def main():
     listed = (dataset, batch, backbone) == (d_ds, d_b, d_bb)
     n_iter = args.n_iter if args.n_iter is not None else DEFAULT_N_ITER[dataset]
 
+    from dupl_amd import engine
+    gemm_mode = engine.GEMM_MODE
     wl = Workload(args, world, rank, local, dataset, batch, backbone, n_iter)
     res = wl.measure("main")
     ms, imgs_per_s, phase, C = res["ms"], res["value"], wl.phase, wl.C
@@ -363,24 +378,29 @@ def main():
         timer = GemmTimer()
         timer.install()
         wl.step(args.warmup + args.steps + 1)
-        gms, gflops, gn, gbytes = timer.result()
+        kind, gms, gflops, gn, gbytes = timer.result()
         timer.remove()
         if not args.single_stream:
             wl.model.enable_dual_stream(True)
         ach = gflops / (gms * 1e-3)
-        traffic, tnote = pmc_traffic_per_launch(args.pmc_profile) if (dataset, batch) == ("voc", 4) else \
+        if kind == "f16x3":
+            # one fp32-equivalent multiply-add costs 3 f16 MFMA products (hi*hi, hi*lo, lo*hi): the roofline of the
+            # ALGORITHMIC flops is the dense f16 MFMA peak / 3
+            peak, kname, prefix = PEAK_F16_MFMA / 3.0, KERNEL_F16X3, "gemm_f16x3_kernel"
+        else:
+            peak, kname, prefix = PEAK_F32_MFMA, KERNEL_F32, "gemm_f32_kernel<false, false"
+        traffic, tnote = pmc_traffic_per_launch(args.pmc_profile, prefix) if (dataset, batch) == ("voc", 4) else \
             (None, "the committed PMC passes are of the VOC 4 img/GPU workload")
-        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<false,false,...> (v_mfma_f32_32x32x2_f32; every Linear forward, all tile instantiations)",
-                "achieved": round(ach / 1e12, 2),
-                "peak": round(PEAK_F32_MFMA / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4),
+        roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach / 1e12, 2),
+                "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_source": tnote, "csrc_sha256": csrc_digest()[:16],
                 "algorithmic_bytes_per_launch": round(gbytes / max(gn, 1)),
                 "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
                 "kernel_share_of_step": round(gms / ms, 3),
-                "step_frac_of_peak": round(imgs_per_s / world * flop_exec / PEAK_F32_MFMA, 4),
                 "step_flop_per_img": {"reference_algorithm": flop_ref, "executed": flop_exec},
+                "step_algorithmic_tflops": round(imgs_per_s / world * flop_exec / 1e12, 1),
                 "note": "HIP event pairs around every launch of the kernel during one extra step run right after the timed "
-                        "region (same stream, same workload); algorithmic flops = 2*M*N*K per launch"}
+                        "region (same stream, same workload); algorithmic flops = 2*M*N*K per launch (fp32-equivalent)"}
 
     weak4 = None
     if world > 1 and not args.no_weak4 and (dataset, batch) != ("voc", 4):
@@ -402,14 +422,14 @@ def main():
         rec = {"metric": f"training img/s at 448^2, {'VOC' if dataset == 'voc' else 'COCO'} dual-student ViT-B/16, phase {phase} step",
                "value": round(imgs_per_s, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": DTYPE[gemm_mode], "data": "synthetic",
                "config": {"workload": (f"VOC2012 {args.size}^2" if dataset == "voc" else f"MSCOCO2014 {args.size}^2") +
                                       f" dual-student {backbone} + ms-CAM(1.0,0.5,1.5) + PAR + cross seg loss, phase {phase}, "
                                       f"{batch} img/GPU, DDP world_size={world}",
                           "baseline_config": d_cfg if listed else "custom (--dataset/--batch/--backbone)",
                           "global_batch": world * batch, "img_per_gpu": batch, "num_classes": C + 1,
                           "n_iter": n_iter, "parallelism": f"dp{world}", "student_streams": 1 if args.single_stream else 2,
-                          "shared_scale1_encoder_pass": not args.no_share_encoder,
+                          "shared_scale1_encoder_pass": not args.no_share_encoder, "forward_gemm": gemm_mode,
                           "loss": round(res["loss"], 5)},
                "comm": res["comm"], "weak_4img_per_gpu": weak4,
                "roofline": roof, "cpu_baseline": cpu}

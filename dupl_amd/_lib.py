@@ -32,6 +32,19 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class Gemm16Desc(ctypes.Structure):
+    """Mirror of `dupl_gemm16_desc` (include/dupl_hip.h): operands as fp16 hi / lo planes."""
+    _fields_ = [
+        ("A_hi", ctypes.c_void_p), ("A_lo", ctypes.c_void_p), ("B_hi", ctypes.c_void_p), ("B_lo", ctypes.c_void_p),
+        ("C", ctypes.c_void_p), ("C_hi", ctypes.c_void_p), ("C_lo", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p), ("aux", ctypes.c_void_p),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("ldo", ctypes.c_int32),
+        ("ldr", ctypes.c_int32), ("ldaux", ctypes.c_int32),
+        ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
 GEMM_A_MCONTIG, GEMM_B_NCONTIG, GEMM_GELU, GEMM_ACCUM = 1, 2, 4, 8
 GEMM_MUL_DGELU, GEMM_RELU, GEMM_MUL_RELUMASK, GEMM_ABS, GEMM_STORE_PRE = 16, 32, 64, 128, 256
 
@@ -42,6 +55,8 @@ def _ctype(decl: str):
     d = decl.strip()
     if d == "void" or not d:
         return None
+    if "dupl_gemm16_desc" in d:
+        return ctypes.POINTER(Gemm16Desc)
     if "dupl_gemm_desc" in d:
         return ctypes.POINTER(GemmDesc)
     if "*" in d or d.startswith("dupl_stream_t"):

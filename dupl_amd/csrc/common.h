@@ -1,6 +1,7 @@
 // Shared device helpers for the DuPL gfx950 kernels.  CDNA4 only: wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 #define DUPL_OK 0
@@ -89,4 +90,12 @@ __device__ __forceinline__ void atomic_max_f(float* addr, float v) {
 __device__ __forceinline__ void atomic_min_f(float* addr, float v) {
     if (v >= 0.f) atomicMin((int*)addr, __float_as_int(v));
     else atomicMax((unsigned int*)addr, __float_as_uint(v));
+}
+
+// f16x3 operand split (gemm_split.hip): x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048); saturating
+constexpr float DUPL_LO_SCALE = 2048.f;
+__device__ __forceinline__ void split_f32(float x, __half& hi, __half& lo) {
+    x = fminf(fmaxf(x, -65504.f), 65504.f);
+    hi = __float2half_rn(x);
+    lo = __float2half_rn((x - __half2float(hi)) * DUPL_LO_SCALE);
 }

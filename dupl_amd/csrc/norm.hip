@@ -11,7 +11,8 @@ template <int LN_MAXC>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                            long rows, int D, float eps) {
+                                                            long rows, int D, float eps, __half* __restrict__ y_hi,
+                                                            __half* __restrict__ y_lo) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -39,7 +40,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float rstd = 1.0f / sqrtf(var + eps);
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
-    float4* yr = reinterpret_cast<float4*>(y + row * D);
+    float4* yr = y ? reinterpret_cast<float4*>(y + row * D) : nullptr;
+    uint2* hr = y_hi ? reinterpret_cast<uint2*>(y_hi + row * D) : nullptr;   // f16x3 operand planes of the output
+    uint2* lr = y_hi ? reinterpret_cast<uint2*>(y_lo + row * D) : nullptr;
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
@@ -50,7 +53,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z;
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            yr[c] = o;
+            if (yr) yr[c] = o;
+            if (hr) {
+                __half h[4], l[4];
+                split_f32(o.x, h[0], l[0]);
+                split_f32(o.y, h[1], l[1]);
+                split_f32(o.z, h[2], l[2]);
+                split_f32(o.w, h[3], l[3]);
+                hr[c] = *reinterpret_cast<uint2*>(h);
+                lr[c] = *reinterpret_cast<uint2*>(l);
+            }
         }
     }
     if (lane == 0) {
@@ -181,10 +193,18 @@ inline int ew_grid(long n) {
 extern "C" int dupl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                   float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
-    if (!x || !gamma || !beta || !y || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256) return DUPL_ERR_ARG;
+    return dupl_layernorm_fwd16(x, gamma, beta, y, nullptr, nullptr, mean, rstd, rows, D, eps, s);
+}
+
+extern "C" int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
+                                    float* mean, float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s) {
+    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
+    if (!x || !gamma || !beta || (!y && !y_hi) || ((y_hi == nullptr) != (y_lo == nullptr)) || rows <= 0 || D <= 0 || (D & 3) ||
+        D > LN_MAXC_LIMIT * 256)
+        return DUPL_ERR_ARG;
     const int grid = (int)((rows + 3) / 4);
 #define LN_FWD(MC) hipLaunchKernelGGL(layernorm_fwd_kernel<MC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, gamma, beta, y, \
-                                      mean, rstd, (long)rows, D, eps)
+                                      mean, rstd, (long)rows, D, eps, (__half*)y_hi, (__half*)y_lo)
     if (D <= 256) LN_FWD(1);
     else if (D <= 768) LN_FWD(3);
     else if (D <= 1024) LN_FWD(4);

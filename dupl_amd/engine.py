@@ -13,6 +13,7 @@ Reference behaviour mirrored (paths relative to the reference):
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -21,6 +22,18 @@ import torch
 from . import ops
 
 Tensor = torch.Tensor
+
+# Forward Linear layers of the encoder: "f16x3" (default) = the fp32-equivalent split GEMM on the f16 matrix cores
+# (csrc/gemm_split.hip: 3 f16 MFMAs per block, operands as fp16 hi / lo planes written by the producing kernels; closer to
+# an fp64-accumulated reference than the fp32 fmaf chain, every parity test holds in either mode), "f32" = the exact-f32
+# MFMA kernel (csrc/gemm.hip; DUPL_GEMM=f32 or set_gemm_mode).  Backward GEMMs and attention always run on f32 kernels.
+GEMM_MODE = os.environ.get("DUPL_GEMM", "f16x3")
+
+
+def set_gemm_mode(mode: str):
+    global GEMM_MODE
+    assert mode in ("f32", "f16x3"), mode
+    GEMM_MODE = mode
 
 
 @dataclass(frozen=True)
@@ -120,7 +133,7 @@ class FlatStorage:
                 for d in shp:
                     n *= d
                 self.layout[k] = (off, n)
-                off += (n + 3) // 4 * 4   # 16-byte alignment of every tensor
+                off += (n + 7) // 8 * 8   # 32-byte alignment of every tensor (16 bytes in the fp16 operand planes)
             self.seg_bounds.append((start, off))
         self.student_numel = off
         self.data = torch.zeros(n_students * off, dtype=torch.float32, device=device)
@@ -128,6 +141,12 @@ class FlatStorage:
         # sticky "this segment has received a gradient at least once" flags == torch's `p.grad is None` skip
         self.seg_has_grad = [[False] * 5 for _ in range(n_students)]
         self.streams: List = []     # side streams the students run on (siamese_network.enable_dual_stream)
+        # f16x3 operand planes of the parameters (ops.Split16 format, csrc/gemm_split.hip): [2, n_students * numel] fp16,
+        # refreshed per student when its key (torch version counter of the flat buffer, `dirty` bumped by raw-pointer
+        # writers such as the optimiser kernel, buffer address) changes
+        self.data16: Optional[Tensor] = None
+        self.dirty = 0
+        self._w16_key = [None] * n_students
 
     def wait_streams(self):
         """Make the current stream wait for everything queued on the student streams."""
@@ -145,6 +164,32 @@ class FlatStorage:
     def apply(self, fn):
         self.data = fn(self.data)
         self.grad = fn(self.grad)
+        self.data16 = None
+        self._w16_key = [None] * self.n_students
+
+    def mark_dirty(self):
+        """To be called by whoever rewrites parameters through raw pointers (the optimiser kernel)."""
+        self.dirty += 1
+
+    def ensure_w16(self, student: int):
+        """Bring the fp16 hi / lo planes of one student's parameters up to date (on the current stream)."""
+        key = (self.data._version, self.dirty, self.data.data_ptr())
+        if self._w16_key[student] == key and self.data16 is not None:
+            return
+        if self.data16 is None or self.data16.device != self.data.device:
+            self.data16 = torch.empty((2, self.data.numel()), device=self.data.device, dtype=torch.float16)
+            self._w16_key = [None] * self.n_students
+        n, base = self.student_numel, student * self.student_numel
+        ops.L().dupl_split_f16x2(self.data.data_ptr() + 4 * base, self.data16.data_ptr() + 2 * base,
+                                 self.data16.data_ptr() + 2 * (self.data.numel() + base), n, ops._stream())
+        self._w16_key[student] = key
+
+    def w16(self, student: int, key: str, rows: int) -> "ops.W16":
+        """Operand planes of parameter `key` viewed as a [rows, numel / rows] matrix."""
+        off, n = self.layout[key]
+        base = student * self.student_numel + off
+        p = self.data16.data_ptr()
+        return ops.W16(p + 2 * base, p + 2 * (self.data.numel() + base), rows, n // rows)
 
     def trainable_range(self, student: int) -> Tuple[int, int]:
         s = student * self.student_numel
@@ -154,7 +199,7 @@ class FlatStorage:
         """[start, end) within a student of transformer block i's tensors in the backbone segment."""
         pre = f"encoder.blocks.{i}."
         offs = [(o, n) for k, (o, n) in self.layout.items() if k.startswith(pre) and param_segment(k) == SEG_BACKBONE]
-        return min(o for o, _ in offs), max((o + n + 3) // 4 * 4 for o, n in offs)
+        return min(o for o, _ in offs), max((o + n + 7) // 8 * 8 for o, n in offs)
 
     def grad_buckets(self, student: int, blocks_per_bucket: int = 2) -> List[Tuple[int, int, object]]:
         """Partition of the student's trainable gradient range into (lo, hi, trigger) buckets in the order the backward
@@ -202,6 +247,9 @@ class StudentParams:
     def mark_grad(self, seg: int):
         self.store.seg_has_grad[self.student][seg] = True
 
+    def w16(self, key: str, rows: int):
+        return self.store.w16(self.student, key, rows)
+
 
 # ------------------------------------------------------------------------------------------------
 # forward
@@ -238,6 +286,8 @@ class EncoderSaved:
 def encoder_forward(P: StudentParams, x: Tensor, save: bool):
     """forward_features (vit.py:308-326).  Returns (tokens_final [B*(1+n), D], tokens_aux [B*(1+n), D], saved).
     tokens_aux = output of block `aux_layer` (un-normalised unless it is the last block)."""
+    if GEMM_MODE == "f16x3":
+        return _encoder_forward16(P, [x], save)[0]
     cfg = P.cfg
     B, _, Himg, Wimg = x.shape
     h, w = Himg // cfg.patch, Wimg // cfg.patch
@@ -277,6 +327,75 @@ def encoder_forward(P: StudentParams, x: Tensor, save: bool):
     return tf, aux, sv
 
 
+def _encoder_forward16(P: StudentParams, xs, save: bool):
+    """forward_features of ONE or SEVERAL batches (different resolutions) with every Linear on the f16x3 split GEMM.
+    Token rows of all batches are concatenated (every row-wise kernel runs once over all of them, attention per batch on
+    its row slice -- the merged ms-CAM pass of cam_logits_multi); with save=True (single batch only) the fp32 copies
+    the hand-written backward consumes are written next to the operand planes.  Data flow per block (fp32 residual
+    stream; `16` = hi / lo fp16 planes, the A operand of the next GEMM, written by the producing kernel):
+        t -LN-> ln1_16 -GEMM-> qkv (fp32) -attention-> att (fp32) -split-> att16 -GEMM + t-> x_mid
+        x_mid -LN-> ln2_16 -GEMM, GELU-> h1_16 -GEMM + x_mid-> t
+    Returns [(tokens_final, tokens_aux, saved)] per batch (row-slice views)."""
+    cfg = P.cfg
+    D, H, hd = cfg.embed_dim, cfg.num_heads, cfg.head_dim
+    W = P.w
+    assert not (save and len(xs) > 1)
+    P.store.ensure_w16(P.student)
+    toks, groups = [], []
+    r0 = 0
+    for x in xs:
+        B, _, Himg, Wimg = x.shape
+        h, w = Himg // cfg.patch, Wimg // cfg.patch
+        n = h * w
+        rows16 = ops.split16(ops.patch_im2row(x, cfg.patch))
+        patch, _ = ops.linear16(rows16, P.w16("encoder.patch_embed.proj.weight", D), W["encoder.patch_embed.proj.bias"])
+        del rows16
+        toks.append(ops.assemble_tokens(patch, W["encoder.cls_token"], P.pos_embed_for(h, w), B, n, D))
+        groups.append((r0, B, n + 1, h, w))
+        r0 += B * (n + 1)
+    t = torch.cat(toks, dim=0) if len(toks) > 1 else toks[0]
+    del toks
+    R = t.shape[0]
+    sv = None
+    if save:
+        _, B, _, h, w = groups[0]
+        sv = EncoderSaved(B=B, h=h, w=w, x_img=xs[0])
+    aux_idx = cfg.aux_layer % cfg.depth
+    aux = None
+    scale = hd ** -0.5
+    for i in range(cfg.depth):
+        p = f"encoder.blocks.{i}."
+        ln1, ln1_16, m1, r1 = ops.layernorm_fwd16(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, save, want_f32=save)
+        qkv, _ = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"])
+        del ln1_16
+        att = torch.empty((R, D), device=t.device, dtype=torch.float32)
+        lse = None
+        for (g0, B, N, _, _) in groups:
+            _, lse = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
+        att16 = ops.split16(att)
+        x_mid, _ = ops.linear16(att16, P.w16(p + "attn.proj.weight", D), W[p + "attn.proj.bias"], res=t)
+        del att16
+        ln2, ln2_16, m2, r2 = ops.layernorm_fwd16(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save, want_f32=save)
+        pre1 = torch.empty((R, D * cfg.mlp_ratio), device=t.device, dtype=torch.float32) if save else None
+        h1, h1_16 = ops.linear16(ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio), W[p + "mlp.fc1.bias"], gelu=True,
+                                 store_pre=pre1, want_f32=save, want16=True)
+        del ln2_16
+        x_out, _ = ops.linear16(h1_16, P.w16(p + "mlp.fc2.weight", D), W[p + "mlp.fc2.bias"], res=x_mid)
+        del h1_16
+        if save:
+            sv.blocks.append(BlockSaved(x_in=t, mean1=m1, rstd1=r1, ln1=ln1, qkv=qkv, lse=lse, att=att, x_mid=x_mid,
+                                        mean2=m2, rstd2=r2, ln2=ln2, pre1=pre1, h1=h1))
+        t = x_out
+        if i == aux_idx and i != cfg.depth - 1:
+            aux = t
+    tf, mf, rf = ops.layernorm_fwd(t, W["encoder.norm.weight"], W["encoder.norm.bias"], cfg.ln_eps, save)
+    if save:
+        sv.x_last, sv.mean_f, sv.rstd_f = t, mf, rf
+    if aux is None:
+        aux = tf
+    return [(tf[g0:g0 + B * N], aux[g0:g0 + B * N], sv) for (g0, B, N, _, _) in groups]
+
+
 def cam_logits(P: StudentParams, x: Tensor):
     """cam_only path (model_dupl.py:81-84), token-major: returns (cam_aux_tok, cam_tok), each
     [B*(1+n), C] (row 0 of every image is the cls token and must be skipped), plus (h, w)."""
@@ -297,6 +416,20 @@ def cam_logits_multi(P: StudentParams, xs):
     cfg = P.cfg
     D, H, hd = cfg.embed_dim, cfg.num_heads, cfg.head_dim
     W = P.w
+    if GEMM_MODE == "f16x3":
+        C = P.num_classes - 1
+        outs = _encoder_forward16(P, list(xs), save=False)
+        # the CAM heads (N = C columns) stay on the f32 kernel: one launch over the concatenated rows of all batches
+        tf_all = torch.cat([o[0] for o in outs], dim=0) if len(outs) > 1 else outs[0][0]
+        aux_all = torch.cat([o[1] for o in outs], dim=0) if len(outs) > 1 else outs[0][1]
+        cam = ops.linear(tf_all, W["classifier.weight"].view(C, -1))
+        cam_aux = ops.linear(aux_all, W["aux_classifier.weight"].view(C, -1))
+        res, g0 = [], 0
+        for o in outs:
+            r = o[0].shape[0]
+            res.append((cam_aux[g0:g0 + r], cam[g0:g0 + r]))
+            g0 += r
+        return res
     toks, groups = [], []
     r0 = 0
     for x in xs:

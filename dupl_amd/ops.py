@@ -58,6 +58,88 @@ def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int,
     L().dupl_gemm_f32(ctypes.byref(d), _stream())
 
 
+# ------------------------------------------------------------------------------------------ f16x3 split GEMM
+class Split16:
+    """A matrix as two fp16 planes (hi, lo*2048): the operand format of dupl_gemm_f16x3 (csrc/gemm_split.hip).
+    `planes` is one [2, rows, cols] fp16 tensor (plane 0 = hi, plane 1 = lo)."""
+    __slots__ = ("planes", "rows", "cols")
+
+    def __init__(self, planes: Tensor):
+        assert planes.dtype == torch.float16 and planes.dim() == 3 and planes.shape[0] == 2 and planes.is_contiguous()
+        self.planes, self.rows, self.cols = planes, planes.shape[1], planes.shape[2]
+
+    @property
+    def hi(self) -> int:
+        return self.planes.data_ptr()
+
+    @property
+    def lo(self) -> int:
+        return self.planes.data_ptr() + 2 * self.rows * self.cols
+
+    def rows_slice(self, r0: int, r1: int) -> "Split16View":
+        return Split16View(self, r0, r1)
+
+
+class Split16View:
+    """Row range [r0, r1) of a Split16 (both planes), as an A operand."""
+    __slots__ = ("hi", "lo", "rows", "cols", "base")
+
+    def __init__(self, base: Split16, r0: int, r1: int):
+        self.base = base
+        self.hi = base.hi + 2 * r0 * base.cols
+        self.lo = base.lo + 2 * r0 * base.cols
+        self.rows, self.cols = r1 - r0, base.cols
+
+
+class W16:
+    """Raw operand planes (pointers) of a [rows, cols] matrix living in someone else's buffer (parameter planes)."""
+    __slots__ = ("hi", "lo", "rows", "cols")
+
+    def __init__(self, hi: int, lo: int, rows: int, cols: int):
+        self.hi, self.lo, self.rows, self.cols = hi, lo, rows, cols
+
+
+def split16_empty(rows: int, cols: int, device) -> Split16:
+    return Split16(torch.empty((2, rows, cols), device=device, dtype=torch.float16))
+
+
+def split16(x: Tensor, out: Optional[Split16] = None) -> Split16:
+    """fp32 [rows, cols] (contiguous, cols % 4 == 0) -> hi / lo planes."""
+    _chk(x)
+    rows, cols = x.shape[0], x.numel() // x.shape[0]
+    out = out if out is not None else split16_empty(rows, cols, x.device)
+    L().dupl_split_f16x2(x.data_ptr(), out.hi, out.lo, x.numel(), _stream())
+    return out
+
+
+def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False, relu: bool = False,
+             res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None,
+             want_f32: bool = True, out16: Optional[Split16] = None, want16: bool = False, device=None):
+    """y = act(x W^T + bias) (+ res) on the f16x3 split GEMM.  x: Split16 / Split16View [M, K]; W: Split16 [N, K].
+    Returns (y fp32 [M, N] or None, y as Split16 or None)."""
+    M, K, N = x.rows, x.cols, W.rows
+    assert W.cols == K and K % 32 == 0
+    dev = device if device is not None else (x.planes.device if isinstance(x, Split16) else x.base.planes.device)
+    y = None
+    if want_f32 or out is not None:
+        y = out if out is not None else torch.empty((M, N), device=dev, dtype=torch.float32)
+    y16 = out16 if out16 is not None else (split16_empty(M, N, dev) if want16 else None)
+    d = _lib.Gemm16Desc()
+    d.A_hi, d.A_lo, d.B_hi, d.B_lo = x.hi, x.lo, W.hi, W.lo
+    d.C = _p(y)
+    d.C_hi, d.C_lo = (y16.hi, y16.lo) if y16 is not None else (None, None)
+    d.bias, d.res, d.aux = _p(bias), _p(res), _p(store_pre)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb = K, K
+    d.ldc = y.stride(0) if y is not None else 0
+    d.ldo = N
+    d.ldr = res.stride(0) if res is not None else 0
+    d.ldaux = store_pre.stride(0) if store_pre is not None else 0
+    d.flags = (_lib.GEMM_GELU if gelu else 0) | (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_STORE_PRE if store_pre is not None else 0)
+    L().dupl_gemm_f16x3(ctypes.byref(d), _stream())
+    return y, y16
+
+
 def linear(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, gelu: bool = False, relu: bool = False,
            res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None) -> Tensor:
     """y[M,N] = act(x[M,K] @ W[N,K]^T + bias) + res     (nn.Linear / 1x1 conv forward).
@@ -119,6 +201,21 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bool
     L().dupl_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _p(mean), _p(rstd), rows, D,
                            eps, _stream())
     return y, mean, rstd
+
+
+def layernorm_fwd16(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bool = False, want_f32: bool = False):
+    """LayerNorm whose output goes out as f16x3 operand planes (and as fp32 too when want_f32, e.g. saved for backward).
+    Returns (y fp32 or None, y16 Split16, mean, rstd)."""
+    rows, D = x.shape
+    y = torch.empty_like(x) if want_f32 else None
+    y16 = split16_empty(rows, D, x.device)
+    mean = rstd = None
+    if save:
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    L().dupl_layernorm_fwd16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y), y16.hi, y16.lo, _p(mean), _p(rstd), rows, D,
+                             eps, _stream())
+    return y, y16, mean, rstd
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor,

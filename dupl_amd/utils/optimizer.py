@@ -100,4 +100,5 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
                 sl = slice(base + lo, base + hi)
                 adamw_segment(store.data[sl], store.grad[sl], m[sl], v[sl], steps[s][seg], grp["lr"], b1, b2, grp["eps"],
                               grp["weight_decay"])
+        store.mark_dirty()       # parameters were rewritten through raw pointers: their f16x3 operand planes are stale
         self.global_step += 1

@@ -57,6 +57,34 @@ typedef struct dupl_gemm_desc {
 } dupl_gemm_desc;
 /* the GEMM described above (vit.py:92-136, model_dupl.py:82-95, conv_head.py:32-41, losses.py:12 and their autograd) */
 int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * fp32-equivalent GEMM on the f16 matrix cores by operand splitting (csrc/gemm_split.hip):
+ *   x = hi + lo/2048 with hi = fp16(x), lo = fp16((x - hi) * 2048);  a*b ~= hi_a hi_b + (hi_a lo_b + lo_a hi_b)/2048,
+ * fp32 accumulation, 3 v_mfma_f32_32x32x16_f16 per 32x32x16 block.  Same reference sites as dupl_gemm_f32 for the
+ * k-contiguous x k-contiguous case (every nn.Linear forward: vit.py:92-102,115-122,136).  Operands are passed as two
+ * fp16 planes each ([rows][ld] halfs); the result can be written as fp32 and / or as planes (the next GEMM's A operand).
+ *   C = act(A . B^T + bias) (+ res);   flags: DUPL_GEMM_GELU | DUPL_GEMM_RELU | DUPL_GEMM_STORE_PRE (aux = pre-activation)
+ * K % 32 == 0; lda / ldb in halfs, multiples of 8; plane pointers 16-byte aligned. */
+typedef struct dupl_gemm16_desc {
+    const void* A_hi; const void* A_lo;   /* [M][lda] fp16 */
+    const void* B_hi; const void* B_lo;   /* [N][ldb] fp16 */
+    float* C;                             /* [M][ldc] fp32 or NULL */
+    void* C_hi; void* C_lo;               /* [M][ldo] fp16 planes of the result, or both NULL */
+    const float* bias;                    /* [N] or NULL */
+    const float* res;                     /* [M][ldr] or NULL, added after the activation */
+    float* aux;                           /* [M][ldaux], written when DUPL_GEMM_STORE_PRE */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldo, ldr, ldaux;
+    int32_t flags;
+    int32_t reserved;
+} dupl_gemm16_desc;
+int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream);
+/* the operand split of the GEMM above: n fp32 values (n % 4 == 0) -> hi / lo fp16 planes (no reference counterpart) */
+int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, dupl_stream_t stream);
+/* tuning knob: row-tiles per group of the block order of dupl_gemm_f16x3 */
+int dupl_set_gemm16_group(int32_t gm);
+/* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 1 128x128, 2 256x128 on 8 waves, 3 128x64, 4 64x128) */
+int dupl_set_gemm16_tile(int32_t t);
 /* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
 int dupl_set_gemm_tile(int32_t rows);
 /* tuning knob (no reference counterpart): column tile of the 64-row GEMM kernels, 64 or 128 (0 = heuristic on the grid) */
@@ -73,6 +101,10 @@ int dupl_set_gemm_group(int32_t gm);
  *      dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (atomic accumulate: zero them first). */
 int dupl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s);
+/* the same LayerNorm writing its output (also / only) as f16x3 operand planes y_hi / y_lo [rows][D] fp16 for
+ * dupl_gemm_f16x3 (y may be NULL when only the planes are wanted; y_hi / y_lo both NULL = dupl_layernorm_fwd) */
+int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
+                         float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s);
 /* LayerNorm backward (autograd of vit.py:157,159,323), optionally fused with the residual-stream gradient add */
 int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,

@@ -58,9 +58,20 @@ def test_tiny_ms_cam_matches_reference(dev, golden_dir, tiny_student):
     assert d1 < 2e-5 and d2 < 2e-5      # what the exact-fp32 MFMA path actually delivers
 
 
+@pytest.fixture
+def gemm_mode(request):
+    """Run a test with the encoder's forward Linears on the named GEMM path (f16x3 split = product default, f32 = exact)."""
+    from dupl_amd import engine
+    prev = engine.GEMM_MODE
+    engine.set_gemm_mode(request.param)
+    yield request.param
+    engine.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("gemm_mode", ["f16x3", "f32"], indirect=True)
 @pytest.mark.parametrize("dual", [False, True], ids=["one-stream", "two-streams"])
 @pytest.mark.parametrize("tag", ["A", "B"])
-def test_tiny_train_step_matches_reference(dev, golden_dir, tag, dual):
+def test_tiny_train_step_matches_reference(dev, golden_dir, tag, dual, gemm_mode):
     from dupl_amd.model.model_dupl import siamese_network
     from dupl_amd.model.PAR import PAR
     from dupl_amd import trainer
@@ -156,9 +167,9 @@ def test_cam_with_grad_matches_reference(dev, golden_dir):
         ref = g[k]
         if ref.shape != got.shape:
             got = got.reshape(-1)[::7]
-        # floor 1e-5: the gradient of encoder.norm.bias through a min/max-normalised CAM alone (branch 2) is zero up to
-        # round-off (2e-7) -- a per-channel offset nearly cancels in (cam - min) / max
-        worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-5)))
+        # floor 1e-3 (the typical gradient tensor here has max 1e-2 .. 1): the gradient of encoder.norm.bias through a
+        # min/max-normalised CAM alone (branch 2) is zero up to round-off (2e-7): a per-channel offset nearly cancels
+        worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3)))
         nchk += 1
     print(f"cam_with_grad: {nchk} gradient tensors, worst rel err {worst:.2e}")
     assert nchk >= 100 and worst < 2e-3
@@ -401,8 +412,10 @@ def test_single_student_gradients_vs_oracle_autograd(dev, S, second):
     assert worst < 2e-5, worst
 
 
-@pytest.mark.parametrize("case", ["voc_B", "coco_B2", "voc_C", "voc_B_bs4", "coco_B2_bs2_vit21k"])
-def test_full_size_vitb_step_vs_oracle(dev, case):
+@pytest.mark.parametrize("gemm_mode,case", [("f16x3", "voc_B"), ("f16x3", "coco_B2"), ("f16x3", "voc_C"), ("f16x3", "voc_B_bs4"),
+                                            ("f16x3", "coco_B2_bs2_vit21k"), ("f32", "voc_B"), ("f32", "voc_B_bs4")],
+                         indirect=["gemm_mode"])
+def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     """BASELINE configs at FULL size: dual-student ViT-B/16, 448^2 -- the whole step (ms-CAM at three scales, dual
     forward/backward, PAR refinement, all losses; voc_C adds the on-device RandAugment view, the 336^2 aug
     forward/backward, the GMM filter and the consistency loss; coco_B2 has 81 classes and the COCO schedule) against the
@@ -411,7 +424,8 @@ def test_full_size_vitb_step_vs_oracle(dev, case):
     instantiations); coco_B2_bs2_vit21k is the per-GPU batch of configs[3]/[4] (2 images, 81 classes) built through the
     `vit_base_patch16_224` factory of configs[4].  Bars: CAM max-abs-diff < 1e-3 (north_star), identical pseudo-label
     maps, refined label maps identical except at PROVEN argmax ties (oracle decision margin < 1e-5 at every
-    mismatching pixel), loss pieces 1e-4, gradients of a spread of tensors 2e-3."""
+    mismatching pixel), loss pieces 1e-4, gradients of a spread of tensors 2e-3.  gemm_mode: the forward Linears on the
+    f16x3 split GEMM (product default) or on the exact-f32 MFMA kernel -- the same bars hold for both."""
     import random
     from dupl_amd.model.model_dupl import siamese_network
     from dupl_amd.model.PAR import PAR

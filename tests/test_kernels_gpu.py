@@ -527,3 +527,56 @@ def test_gmm_noise_filter_vs_sklearn(dev, H, W):
         print(f"case {i} ({kind}): n {x.shape[0]}, relabelled {int(stats[i, 13])}, mismatching px {mism}")
         assert mism <= max(2, x.shape[0] // 20000), kind
         assert (stats[i, 1] == 1) == (kind == "bimodal")
+
+
+# ------------------------------------------------------------------------------------------ f16x3 split GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (1570, 768, 768), (129, 128, 32), (64, 2304, 768), (785, 3072, 768), (3140, 768, 3072)])
+def test_gemm_f16x3_is_fp32_equivalent(dev, M, N, K):
+    """dupl_gemm_f16x3 (fp16 hi / lo operand planes, 3 f16 MFMAs per block, fp32 accumulate) vs an fp64 reference: at
+    least as close as the exact-f32 MFMA kernel on the same operands (bar: 2x its error + 1e-7), incl. bias / GELU /
+    residual / pre-activation store epilogues, the plane outputs (hi + lo / 2048 reconstructs the result) and ragged
+    M / N edges; split16 itself reconstructs its input to 2^-22."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    xs, Ws = ops.split16(x), ops.split16(W)
+    rec = xs.planes[0].float() + xs.planes[1].float() / 2048.0
+    assert float(((rec - x).abs() / x.abs().clamp_min(1e-3)).max()) <= 2.0 ** -21
+    ref = x.double() @ W.double().t() + b.double()
+    pre = torch.empty(M, N, device=dev)
+    y, y16 = ops.linear16(xs, Ws, b, gelu=True, res=res, store_pre=pre, want16=True)
+    y32 = ops.linear(x, W, b, gelu=True, res=res)
+    want = F.gelu(ref) + res.double()
+    sc = float(want.abs().max())
+    e16, e32 = float((y.double() - want).abs().max()) / sc, float((y32.double() - want).abs().max()) / sc
+    print(f"{M}x{N}x{K}: f16x3 {e16:.2e}  f32 {e32:.2e}")
+    assert e16 <= 2.0 * e32 + 1e-7
+    assert float((pre.double() - ref).abs().max()) / float(ref.abs().max()) <= 2.0 * e32 + 1e-7
+    rec = y16.planes[0].float() + y16.planes[1].float() / 2048.0
+    assert float((rec - y).abs().max()) <= 2.0 ** -21 * sc
+    # planes-only output (no fp32 C) and fp32-only output agree with the combined call
+    _, only16 = ops.linear16(xs, Ws, b, gelu=True, res=res, want_f32=False, want16=True)
+    assert torch.equal(only16.planes, y16.planes)
+    y2, none16 = ops.linear16(xs, Ws, b, gelu=True, res=res)
+    assert none16 is None and torch.equal(y2, y)
+    # a row range of the A planes as operand (merged ms-CAM passes slice per batch)
+    if M > 70:
+        ys, _ = ops.linear16(xs.rows_slice(64, M), Ws, b)
+        yf, _ = ops.linear16(xs, Ws, b)
+        assert torch.equal(ys, yf[64:])
+
+
+def test_layernorm_fwd16_planes(dev):
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(333, 768, generator=g) * 3 + 1).to(dev)
+    gam, bet = torch.randn(768, generator=g).to(dev), torch.randn(768, generator=g).to(dev)
+    y, m, r = ops.layernorm_fwd(x, gam, bet, 1e-6, True)
+    y2, y16, m2, r2 = ops.layernorm_fwd16(x, gam, bet, 1e-6, True, want_f32=True)
+    assert torch.equal(y, y2) and torch.equal(m, m2) and torch.equal(r, r2)
+    assert torch.equal(y16.planes, ops.split16(y).planes)
+    y3, y16b, _, _ = ops.layernorm_fwd16(x, gam, bet, 1e-6, False, want_f32=False)
+    assert y3 is None and torch.equal(y16b.planes, y16.planes)

@@ -114,14 +114,15 @@ def test_bench_contract_line(dev):
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "img/s" and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["data"] == "synthetic" and d["dtype"].startswith("f32")
+    assert d["config"]["forward_gemm"] in ("f16x3", "f32") and ("f16x3" in d["dtype"]) == (d["config"]["forward_gemm"] == "f16x3")
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["config"]["global_batch"] * 1000.0 / d["ms_per_step"]) < 0.05 * d["value"]
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert 0.3 < rf["frac"] < 1.0 and d["value"] > 10.0
+    assert 0.15 < rf["frac"] < 1.0 and d["value"] > 10.0
     # roofline.traffic is only quoted from a PMC summary tagged with THIS build's kernel-source digest
     from dupl_amd.build import source_digest
     assert rf["csrc_sha256"] == source_digest()[:16] and "traffic_source" in rf
