@@ -147,7 +147,7 @@ def cpu_baseline(args, dataset, C):
         return time.perf_counter() - t0
 
     phys = physical_cores()
-    cand = [args.cpu_threads] if args.cpu_threads > 0 else sorted({phys, min(64, phys), min(32, phys)}, reverse=True)
+    cand = [args.cpu_threads] if args.cpu_threads > 0 else sorted({phys, min(64, phys), min(32, phys), min(16, phys)}, reverse=True)
     one_step(cand[0])                                   # warm-up (allocator, thread pool, page-in)
     sweep = {}
     if len(cand) > 1:

@@ -1,0 +1,267 @@
+// Fused multi-head attention forward as fp32-equivalent split products on the f16 matrix cores ("f16x3", see
+// gemm_split.hip): q, k, v arrive as fp16 hi / lo planes (the qkv GEMM writes them), S = q k^T and O = P v are each
+//     hi hi + (hi lo + lo hi) / 2048       (3 v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulate)
+// with the softmax in fp32 and the probabilities split in registers.  Head dim 64.
+//
+// Transposed formulation (as attn.hip): S^T[key][q] = K Q^T puts one query per lane column, so the row softmax is
+// lane-local (+ one lane^32 exchange) and the probability registers ARE the B operand of O^T[d][q] += V^T[d][key] P^T[key][q].
+// For the f16 MFMA a lane's B fragment is 8 consecutive reduction slots; the accumulator gives lane half hf the MFMA rows
+// {0-3, 8-11} / {4-7, 12-15} of each 16-row group, so the K rows are fed in the permuted order pi (4-row groups 1 and 2
+// swapped): then registers e = 8s .. 8s+7 of a lane ARE keys 16s + 8 hf + 0..7 -- the fragment, without any permute.
+// V is consumed as V^T [d][key] (key-contiguous), produced by vt_planes_kernel from the qkv planes, so both K and V^T
+// tiles are [64 rows][64 halfs = 128 bytes] images filled by direct-to-LDS DMA (8 rows per wave instruction) with the
+// bank swizzle chunk ^ ((row >> 1) & 7) applied on the source side, and every fragment read is one ds_read_b128.
+// Block = 4 waves x 32 queries, 64 keys per iteration, two LDS stages (64 KB, 2 blocks / CU), one barrier per key tile.
+#include "common.h"
+#include "../../include/dupl_hip.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr float LO_INV = 1.f / DUPL_LO_SCALE;
+constexpr int HD = 64, KT = 64;
+constexpr int PLANE = KT * 128;          // one [64][128 B] image
+constexpr int STAGE = 4 * PLANE;         // K_hi | K_lo | VT_hi | VT_lo
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+__device__ __forceinline__ void xcd_remap3(int remap, int& bx, int& by, int& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (!remap) return;
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * gridDim.z;
+    const int L = bx + gx * (by + gy * bz);
+    const int q = total >> 3, r = total & 7;
+    const int xcd = L & 7, idx = L >> 3;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = w % gx;
+    by = (w / gx) % gy;
+    bz = w / (gx * gy);
+}
+
+// V^T planes: vT[(b*H + h)*64 + d][key], key < Npad (a multiple of 64), zero for key >= N.  One block per (64-key tile, h, b).
+__global__ __launch_bounds__(256) void vt_planes_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
+                                                        __half* __restrict__ vT_hi, __half* __restrict__ vT_lo, int N, int H,
+                                                        int Npad) {
+    __shared__ __half tile[2][64][66];
+    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * HD, ld = 3 * D;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const __half* src = (pl == 0 ? qkv_hi : qkv_lo) + (size_t)b * N * ld + 2 * D + h * HD;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i;              // 512 chunks of 8 halfs: key = c / 8, d0 = (c % 8) * 8
+            const int key = c >> 3, d0 = (c & 7) << 3;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (k0 + key < N) v = *reinterpret_cast<const uint4*>(src + (size_t)(k0 + key) * ld + d0);
+            const __half* hv = reinterpret_cast<const __half*>(&v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[pl][key][d0 + j] = hv[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        __half* dst = (pl == 0 ? vT_hi : vT_lo) + ((size_t)(b * H + h) * HD) * Npad + k0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i;              // d = c / 8, keys (c % 8) * 8 .. + 7
+            const int d = c >> 3, kk = (c & 7) << 3;
+            __half o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = tile[pl][kk + j][d];
+            *reinterpret_cast<uint4*>(dst + (size_t)d * Npad + kk) = *reinterpret_cast<const uint4*>(o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
+                                                            const __half* __restrict__ vT_hi, const __half* __restrict__ vT_lo,
+                                                            float* __restrict__ out, __half* __restrict__ out_hi,
+                                                            __half* __restrict__ out_lo, float* __restrict__ lse, int N, int H,
+                                                            int Npad, float scale, int remap) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    int bx, h, b;
+    xcd_remap3(remap, bx, h, b);
+    const int q0 = bx * 128 + wave * 32;
+    const int D = H * HD, ld = 3 * D;
+    const int qrow = q0 + l31;
+    const bool wave_active = q0 < N;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (q, hf) holds Q[q][16 s + 8 hf .. + 7], both planes
+    h8 qh[4], ql[4];
+    {
+        const size_t off = ((size_t)b * N + min(qrow, N - 1)) * ld + h * HD + 8 * hf;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qh[s] = *reinterpret_cast<const h8*>(qkv_hi + off + 16 * s);
+            ql[s] = *reinterpret_cast<const h8*>(qkv_lo + off + 16 * s);
+        }
+    }
+
+    // ---- DMA plan: piece g = wave + 4 i covers rows 8 q .. 8 q + 7 (q = wave + 4 (i & 1)) of plane i / 2
+    const int prow = lane >> 3, pch = lane & 7;
+    const char* kbase[2];      // K planes at this (b, h): row 0, column chunk 0
+    kbase[0] = reinterpret_cast<const char*>(qkv_hi + (size_t)b * N * ld + D + h * HD);
+    kbase[1] = reinterpret_cast<const char*>(qkv_lo + (size_t)b * N * ld + D + h * HD);
+    const char* vp[4];         // V^T pieces i = 4 .. 7: per-lane pointer at key tile 0
+    int krow[2], kch[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * (wave + 4 * j) + prow;                 // tile row of this lane in pieces with (i & 1) == j
+        const int c = pch ^ ((r >> 1) & 7);                      // source chunk (swizzle on the source side)
+        krow[j] = r;
+        kch[j] = c * 16;
+        vp[j] = reinterpret_cast<const char*>(vT_hi + ((size_t)(b * H + h) * HD + r) * Npad) + c * 16;
+        vp[2 + j] = reinterpret_cast<const char*>(vT_lo + ((size_t)(b * H + h) * HD + r) * Npad) + c * 16;
+    }
+    auto issue = [&](int t, int buf) __attribute__((always_inline)) {
+        char* dst = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = i & 1;
+            const char* src;
+            if (i < 4) src = kbase[i >> 1] + (size_t)min(t * KT + krow[j], N - 1) * (ld * 2) + kch[j];
+            else src = vp[(i >= 6 ? 2 : 0) + j] + (size_t)t * (KT * 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses
+    // K (A operand of S^T): MFMA row l31 <- key pi(l31) of the 32-key sub-tile; chunk (2 s + hf) ^ ((row >> 1) & 7)
+    const int g4 = (l31 >> 2) & 3;
+    const int krow_a = (l31 & ~12) | ((g4 == 1 ? 2 : (g4 == 2 ? 1 : g4)) << 2);
+    const int k_off = krow_a * 128, k_sw = (krow_a >> 1) & 7;
+    // V^T (A operand of O^T): MFMA row l31 <- d = 32 dt + l31; chunk (2 sigma + hf) ^ ((row >> 1) & 7)
+    const int v_off = l31 * 128, v_sw = (l31 >> 1) & 7;
+
+    f32x16 oM[2], oX[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oM[d][e] = 0.f; oX[d][e] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (N + KT - 1) / KT;
+    issue(0, 0);
+    for (int t = 0; t < nkt; ++t) {
+        __syncthreads();
+        if (t + 1 < nkt) issue(t + 1, (t + 1) & 1);
+        if (!wave_active) continue;
+        const char* st = smem + (t & 1) * STAGE;
+
+        // ---- S^T = K Q^T, two 32-key sub-tiles
+        f32x16 sM[2], sX[2];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sM[kt2][e] = 0.f; sX[kt2][e] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ch = ((2 * s + hf) ^ k_sw) * 16;
+                const h8 kh = *reinterpret_cast<const h8*>(st + kt2 * 4096 + k_off + ch);
+                const h8 kl = *reinterpret_cast<const h8*>(st + PLANE + kt2 * 4096 + k_off + ch);
+                sM[kt2] = MFMA16(kh, qh[s], sM[kt2]);
+                sX[kt2] = MFMA16(kh, ql[s], sX[kt2]);
+                sX[kt2] = MFMA16(kl, qh[s], sX[kt2]);
+            }
+        }
+        // ---- online softmax (fp32).  Register e of sub-tile kt2 is key  t*64 + 32 kt2 + 16 (e >> 3) + 8 hf + (e & 7)
+        const int kbase_t = t * KT + 8 * hf;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = (sM[kt2][e] + sX[kt2][e] * LO_INV) * scale;
+                if (kbase_t + 32 * kt2 + 16 * (e >> 3) + (e & 7) >= N) v = -INFINITY;
+                sM[kt2][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fast_exp(m_run - m_new);
+        float psum = 0.f;
+        h8 ph[4], pl[4];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = fast_exp(sM[kt2][e] - m_new);
+                psum += pv;
+                const _Float16 hh = (_Float16)pv;
+                ph[2 * kt2 + (e >> 3)][e & 7] = hh;
+                pl[2 * kt2 + (e >> 3)][e & 7] = (_Float16)((pv - (float)hh) * DUPL_LO_SCALE);
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oM[d][e] *= alpha; oX[d][e] *= alpha; }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const int ch = ((2 * sg + hf) ^ v_sw) * 16;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const h8 vh = *reinterpret_cast<const h8*>(st + 2 * PLANE + d * 4096 + v_off + ch);
+                const h8 vl = *reinterpret_cast<const h8*>(st + 3 * PLANE + d * 4096 + v_off + ch);
+                oM[d] = MFMA16(vh, ph[sg], oM[d]);
+                oX[d] = MFMA16(vh, pl[sg], oX[d]);
+                oX[d] = MFMA16(vl, ph[sg], oX[d]);
+            }
+        }
+    }
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow < N) {
+        const size_t ro = ((size_t)b * N + qrow) * D + h * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (oM[d][4 * g + j] + oX[d][4 * g + j] * LO_INV) * inv;
+                const int col = d * 32 + 8 * g + 4 * hf;
+                if (out) *reinterpret_cast<float4*>(out + ro + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (out_hi) {
+                    __half hh[4], ll[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) split_f32(v[j], hh[j], ll[j]);
+                    *reinterpret_cast<uint2*>(out_hi + ro + col) = *reinterpret_cast<const uint2*>(hh);
+                    *reinterpret_cast<uint2*>(out_lo + ro + col) = *reinterpret_cast<const uint2*>(ll);
+                }
+            }
+        if (lse && hf == 0) lse[((size_t)b * H + h) * N + qrow] = m_run + logf(l_tot);
+    }
+}
+
+}  // namespace
+
+static int g_attn16_remap = 1;
+
+extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
+                                    void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
+                                    float scale, dupl_stream_t s) {
+    (void)hipGetLastError();
+    if (!qkv_hi || !qkv_lo || !vT_hi || !vT_lo || (!out && !out_hi) || ((out_hi == nullptr) != (out_lo == nullptr)) || B <= 0 ||
+        N <= 0 || H <= 0 || hd != HD || Npad < N || (Npad % KT))
+        return DUPL_ERR_ARG;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(qkv_hi) || !al16(qkv_lo) || !al16(vT_hi) || !al16(vT_lo)) return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(vt_planes_kernel, dim3(Npad / KT, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
+                       (const __half*)qkv_lo, (__half*)vT_hi, (__half*)vT_lo, N, H, Npad);
+    hipLaunchKernelGGL(attn_fwd16_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
+                       (const __half*)qkv_lo, (const __half*)vT_hi, (const __half*)vT_lo, out, (__half*)out_hi, (__half*)out_lo, lse,
+                       N, H, Npad, scale, g_attn16_remap);
+    return dupl_launch_status();
+}

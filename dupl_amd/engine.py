@@ -333,7 +333,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
     its row slice -- the merged ms-CAM pass of cam_logits_multi); with save=True (single batch only) the fp32 copies
     the hand-written backward consumes are written next to the operand planes.  Data flow per block (fp32 residual
     stream; `16` = hi / lo fp16 planes, the A operand of the next GEMM, written by the producing kernel):
-        t -LN-> ln1_16 -GEMM-> qkv (fp32) -attention-> att (fp32) -split-> att16 -GEMM + t-> x_mid
+        t -LN-> ln1_16 -GEMM-> qkv16 -split attention (head dim 64)-> att16 -GEMM + t-> x_mid
         x_mid -LN-> ln2_16 -GEMM, GELU-> h1_16 -GEMM + x_mid-> t
     Returns [(tokens_final, tokens_aux, saved)] per batch (row-slice views)."""
     cfg = P.cfg
@@ -366,13 +366,26 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
     for i in range(cfg.depth):
         p = f"encoder.blocks.{i}."
         ln1, ln1_16, m1, r1 = ops.layernorm_fwd16(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, save, want_f32=save)
-        qkv, _ = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"])
-        del ln1_16
-        att = torch.empty((R, D), device=t.device, dtype=torch.float32)
         lse = None
-        for (g0, B, N, _, _) in groups:
-            _, lse = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
-        att16 = ops.split16(att)
+        if hd == 64:
+            # q, k, v stay fp16 planes end to end: the qkv GEMM writes them, the split attention kernel reads them and
+            # writes the planes the projection GEMM consumes; fp32 copies only where the backward needs them (save)
+            qkv, qkv16 = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"], want_f32=save,
+                                      want16=True)
+            del ln1_16
+            att = torch.empty((R, D), device=t.device, dtype=torch.float32) if save else None
+            att16 = ops.split16_empty(R, D, t.device)
+            for (g0, B, N, _, _) in groups:
+                lse = ops.attention_fwd16(qkv16.rows_slice(g0, g0 + B * N), B, N, H, hd, scale, need_lse=save,
+                                          out=att[g0:g0 + B * N] if save else None, out16=att16.rows_slice(g0, g0 + B * N))
+            del qkv16
+        else:   # other head dims (the 96-dim test backbone): exact-f32 attention kernel between split GEMMs
+            qkv, _ = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"])
+            del ln1_16
+            att = torch.empty((R, D), device=t.device, dtype=torch.float32)
+            for (g0, B, N, _, _) in groups:
+                _, lse = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
+            att16 = ops.split16(att)
         x_mid, _ = ops.linear16(att16, P.w16(p + "attn.proj.weight", D), W[p + "attn.proj.bias"], res=t)
         del att16
         ln2, ln2_16, m2, r2 = ops.layernorm_fwd16(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save, want_f32=save)

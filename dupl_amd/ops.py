@@ -240,6 +240,24 @@ def attention_fwd(qkv: Tensor, B: int, N: int, H: int, hd: int, scale: float, ne
     return out, lse
 
 
+def attention_fwd16(qkv16, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool = False,
+                    out: Optional[Tensor] = None, out16=None):
+    """Attention forward on the f16x3 split kernels (head dim 64).  qkv16: Split16 / Split16View [B*N, 3*H*hd] (planes of
+    the qkv GEMM output); out: optional fp32 [B*N, H*hd] destination; out16: optional Split16 / Split16View [B*N, H*hd]
+    receiving the planes of the output.  Returns lse (B, H, N) or None."""
+    assert hd == 64 and qkv16.rows == B * N and qkv16.cols == 3 * H * hd and (out is not None or out16 is not None)
+    dev = out.device if out is not None else (out16.planes.device if isinstance(out16, Split16) else out16.base.planes.device)
+    npad = (N + 63) // 64 * 64
+    vt = torch.empty((2, B * H * hd * npad), device=dev, dtype=torch.float16)
+    lse = torch.empty((B, H, N), device=dev, dtype=torch.float32) if need_lse else None
+    if out is not None:
+        assert out.shape == (B * N, H * hd) and out.is_contiguous()
+    L().dupl_attention_fwd16(qkv16.hi, qkv16.lo, vt.data_ptr(), vt.data_ptr() + 2 * vt.shape[1], _p(out),
+                             out16.hi if out16 is not None else None, out16.lo if out16 is not None else None, _p(lse),
+                             B, N, H, hd, npad, float(scale), _stream())
+    return lse
+
+
 def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, hd: int, scale: float) -> Tensor:
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), device=qkv.device, dtype=torch.float32)

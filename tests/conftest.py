@@ -29,6 +29,7 @@ def golden_dir():
 def _report_gemm_mode():
     """DUPL_GEMM=f16x3 runs the WHOLE suite with the encoder's forward Linears on the split-f16 GEMM (the gate for
     making it the default: every parity bar must hold in either mode)."""
-    mode = os.environ.get("DUPL_GEMM", "f32")
+    from dupl_amd import engine
+    mode = engine.GEMM_MODE
     print(f"\n[dupl_amd] forward GEMM mode for this session: {mode}")
     yield

@@ -580,3 +580,36 @@ def test_layernorm_fwd16_planes(dev):
     assert torch.equal(y16.planes, ops.split16(y).planes)
     y3, y16b, _, _ = ops.layernorm_fwd16(x, gam, bet, 1e-6, False, want_f32=False)
     assert y3 is None and torch.equal(y16b.planes, y16.planes)
+
+
+@pytest.mark.parametrize("B,N", [(2, 197), (1, 785), (2, 64), (1, 130), (3, 50)])
+def test_attention_fwd16_is_fp32_equivalent(dev, B, N):
+    """dupl_attention_fwd16 (q / k / v as fp16 hi / lo planes, QK^T and PV as f16x3 split products, fp32 softmax) vs an fp64
+    reference: output and log-sum-exp at least as close as the exact-f32 MFMA attention kernel (bar 2x its error + 2e-7),
+    plane outputs reconstruct the fp32 output, ragged N (masked last key tile, partial query blocks)."""
+    from dupl_amd import ops
+    H, hd = 12, 64
+    D = H * hd
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    qkv = (torch.randn(B * N, 3 * D, generator=g) * 1.5).to(dev)
+    scale = hd ** -0.5
+    q, k, v = (qkv.double().view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+    att = (q @ k.transpose(-1, -2)) * scale
+    ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+    ref_lse = torch.logsumexp(att, dim=-1)
+    o32, lse32 = ops.attention_fwd(qkv, B, N, H, hd, scale, need_lse=True)
+    qkv16 = ops.split16(qkv)
+    out = torch.empty(B * N, D, device=dev)
+    o16 = ops.split16_empty(B * N, D, dev)
+    lse = ops.attention_fwd16(qkv16, B, N, H, hd, scale, need_lse=True, out=out, out16=o16)
+    sc = float(ref.abs().max())
+    e16, e32 = float((out.double() - ref).abs().max()) / sc, float((o32.double() - ref).abs().max()) / sc
+    l16, l32 = float((lse.double() - ref_lse).abs().max()), float((lse32.double() - ref_lse).abs().max())
+    print(f"B{B} N{N}: out f16x3 {e16:.2e} f32 {e32:.2e}; lse f16x3 {l16:.2e} f32 {l32:.2e}")
+    assert e16 <= 2.0 * e32 + 2e-7 and l16 <= 2.0 * l32 + 1e-6
+    rec = o16.planes[0].float() + o16.planes[1].float() / 2048.0
+    assert float((rec - out).abs().max()) <= 2.0 ** -21 * sc
+    # planes-only output on a row slice of a larger buffer (merged ms-CAM passes)
+    big = ops.split16_empty(B * N + 128, D, dev)
+    ops.attention_fwd16(qkv16, B, N, H, hd, scale, out16=big.rows_slice(64, 64 + B * N))
+    assert torch.equal(big.planes[:, 64:64 + B * N], o16.planes)
