@@ -109,12 +109,19 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINB) void gemm_f16x3_kernel(const 
                 accX[i][j][e] = 0.f;
             }
 
-    const int nt = p.K / TBK;
-    issue(0, 0);
+    // split-K (gridDim.y > 1, accumulating GEMMs only): this block reduces k-tiles [tb, te) and adds its partial tile
+    // atomically
+    const int ntk = p.K / TBK;
+    const int ksplit = gridDim.y;
+    const int per = (ntk + ksplit - 1) / ksplit;
+    const int tb = blockIdx.y * per, te = min(ntk, tb + per);
+    if (tb >= te) return;
+    const int nt = te - tb;
+    issue(tb, 0);
     for (int t = 0; t < nt; ++t) {
         __syncthreads();                       // s_waitcnt vmcnt(0): my DMA of tile t landed; barrier: everyone's did, and
                                                // everyone is done reading the other stage
-        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        if (t + 1 < nt) issue(tb + t + 1, (t + 1) & 1);
         const char* st = smem + (t & 1) * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -144,24 +151,36 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINB) void gemm_f16x3_kernel(const 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     const int fl = p.flags;
     const bool f_pre = fl & DUPL_GEMM_STORE_PRE, f_gelu = fl & DUPL_GEMM_GELU, f_relu = fl & DUPL_GEMM_RELU;
+    const bool f_acc = fl & DUPL_GEMM_ACCUM, f_dgelu = fl & DUPL_GEMM_MUL_DGELU, f_rmask = fl & DUPL_GEMM_MUL_RELUMASK;
+    const float alpha = p.alpha_dev ? *p.alpha_dev : 1.f;      // inverse operand scale(s) of scaled gradient planes
     __half* Ch = static_cast<__half*>(p.C_hi);
     __half* Cl = static_cast<__half*>(p.C_lo);
+    const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;    // block-uniform: no per-element edge tests
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int col = n0 + wn * (32 * WN) + j * 32 + l31;
-        if (col >= p.N) continue;
+        if (!interior && col >= p.N) continue;
         const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
+            const int rbase = m0 + wm * (32 * WM) + i * 32 + 4 * hf;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (32 * WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf;
-                if (row >= p.M) continue;
-                float v = accM[i][j][e] + accX[i][j][e] * LO_INV + bv;
+                const int row = rbase + (e & 3) + 8 * (e >> 2);
+                if (!interior && row >= p.M) continue;
+                float v = (accM[i][j][e] + accX[i][j][e] * LO_INV) * alpha + bv;
                 if (f_pre) p.aux[(size_t)row * p.ldaux + col] = v;
                 if (f_gelu) v = gelu_f(v);
                 if (f_relu) v = fmaxf(v, 0.f);
+                if (f_dgelu) v *= gelu_grad_f(p.aux[(size_t)row * p.ldaux + col]);
+                if (f_rmask) v = p.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
                 if (p.res) v += p.res[(size_t)row * p.ldr + col];
+                if (f_acc) {
+                    float* cp = p.C + (size_t)row * p.ldc + col;
+                    if (ksplit > 1) unsafeAtomicAdd(cp, v);
+                    else *cp += v;
+                    continue;
+                }
                 if (p.C) p.C[(size_t)row * p.ldc + col] = v;
                 if (Ch) {
                     __half h, l;
@@ -177,7 +196,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINB) void gemm_f16x3_kernel(const 
 }  // namespace
 
 static int g16_group_m = 8;
-static int g16_tile = 0;     // 0 = heuristic; 1: 128x128 (4 waves), 2: 256x128 (8 waves), 3: 128x64, 4: 64x128
+static int g16_tile = 0;     // 0 = heuristic; 1: 128x128 (4 waves), 2: 256x128 (8 waves), 3: 128x64, 4: 64x128,
+                             // 5 / 6: 128x128 on 8 waves (wave tile 64x32 / 32x64)
 
 extern "C" int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, dupl_stream_t stream) {
     (void)hipGetLastError();
@@ -198,7 +218,7 @@ extern "C" int dupl_set_gemm16_group(int32_t gm) {
 }
 
 extern "C" int dupl_set_gemm16_tile(int32_t t) {
-    if (t < 0 || t > 4) return DUPL_ERR_ARG;
+    if (t < 0 || t > 6) return DUPL_ERR_ARG;
     g16_tile = t;
     return DUPL_OK;
 }
@@ -211,21 +231,39 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
     if (!al16(d->A_hi) || !al16(d->A_lo) || !al16(d->B_hi) || !al16(d->B_lo)) return DUPL_ERR_ARG;
     if (!d->C && !d->C_hi) return DUPL_ERR_ARG;
     if ((d->C_hi == nullptr) != (d->C_lo == nullptr)) return DUPL_ERR_ARG;
-    if ((d->flags & DUPL_GEMM_STORE_PRE) && !d->aux) return DUPL_ERR_ARG;
-    if (d->flags & ~(DUPL_GEMM_GELU | DUPL_GEMM_RELU | DUPL_GEMM_STORE_PRE)) return DUPL_ERR_ARG;
+    if ((d->flags & (DUPL_GEMM_STORE_PRE | DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK)) && !d->aux) return DUPL_ERR_ARG;
+    if (d->flags & ~(DUPL_GEMM_GELU | DUPL_GEMM_RELU | DUPL_GEMM_STORE_PRE | DUPL_GEMM_ACCUM | DUPL_GEMM_MUL_DGELU |
+                     DUPL_GEMM_MUL_RELUMASK))
+        return DUPL_ERR_ARG;
+    const bool accum = d->flags & DUPL_GEMM_ACCUM;
+    if (accum && (!d->C || d->C_hi || d->bias || d->res)) return DUPL_ERR_ARG;   // C += alpha * A B^T, nothing else
     hipStream_t s = (hipStream_t)stream;
+    // split-K for accumulating GEMMs (weight gradients: few output tiles, K = all tokens): >= ~2 blocks per CU,
+    // >= 8 k-tiles per split
+    int ksplit = 1;
+    if (accum) {
+        const long tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+        ksplit = (int)((512 + tiles - 1) / tiles);
+        const int maxs = (d->K / TBK + 7) / 8;
+        if (ksplit > maxs) ksplit = maxs;
+        if (ksplit < 1) ksplit = 1;
+    }
     int tile = g16_tile;
     if (tile == 0) {
         // 128 x 128 tiles unless they leave most of the 512 block slots (2 per CU) empty: then 128 x 64 (twice the blocks)
-        const long b128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-        tile = b128 < 400 ? 3 : 1;
+        // 128 x 128 on 8 waves (4 waves / SIMD: +10..25 % over 4 waves on K = 768, profiles/r02_gemm16_tiles.txt) unless
+        // that leaves most of the 512 block slots empty: then 128 x 64 on 4 waves (twice the blocks)
+        const long b128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * ksplit;
+        tile = b128 < 200 ? 3 : 5;
     }
-    auto blocks = [&](int bm, int bn) { return dim3((unsigned)(((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn))); };
+    auto blocks = [&](int bm, int bn) { return dim3((unsigned)(((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn)), (unsigned)ksplit); };
     switch (tile) {
         case 1: hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, 2>), blocks(128, 128), dim3(256), 0, s, *d, g16_group_m); break;
         case 2: hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 4, 2, 1>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_m); break;
         case 3: hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 2, 2>), blocks(128, 64), dim3(256), 0, s, *d, g16_group_m); break;
-        default: hipLaunchKernelGGL((gemm_f16x3_kernel<1, 2, 2, 2, 2>), blocks(64, 128), dim3(256), 0, s, *d, g16_group_m); break;
+        case 4: hipLaunchKernelGGL((gemm_f16x3_kernel<1, 2, 2, 2, 2>), blocks(64, 128), dim3(256), 0, s, *d, g16_group_m); break;
+        case 5: hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 4, 4>), blocks(128, 128), dim3(512), 0, s, *d, g16_group_m); break;
+        default: hipLaunchKernelGGL((gemm_f16x3_kernel<1, 2, 4, 2, 4>), blocks(128, 128), dim3(512), 0, s, *d, g16_group_m); break;
     }
     return dupl_launch_status();
 }

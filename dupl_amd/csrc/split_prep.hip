@@ -1,0 +1,125 @@
+// Operand preparation for the f16x3 split GEMM on the BACKWARD path (gemm_split.hip).
+//
+// Gradients are small (1e-3 .. 1e-9): their fp16 `hi` part would be subnormal or zero.  Each gradient tensor is therefore
+// scaled by a power of two chosen from its own max-abs (amax * scale in [2^14, 2^15)), which is exact, keeps every
+// element within 2^-11 * 2^-25 of the tensor's largest one, and is undone by the GEMM epilogue (the inverse scale travels
+// through device memory: no host synchronisation).  Activations and weights are O(1) and are split unscaled.
+//
+// The backward GEMMs are cast as k-contiguous x k-contiguous products (the only layout gemm_split.hip implements):
+//   dgrad  dx[M][K] = dy[M][N] . W[N][K]          = dy16 [M][N] . (W^T16 [K][N])^T
+//   wgrad  dW[N][K] += dy[M][N]^T . x[M][K]        = dy^T16 [N][Mp] . (x^T16 [K][Mp])^T      (Mp = M rounded up to 32, zeros)
+// so this file provides: amax, and ONE tiled kernel that reads an fp32 matrix [R][C] once and writes its row-major planes
+// [R][C] and / or its transposed planes [C][Rp] (64 x 64 tiles through LDS), scaled or not.
+#include "common.h"
+#include "../../include/dupl_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n4, unsigned int* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));   // one atomic per block; non-negative floats order like their bits
+    }
+}
+
+// scale = 2^(15 - e), with amax in [2^(e-1), 2^e): amax * scale in [2^14, 2^15)   (1 for amax == 0 / non-finite)
+__device__ __forceinline__ void scale_from_amax(unsigned int bits, float& s, float& inv) {
+    const float a = __uint_as_float(bits);
+    s = 1.f;
+    inv = 1.f;
+    if (a > 0.f && a < INFINITY) {
+        int e;
+        frexpf(a, &e);
+        s = ldexpf(1.f, 15 - e);
+        inv = ldexpf(1.f, e - 15);
+    }
+}
+
+// x [R][ld] fp32 (C columns used) -> row-major planes hi / lo [R][C] (optional) and transposed planes hiT / loT [C][Rp]
+// (optional; rows R .. Rp-1 of the transposed image are written as zeros).  scale: device float or NULL (= 1).
+// slot (scaled tensors): {scale, 1 / scale, amax bits, -} in device memory; next_bits: the amax word of the ring slot the
+// NEXT scaled tensor on this stream will use, zeroed here (stream order makes that safe) so that no memset node is needed.
+__global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__ x, int ld, int R, int C, float* __restrict__ slot,
+                                                       unsigned int* __restrict__ next_bits, __half* __restrict__ hi,
+                                                       __half* __restrict__ lo, __half* __restrict__ hiT, __half* __restrict__ loT,
+                                                       int Rp) {
+    __shared__ __half th[64][66], tl[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    float s = 1.f;
+    if (slot) {
+        float inv;
+        scale_from_amax(reinterpret_cast<const unsigned int*>(slot)[2], s, inv);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            slot[0] = s;
+            slot[1] = inv;
+            if (next_bits) *next_bits = 0u;
+        }
+    }
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;            // 1024 float4 chunks: row c / 16, cols (c % 16) * 4
+        const int r = c >> 4, cc = (c & 15) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < R && c0 + cc < C) v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + r) * ld + c0 + cc);   // C % 4 == 0
+        __half h[4], l[4];
+        split_f32(v.x * s, h[0], l[0]);
+        split_f32(v.y * s, h[1], l[1]);
+        split_f32(v.z * s, h[2], l[2]);
+        split_f32(v.w * s, h[3], l[3]);
+        if (hi && r0 + r < R && c0 + cc < C) {
+            *reinterpret_cast<uint2*>(hi + (size_t)(r0 + r) * C + c0 + cc) = *reinterpret_cast<const uint2*>(h);
+            *reinterpret_cast<uint2*>(lo + (size_t)(r0 + r) * C + c0 + cc) = *reinterpret_cast<const uint2*>(l);
+        }
+        if (hiT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { th[r][cc + j] = h[j]; tl[r][cc + j] = l[j]; }
+        }
+    }
+    if (!hiT) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;            // 512 chunks of 8 halfs: column c / 8, rows (c % 8) * 8 .. + 7
+        const int col = c >> 3, rr = (c & 7) << 3;
+        if (c0 + col >= C || r0 + rr >= Rp) continue;       // Rp % 8 == 0
+        __half oh[8], ol[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { oh[j] = th[rr + j][col]; ol[j] = tl[rr + j][col]; }   // rows >= R were loaded as zeros
+        *reinterpret_cast<uint4*>(hiT + (size_t)(c0 + col) * Rp + r0 + rr) = *reinterpret_cast<const uint4*>(oh);
+        *reinterpret_cast<uint4*>(loT + (size_t)(c0 + col) * Rp + r0 + rr) = *reinterpret_cast<const uint4*>(ol);
+    }
+}
+
+}  // namespace
+
+extern "C" int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
+                                  void* hiT, void* loT, int32_t Rp, dupl_stream_t stream) {
+    (void)hipGetLastError();
+    if (!x || R <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C || (!hi && !hiT) || ((hi == nullptr) != (lo == nullptr)) ||
+        ((hiT == nullptr) != (loT == nullptr)) || (hiT && (Rp < R || (Rp & 7))))
+        return DUPL_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15)) return DUPL_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (slot) {
+        if (ld != C) return DUPL_ERR_ARG;      // the amax pass reads the matrix as one contiguous run
+        const long n4 = (long)R * C / 4;
+        long g = (n4 + 2047) / 2048;           // >= 8 float4 per thread, at most one block per CU
+        if (g > 256) g = 256;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, s, x, n4, reinterpret_cast<unsigned int*>(slot) + 2);
+    }
+    const int Rt = hiT ? Rp : R;
+    hipLaunchKernelGGL(split_rt_kernel, dim3((C + 63) / 64, (Rt + 63) / 64), dim3(256), 0, s, x, ld, R, C, slot,
+                       (unsigned int*)next_bits, (__half*)hi, (__half*)lo, (__half*)hiT, (__half*)loT, Rp);
+    return dupl_launch_status();
+}

@@ -147,6 +147,7 @@ class FlatStorage:
         self.data16: Optional[Tensor] = None
         self.dirty = 0
         self._w16_key = [None] * n_students
+        self._w16T: Dict = {}
 
     def wait_streams(self):
         """Make the current stream wait for everything queued on the student streams."""
@@ -166,6 +167,7 @@ class FlatStorage:
         self.grad = fn(self.grad)
         self.data16 = None
         self._w16_key = [None] * self.n_students
+        self._w16T = {}
 
     def mark_dirty(self):
         """To be called by whoever rewrites parameters through raw pointers (the optimiser kernel)."""
@@ -183,6 +185,18 @@ class FlatStorage:
         ops.L().dupl_split_f16x2(self.data.data_ptr() + 4 * base, self.data16.data_ptr() + 2 * base,
                                  self.data16.data_ptr() + 2 * (self.data.numel() + base), n, ops._stream())
         self._w16_key[student] = key
+
+    def w16T(self, student: int, key: str, rows: int):
+        """Operand planes of the TRANSPOSE of parameter `key` ([rows, cols] -> planes [cols, rows]): the B operand of the data
+        gradient dx = dy . W as a k-contiguous product.  Built on first use after every parameter change (backward only)."""
+        ver = (self.data._version, self.dirty, self.data.data_ptr())
+        hit = self._w16T.get((student, key))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        w = self.view(student, key).view(rows, -1)
+        _, T, _ = ops.split_prepare(w, scaled=False, want_rm=False, want_T=True, rows_pad=rows)
+        self._w16T[(student, key)] = (ver, T)
+        return T
 
     def w16(self, student: int, key: str, rows: int) -> "ops.W16":
         """Operand planes of parameter `key` viewed as a [rows, numel / rows] matrix."""
@@ -249,6 +263,9 @@ class StudentParams:
 
     def w16(self, key: str, rows: int):
         return self.store.w16(self.student, key, rows)
+
+    def w16T(self, key: str, rows: int):
+        return self.store.w16T(self.student, key, rows)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -564,6 +581,28 @@ def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
 # ------------------------------------------------------------------------------------------------
 # backward
 # ------------------------------------------------------------------------------------------------
+def _linear_backward32(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu_of: Optional[Tensor] = None) -> Tensor:
+    """Backward of y = x W^T + b on the exact-f32 MFMA kernels: accumulates dW, db; returns dx (* gelu'(dgelu_of))."""
+    ops.linear_wgrad(dy, x, P.g[name + ".weight"], accumulate=True)
+    ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
+    return ops.linear_dgrad(dy, P.w[name + ".weight"], dgelu_of=dgelu_of)
+
+
+def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu_of: Optional[Tensor] = None) -> Tensor:
+    """The same on the f16x3 split GEMM (fp32-equivalent).  The gradient dy is scaled by a power of two from its own
+    max-abs before it is split (its values are far below fp16's normal range); both GEMMs run as k-contiguous products
+    through transposed operand planes:  dW += dy^T16 . (x^T16)^T,  dx = dy16 . (W^T16)^T  (csrc/split_prep.hip)."""
+    M, N = dy.shape
+    Mp = (M + 31) // 32 * 32
+    dy16, dyT16, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=True, rows_pad=Mp)
+    _, xT16, _ = ops.split_prepare(x, scaled=False, want_rm=False, want_T=True, rows_pad=Mp)
+    gw = P.g[name + ".weight"]
+    ops.linear16(dyT16, xT16, out=gw.view(N, -1), accumulate=True, alpha=alpha)
+    ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
+    dx, _ = ops.linear16(dy16, P.w16T(name + ".weight", N), alpha=alpha, dgelu_of=dgelu_of)
+    return dx
+
+
 def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], dseg: Optional[Tensor],
                      dx4: Optional[Tensor], dcls_aux: Optional[Tensor], on_ready=None):
     """Adjoint of network_forward; accumulates into P.g[...] (the flat gradient buffer).
@@ -628,24 +667,17 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         s = enc.blocks[i]
         if dta is not None and i == aux_idx:
             ops.axpy_(dx, dta, 1.0)
+        lin_bwd = _linear_backward16 if GEMM_MODE == "f16x3" else _linear_backward32
         # MLP
-        ops.linear_wgrad(dx, s.h1, G[p + "mlp.fc2.weight"], accumulate=True)
-        ops.colsum(dx, G[p + "mlp.fc2.bias"], accumulate=True)
-        dpre1 = ops.linear_dgrad(dx, W[p + "mlp.fc2.weight"], dgelu_of=s.pre1)
-        ops.linear_wgrad(dpre1, s.ln2, G[p + "mlp.fc1.weight"], accumulate=True)
-        ops.colsum(dpre1, G[p + "mlp.fc1.bias"], accumulate=True)
-        dln2 = ops.linear_dgrad(dpre1, W[p + "mlp.fc1.weight"])
+        dpre1 = lin_bwd(P, dx, s.h1, p + "mlp.fc2", dgelu_of=s.pre1)
+        dln2 = lin_bwd(P, dpre1, s.ln2, p + "mlp.fc1")
         del dpre1
         dx_mid = ops.layernorm_bwd(dln2, s.x_mid, W[p + "norm2.weight"], s.mean2, s.rstd2,
                                    G[p + "norm2.weight"], G[p + "norm2.bias"], dres=dx)
         # attention
-        ops.linear_wgrad(dx_mid, s.att, G[p + "attn.proj.weight"], accumulate=True)
-        ops.colsum(dx_mid, G[p + "attn.proj.bias"], accumulate=True)
-        datt = ops.linear_dgrad(dx_mid, W[p + "attn.proj.weight"])
+        datt = lin_bwd(P, dx_mid, s.att, p + "attn.proj")
         dqkv = ops.attention_bwd(s.qkv, s.att, datt, s.lse, B, N, Hh, hd, scale)
-        ops.linear_wgrad(dqkv, s.ln1, G[p + "attn.qkv.weight"], accumulate=True)
-        ops.colsum(dqkv, G[p + "attn.qkv.bias"], accumulate=True)
-        dln1 = ops.linear_dgrad(dqkv, W[p + "attn.qkv.weight"])
+        dln1 = lin_bwd(P, dqkv, s.ln1, p + "attn.qkv")
         del dqkv, datt
         dx = ops.layernorm_bwd(dln1, s.x_in, W[p + "norm1.weight"], s.mean1, s.rstd1,
                                G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid)

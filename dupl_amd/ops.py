@@ -112,13 +112,61 @@ def split16(x: Tensor, out: Optional[Split16] = None) -> Split16:
     return out
 
 
+_SCALE_RINGS = {}
+_RING = 128
+
+
+def _scale_slot(device):
+    """Next slot of this stream's ring of {scale, 1/scale, amax word, -} records (zero-initialised once; every scaled
+    split_prepare zeroes the amax word of its successor, so the ring is self-cleaning in stream order)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ring = _SCALE_RINGS.get(key)
+    if ring is None:
+        ring = [torch.zeros((_RING, 4), device=device, dtype=torch.float32), 0]
+        _SCALE_RINGS[key] = ring
+    buf, i = ring
+    ring[1] = (i + 1) % _RING
+    base = buf.data_ptr()
+    return base + 16 * i, base + 16 * ((i + 1) % _RING) + 8, buf[i]
+
+
+def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad: int = 0):
+    """Backward-path operand preparation (csrc/split_prep.hip): fp32 [R, C] -> row-major planes [R, C] and / or transposed
+    planes [C, Rp] (Rp = rows_pad >= R, zero-filled), optionally scaled by the power of two that brings max|x| into
+    [2^14, 2^15) (gradients).  Returns (rm Split16 | None, T Split16 | None, alpha: int device pointer of 1 / scale | None;
+    valid for the next ~128 scaled calls on this stream)."""
+    _chk(x)
+    R, C = x.shape
+    Rp = rows_pad if rows_pad else (R + 31) // 32 * 32
+    rm = split16_empty(R, C, x.device) if want_rm else None
+    T = split16_empty(C, Rp, x.device) if want_T else None
+    slot = nxt = rec = None
+    if scaled:
+        slot, nxt, rec = _scale_slot(x.device)
+    L().dupl_split_prepare(x.data_ptr(), x.stride(0), R, C, slot, nxt, rm.hi if rm else None, rm.lo if rm else None,
+                           T.hi if T else None, T.lo if T else None, Rp, _stream())
+    if scaled:
+        for o in (rm, T):
+            if o is not None:
+                o.planes._dupl_scale = rec      # view of the ring record {scale, 1 / scale, ...} (tests read it)
+        return rm, T, slot + 4
+    return rm, T, None
+
+
 def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False, relu: bool = False,
              res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None,
-             want_f32: bool = True, out16: Optional[Split16] = None, want16: bool = False, device=None):
-    """y = act(x W^T + bias) (+ res) on the f16x3 split GEMM.  x: Split16 / Split16View [M, K]; W: Split16 [N, K].
+             want_f32: bool = True, out16: Optional[Split16] = None, want16: bool = False, device=None,
+             alpha: Optional[int] = None, accumulate: bool = False, dgelu_of: Optional[Tensor] = None,
+             relumask_of: Optional[Tensor] = None):
+    """y = act(alpha * x W^T + bias) (+ res) on the f16x3 split GEMM.  x: Split16 / Split16View [M, K]; W: Split16 [N, K].
+    alpha: device pointer of a float (inverse scale of scaled gradient planes).  accumulate: out += alpha * x W^T (weight
+    gradients; split-K).  dgelu_of / relumask_of: multiply by gelu'(pre) / (post > 0) (data gradients through an activation).
     Returns (y fp32 [M, N] or None, y as Split16 or None)."""
     M, K, N = x.rows, x.cols, W.rows
     assert W.cols == K and K % 32 == 0
+    if dgelu_of is not None or relumask_of is not None:
+        assert store_pre is None
+        store_pre = dgelu_of if dgelu_of is not None else relumask_of
     dev = device if device is not None else (x.planes.device if isinstance(x, Split16) else x.base.planes.device)
     y = None
     if want_f32 or out is not None:
@@ -135,7 +183,10 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     d.ldo = N
     d.ldr = res.stride(0) if res is not None else 0
     d.ldaux = store_pre.stride(0) if store_pre is not None else 0
-    d.flags = (_lib.GEMM_GELU if gelu else 0) | (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_STORE_PRE if store_pre is not None else 0)
+    aux_flag = _lib.GEMM_MUL_DGELU if dgelu_of is not None else (_lib.GEMM_MUL_RELUMASK if relumask_of is not None else
+                                                                  (_lib.GEMM_STORE_PRE if store_pre is not None else 0))
+    d.flags = (_lib.GEMM_GELU if gelu else 0) | (_lib.GEMM_RELU if relu else 0) | aux_flag | (_lib.GEMM_ACCUM if accumulate else 0)
+    d.alpha_dev = alpha
     L().dupl_gemm_f16x3(ctypes.byref(d), _stream())
     return y, y16
 

@@ -63,7 +63,10 @@ int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
  * fp32 accumulation, 3 v_mfma_f32_32x32x16_f16 per 32x32x16 block.  Same reference sites as dupl_gemm_f32 for the
  * k-contiguous x k-contiguous case (every nn.Linear forward: vit.py:92-102,115-122,136).  Operands are passed as two
  * fp16 planes each ([rows][ld] halfs); the result can be written as fp32 and / or as planes (the next GEMM's A operand).
- *   C = act(A . B^T + bias) (+ res);   flags: DUPL_GEMM_GELU | DUPL_GEMM_RELU | DUPL_GEMM_STORE_PRE (aux = pre-activation)
+ *   C = act(alpha * A . B^T + bias) (+ res);   flags: DUPL_GEMM_GELU | DUPL_GEMM_RELU | DUPL_GEMM_STORE_PRE (aux =
+ *   pre-activation) | DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK (aux read) | DUPL_GEMM_ACCUM (C += alpha * A . B^T, split-K
+ *   with fp32 atomics: the weight gradients).  The backward GEMMs (autograd of vit.py:92-136) reach this layout through
+ *   transposed operand planes (dupl_split_prepare): dgrad = dy . (W^T)^T, wgrad = dy^T . (x^T)^T.
  * K % 32 == 0; lda / ldb in halfs, multiples of 8; plane pointers 16-byte aligned. */
 typedef struct dupl_gemm16_desc {
     const void* A_hi; const void* A_lo;   /* [M][lda] fp16 */
@@ -77,13 +80,25 @@ typedef struct dupl_gemm16_desc {
     int32_t lda, ldb, ldc, ldo, ldr, ldaux;
     int32_t flags;
     int32_t reserved;
+    const float* alpha_dev;               /* device scalar multiplied into A.B^T before the epilogue (inverse operand scales of
+                                             scaled gradient planes, dupl_split_prepare), or NULL (= 1) */
 } dupl_gemm16_desc;
 int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream);
 /* the operand split of the GEMM above: n fp32 values (n % 4 == 0) -> hi / lo fp16 planes (no reference counterpart) */
 int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, dupl_stream_t stream);
 /* tuning knob: row-tiles per group of the block order of dupl_gemm_f16x3 */
 int dupl_set_gemm16_group(int32_t gm);
-/* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 1 128x128, 2 256x128 on 8 waves, 3 128x64, 4 64x128) */
+/* operand preparation for the backward split GEMMs (csrc/split_prep.hip): x [R][ld] fp32 (C columns) -> row-major planes
+ * hi / lo [R][C] and / or transposed planes hiT / loT [C][Rp] (Rp >= R, multiple of 8; rows R.. are zeros).
+ * slot != NULL (gradients, far below fp16's normal range): the tensor is scaled by the power of two that brings its
+ * max-abs into [2^14, 2^15); slot = 4 floats of device memory {scale, 1 / scale, amax word, -} whose amax word must be
+ * ZERO on entry; pass slot + 1 as the GEMM's alpha_dev.  next_bits (optional): the amax word of the slot the next scaled
+ * call on this stream will use -- it is zeroed by this call (a ring of slots then needs no memset).
+ * No reference counterpart (the reference's autograd calls ATen GEMMs on fp32 operands). */
+int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
+                       void* hiT, void* loT, int32_t Rp, dupl_stream_t stream);
+/* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 1 128x128, 2 256x128 on 8 waves, 3 128x64, 4 64x128, 5 / 6 128x128
+ * on 8 waves) */
 int dupl_set_gemm16_tile(int32_t t);
 /* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
 int dupl_set_gemm_tile(int32_t rows);

@@ -613,3 +613,51 @@ def test_attention_fwd16_is_fp32_equivalent(dev, B, N):
     big = ops.split16_empty(B * N + 128, D, dev)
     ops.attention_fwd16(qkv16, B, N, H, hd, scale, out16=big.rows_slice(64, 64 + B * N))
     assert torch.equal(big.planes[:, 64:64 + B * N], o16.planes)
+
+
+@pytest.mark.parametrize("M,N,K", [(3140, 768, 3072), (785, 2304, 768), (130, 96, 288), (50, 384, 96)])
+def test_backward_split_gemms_fp32_equivalent(dev, M, N, K):
+    """The backward GEMMs of a Linear on the f16x3 path: dupl_split_prepare (power-of-two scaling of the gradient from its
+    max-abs, row-major + transposed planes, zero padding of the token axis) + dupl_gemm_f16x3 with alpha / ACCUM + split-K
+    / gelu' epilogues vs fp64 references, with gradient magnitudes as they occur (1e-6): at least as close as the f32 MFMA
+    kernels (bar 2x + 1e-7 relative)."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = (torch.randn(M, N, generator=g) * 3e-6).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    pre = torch.randn(M, K, generator=g).to(dev)
+    Mp = (M + 31) // 32 * 32
+    dy16, dyT16, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=True, rows_pad=Mp)
+    sc = dy16.planes._dupl_scale.cpu()
+    amax = float(dy.abs().max())
+    assert 2.0 ** 14 <= amax * float(sc[0]) < 2.0 ** 15 and float(sc[0]) * float(sc[1]) == 1.0
+    rec = (dy16.planes[0].float() + dy16.planes[1].float() / 2048.0) * float(sc[1])
+    assert float((rec - dy).abs().max()) <= 2.0 ** -22 * amax
+    assert torch.equal(dyT16.planes[:, :, :M], dy16.planes.transpose(1, 2)) and float(dyT16.planes[:, :, M:].abs().max() if Mp > M else 0) == 0
+    _, xT16, _ = ops.split_prepare(x, scaled=False, want_rm=False, want_T=True, rows_pad=Mp)
+    assert torch.equal(xT16.planes[:, :, :M], ops.split16(x).planes.transpose(1, 2))
+    # wgrad: dW += dy^T x  (on top of existing content)
+    gw0 = torch.randn(N, K, generator=g).to(dev) * 1e-6
+    gw16, gw32 = gw0.clone(), gw0.clone()
+    ops.linear16(dyT16, xT16, out=gw16, accumulate=True, alpha=alpha)
+    ops.linear_wgrad(dy, x, gw32, accumulate=True)
+    ref = gw0.double() + dy.double().t() @ x.double()
+    scw = float(ref.abs().max())
+    e16, e32 = float((gw16.double() - ref).abs().max()) / scw, float((gw32.double() - ref).abs().max()) / scw
+    print(f"wgrad {M}x{N}x{K}: f16x3 {e16:.2e} f32 {e32:.2e}")
+    assert e16 <= 2.0 * e32 + 1e-7
+    # dgrad: dx = (dy W) * gelu'(pre)
+    _, WT16, _ = ops.split_prepare(W, scaled=False, want_rm=False, want_T=True, rows_pad=N)
+    dx16, _ = ops.linear16(dy16, WT16, alpha=alpha, dgelu_of=pre)
+    dx32 = ops.linear_dgrad(dy, W, dgelu_of=pre)
+    pd = pre.double()
+    gp = 0.5 * (1 + torch.erf(pd / 2 ** 0.5)) + pd * torch.exp(-0.5 * pd * pd) / (2 * 3.141592653589793) ** 0.5
+    refx = (dy.double() @ W.double()) * gp
+    scx = float(refx.abs().max())
+    d16, d32 = float((dx16.double() - refx).abs().max()) / scx, float((dx32.double() - refx).abs().max()) / scx
+    print(f"dgrad {M}x{N}x{K}: f16x3 {d16:.2e} f32 {d32:.2e}")
+    assert d16 <= 2.0 * d32 + 2e-7
+    # an all-zero gradient does not poison the scale
+    z16, _, a0 = ops.split_prepare(torch.zeros(64, 96, device=dev), scaled=True, want_rm=True, want_T=False)
+    assert float(z16.planes._dupl_scale[0]) == 1.0 and float(z16.planes.abs().max()) == 0.0
