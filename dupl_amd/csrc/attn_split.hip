@@ -151,6 +151,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
     const int nkt = (N + KT - 1) / KT;
     issue(0, 0);
     for (int t = 0; t < nkt; ++t) {
+        // EVERY wave must have its own DMA pieces of tile t landed before it arrives at the barrier -- including waves
+        // that do not compute (query rows past N): hipcc places the vmcnt wait of a direct-to-LDS load before the wave's
+        // own first LDS read, i.e. nowhere on the `continue` path, so it is written out (found as a cross-wave race:
+        // partial query blocks read K / V^T pieces that an idle wave had issued but not yet seen land).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nkt) issue(t + 1, (t + 1) & 1);
         if (!wave_active) continue;

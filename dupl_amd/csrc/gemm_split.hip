@@ -8,13 +8,16 @@
 // 5.3x the f32-MFMA rate at the same operand bytes (two f16 planes = one fp32).  The cross terms accumulate in their
 // own register set (the 2048 scaling keeps `lo` in fp16's normal range: no subnormal loss, no per-tensor scale search).
 //
-// NT layout only (A [M][K], B = W [N][K], both k-contiguous = every Linear forward), K % 32 == 0.
-// Block = 256 threads = 4 waves (2 x 2), tile 128 x 128 x 32, wave tile 64 x 64 (2 x 2 MFMA tiles, two accumulator sets).
-// Global -> LDS by direct-to-LDS DMA (global_load_lds_dwordx4): wave w streams operand plane w (A_hi, A_lo, B_hi, B_lo),
-// 8 pieces of 16 rows x 64 B per k-tile; the LDS image is lane-linear, so the bank swizzle is applied on the SOURCE side:
-// 16-byte chunk j of row r is stored at chunk j ^ ((r >> 2) & 3), which makes every ds_read_b128 lane group hit 64
-// distinct banks.  Two LDS stages (64 KB, 2 blocks / CU), one barrier per k-tile: the DMA of tile t+1 runs under the
-// MFMAs of tile t.
+// k-contiguous x k-contiguous layout only (A [M][K], B [N][K]: every Linear forward directly; the backward GEMMs through
+// transposed operand planes, split_prep.hip), K % 32 == 0.
+// Block tile 128 x 128 x 32 on 8 waves (2 x 4, wave tile 64 x 32 = 2 x 1 MFMA tiles, two accumulator sets, 103 VGPRs ->
+// 4 waves / SIMD with 2 blocks / CU) or 128 x 64 on 4 waves when the grid would leave most block slots empty.
+// Global -> LDS by direct-to-LDS DMA (global_load_lds_dwordx4): a k-tile is 1 KB pieces of 16 rows x 64 bytes in the order
+// A_hi | A_lo | B_hi | B_lo, piece g is fetched by wave g % NW; the LDS image is lane-linear, so the bank swizzle is applied
+// on the SOURCE side: 16-byte chunk j of row r is stored at chunk j ^ ((r >> 2) & 3), which makes every ds_read_b128
+// lane group hit 64 distinct banks (SQ_LDS_BANK_CONFLICT = 0).  Two LDS stages (64 KB, 2 blocks / CU), one barrier per
+// k-tile: the DMA of tile t+1 runs under the MFMAs of tile t.  Accumulating GEMMs (weight gradients) split K over
+// gridDim.y and add with fp32 atomics.
 #include "common.h"
 #include "../../include/dupl_hip.h"
 
@@ -119,8 +122,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINB) void gemm_f16x3_kernel(const 
     const int nt = te - tb;
     issue(tb, 0);
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();                       // s_waitcnt vmcnt(0): my DMA of tile t landed; barrier: everyone's did, and
-                                               // everyone is done reading the other stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of tile t have landed (written out: hipcc only
+                                                           // guarantees this wait before the wave's OWN first LDS read)
+        __syncthreads();                       // everyone's pieces landed, and everyone is done reading the other stage
         if (t + 1 < nt) issue(tb + t + 1, (t + 1) & 1);
         const char* st = smem + (t & 1) * STAGE;
 #pragma unroll
@@ -196,8 +200,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINB) void gemm_f16x3_kernel(const 
 }  // namespace
 
 static int g16_group_m = 8;
-static int g16_tile = 0;     // 0 = heuristic; 1: 128x128 (4 waves), 2: 256x128 (8 waves), 3: 128x64, 4: 64x128,
-                             // 5 / 6: 128x128 on 8 waves (wave tile 64x32 / 32x64)
+static int g16_tile = 0;     // 0 = heuristic; 3: 128x64 on 4 waves; 5: 128x128 on 8 waves (wave tile 64x32 in both).  Measured
+                             // and dropped: 64x64 wave tiles on 4 / 8 waves (2 waves / SIMD: -10..25 %), 256x128 on 16 waves
 
 extern "C" int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, dupl_stream_t stream) {
     (void)hipGetLastError();
@@ -218,7 +222,7 @@ extern "C" int dupl_set_gemm16_group(int32_t gm) {
 }
 
 extern "C" int dupl_set_gemm16_tile(int32_t t) {
-    if (t < 0 || t > 6) return DUPL_ERR_ARG;
+    if (t != 0 && t != 3 && t != 5) return DUPL_ERR_ARG;
     g16_tile = t;
     return DUPL_OK;
 }
@@ -257,13 +261,7 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         tile = b128 < 200 ? 3 : 5;
     }
     auto blocks = [&](int bm, int bn) { return dim3((unsigned)(((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn)), (unsigned)ksplit); };
-    switch (tile) {
-        case 1: hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, 2>), blocks(128, 128), dim3(256), 0, s, *d, g16_group_m); break;
-        case 2: hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 4, 2, 1>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_m); break;
-        case 3: hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 2, 2>), blocks(128, 64), dim3(256), 0, s, *d, g16_group_m); break;
-        case 4: hipLaunchKernelGGL((gemm_f16x3_kernel<1, 2, 2, 2, 2>), blocks(64, 128), dim3(256), 0, s, *d, g16_group_m); break;
-        case 5: hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 4, 4>), blocks(128, 128), dim3(512), 0, s, *d, g16_group_m); break;
-        default: hipLaunchKernelGGL((gemm_f16x3_kernel<1, 2, 4, 2, 4>), blocks(128, 128), dim3(512), 0, s, *d, g16_group_m); break;
-    }
+    if (tile == 3) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 2, 2>), blocks(128, 64), dim3(256), 0, s, *d, g16_group_m);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 4, 4>), blocks(128, 128), dim3(512), 0, s, *d, g16_group_m);
     return dupl_launch_status();
 }

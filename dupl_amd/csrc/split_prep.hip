@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
                                                        unsigned int* __restrict__ next_bits, __half* __restrict__ hi,
                                                        __half* __restrict__ lo, __half* __restrict__ hiT, __half* __restrict__ loT,
                                                        int Rp) {
-    __shared__ __half th[64][66], tl[64][66];
+    __shared__ unsigned int tile[64][65];            // (hi | lo << 16) per element; odd stride: conflict-free both ways
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     float s = 1.f;
     if (slot) {
@@ -70,33 +70,40 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
         const int c = tid + 256 * i;            // 1024 float4 chunks: row c / 16, cols (c % 16) * 4
         const int r = c >> 4, cc = (c & 15) << 2;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + r < R && c0 + cc < C) v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + r) * ld + c0 + cc);   // C % 4 == 0
+        const bool in = r0 + r < R && c0 + cc < C;          // C % 4 == 0
+        if (in) v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + r) * ld + c0 + cc);
         __half h[4], l[4];
         split_f32(v.x * s, h[0], l[0]);
         split_f32(v.y * s, h[1], l[1]);
         split_f32(v.z * s, h[2], l[2]);
         split_f32(v.w * s, h[3], l[3]);
-        if (hi && r0 + r < R && c0 + cc < C) {
+        if (hi && in) {
             *reinterpret_cast<uint2*>(hi + (size_t)(r0 + r) * C + c0 + cc) = *reinterpret_cast<const uint2*>(h);
             *reinterpret_cast<uint2*>(lo + (size_t)(r0 + r) * C + c0 + cc) = *reinterpret_cast<const uint2*>(l);
         }
         if (hiT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { th[r][cc + j] = h[j]; tl[r][cc + j] = l[j]; }
+            for (int j = 0; j < 4; ++j)
+                tile[r][cc + j] = (unsigned int)__half_as_ushort(h[j]) | ((unsigned int)__half_as_ushort(l[j]) << 16);
         }
     }
     if (!hiT) return;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i;            // 512 chunks of 8 halfs: column c / 8, rows (c % 8) * 8 .. + 7
-        const int col = c >> 3, rr = (c & 7) << 3;
+        const int c = tid + 256 * i;            // 512 chunks of 8 rows: column c / 8, rows (c % 8) * 8 .. + 7 (8 lanes = one
+        const int col = c >> 3, rr = (c & 7) << 3;   // 128-byte run of a transposed row; 2-way LDS read conflicts at most)
         if (c0 + col >= C || r0 + rr >= Rp) continue;       // Rp % 8 == 0
-        __half oh[8], ol[8];
+        unsigned int w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { oh[j] = th[rr + j][col]; ol[j] = tl[rr + j][col]; }   // rows >= R were loaded as zeros
-        *reinterpret_cast<uint4*>(hiT + (size_t)(c0 + col) * Rp + r0 + rr) = *reinterpret_cast<const uint4*>(oh);
-        *reinterpret_cast<uint4*>(loT + (size_t)(c0 + col) * Rp + r0 + rr) = *reinterpret_cast<const uint4*>(ol);
+        for (int j = 0; j < 8; ++j) w[j] = tile[rr + j][col];           // rows >= R were loaded as zeros
+        uint4 oh, ol;
+        oh.x = (w[0] & 0xffffu) | (w[1] << 16); oh.y = (w[2] & 0xffffu) | (w[3] << 16);
+        oh.z = (w[4] & 0xffffu) | (w[5] << 16); oh.w = (w[6] & 0xffffu) | (w[7] << 16);
+        ol.x = (w[0] >> 16) | (w[1] & 0xffff0000u); ol.y = (w[2] >> 16) | (w[3] & 0xffff0000u);
+        ol.z = (w[4] >> 16) | (w[5] & 0xffff0000u); ol.w = (w[6] >> 16) | (w[7] & 0xffff0000u);
+        *reinterpret_cast<uint4*>(hiT + (size_t)(c0 + col) * Rp + r0 + rr) = oh;
+        *reinterpret_cast<uint4*>(loT + (size_t)(c0 + col) * Rp + r0 + rr) = ol;
     }
 }
 

@@ -565,10 +565,18 @@ def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
     dd, dil = cfg.decoder_dim, cfg.decoder_dilation
     col6 = torch.empty((B * n, 9 * D), device=x.device, dtype=torch.float32)
     ops.L().dupl_im2col_dil3(tf.data_ptr() + 4 * D, col6.data_ptr(), B, h, w, D, dil, D, (n + 1) * D, ops._stream())
-    h6 = ops.linear(col6, P.w["decoder.conv6.weight"].view(dd, -1), relu=True)
+    f16 = GEMM_MODE == "f16x3"        # the two 3x3 convs (K = 9 * 768 / 9 * 512) as split GEMMs; conv8 (N = classes) stays f32
+    if f16:
+        P.store.ensure_w16(P.student)
+        h6, _ = ops.linear16(ops.split16(col6), P.w16("decoder.conv6.weight", dd), relu=True)
+    else:
+        h6 = ops.linear(col6, P.w["decoder.conv6.weight"].view(dd, -1), relu=True)
     col7 = torch.empty((B * n, 9 * dd), device=x.device, dtype=torch.float32)
     ops.L().dupl_im2col_dil3(h6.data_ptr(), col7.data_ptr(), B, h, w, dd, dil, dd, n * dd, ops._stream())
-    h7 = ops.linear(col7, P.w["decoder.conv7.weight"].view(dd, -1), relu=True)
+    if f16:
+        h7, _ = ops.linear16(ops.split16(col7), P.w16("decoder.conv7.weight", dd), relu=True)
+    else:
+        h7 = ops.linear(col7, P.w["decoder.conv7.weight"].view(dd, -1), relu=True)
     seg_tok = ops.linear(h7, P.w["decoder.conv8.weight"].view(P.num_classes, dd))
     seg = ops.tokens_to_nchw(seg_tok, B, n, P.num_classes, h, w, skip_cls=False)
     sv = None
@@ -581,14 +589,18 @@ def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
 # ------------------------------------------------------------------------------------------------
 # backward
 # ------------------------------------------------------------------------------------------------
-def _linear_backward32(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu_of: Optional[Tensor] = None) -> Tensor:
+def _linear_backward32(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu_of: Optional[Tensor] = None,
+                       has_bias: bool = True) -> Tensor:
     """Backward of y = x W^T + b on the exact-f32 MFMA kernels: accumulates dW, db; returns dx (* gelu'(dgelu_of))."""
+    N = dy.shape[1]
     ops.linear_wgrad(dy, x, P.g[name + ".weight"], accumulate=True)
-    ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
-    return ops.linear_dgrad(dy, P.w[name + ".weight"], dgelu_of=dgelu_of)
+    if has_bias:
+        ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
+    return ops.linear_dgrad(dy, P.w[name + ".weight"].view(N, -1), dgelu_of=dgelu_of)
 
 
-def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu_of: Optional[Tensor] = None) -> Tensor:
+def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu_of: Optional[Tensor] = None,
+                       has_bias: bool = True) -> Tensor:
     """The same on the f16x3 split GEMM (fp32-equivalent).  The gradient dy is scaled by a power of two from its own
     max-abs before it is split (its values are far below fp16's normal range); both GEMMs run as k-contiguous products
     through transposed operand planes:  dW += dy^T16 . (x^T16)^T,  dx = dy16 . (W^T16)^T  (csrc/split_prep.hip)."""
@@ -598,7 +610,8 @@ def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
     _, xT16, _ = ops.split_prepare(x, scaled=False, want_rm=False, want_T=True, rows_pad=Mp)
     gw = P.g[name + ".weight"]
     ops.linear16(dyT16, xT16, out=gw.view(N, -1), accumulate=True, alpha=alpha)
-    ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
+    if has_bias:
+        ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
     dx, _ = ops.linear16(dy16, P.w16T(name + ".weight", N), alpha=alpha, dgelu_of=dgelu_of)
     return dx
 
@@ -644,13 +657,12 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         ops.nchw_to_tokens_add(dseg.contiguous(), dseg_tok, B, n, NC, skip_cls=False)
         ops.linear_wgrad(dseg_tok, sv.h7, G["decoder.conv8.weight"], accumulate=True)
         dh7 = ops.linear_dgrad(dseg_tok, W["decoder.conv8.weight"].view(NC, dd), relumask_of=sv.h7)
-        ops.linear_wgrad(dh7, sv.col7, G["decoder.conv7.weight"], accumulate=True)
-        dcol7 = ops.linear_dgrad(dh7, W["decoder.conv7.weight"].view(dd, -1))
+        conv_bwd = _linear_backward16 if GEMM_MODE == "f16x3" else _linear_backward32
+        dcol7 = conv_bwd(P, dh7, sv.col7, "decoder.conv7", has_bias=False)
         dh6 = torch.empty((B * n, dd), device=dev, dtype=torch.float32)
         ops.L().dupl_col2im_dil3(dcol7.data_ptr(), dh6.data_ptr(), B, h, w, dd, dil, dd, n * dd, 0, sv.h6.data_ptr(), ops._stream())
         del dcol7
-        ops.linear_wgrad(dh6, sv.col6, G["decoder.conv6.weight"], accumulate=True)
-        dcol6 = ops.linear_dgrad(dh6, W["decoder.conv6.weight"].view(dd, -1))
+        dcol6 = conv_bwd(P, dh6, sv.col6, "decoder.conv6", has_bias=False)
         ops.L().dupl_col2im_dil3(dcol6.data_ptr(), dtf.data_ptr() + 4 * D, B, h, w, D, dil, D, N * D, 1, None, ops._stream())
         del dcol6
         P.mark_grad(SEG_DECODER)

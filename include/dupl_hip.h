@@ -97,8 +97,7 @@ int dupl_set_gemm16_group(int32_t gm);
  * No reference counterpart (the reference's autograd calls ATen GEMMs on fp32 operands). */
 int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
                        void* hiT, void* loT, int32_t Rp, dupl_stream_t stream);
-/* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 1 128x128, 2 256x128 on 8 waves, 3 128x64, 4 64x128, 5 / 6 128x128
- * on 8 waves) */
+/* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 3: 128x64 on 4 waves, 5: 128x128 on 8 waves) */
 int dupl_set_gemm16_tile(int32_t t);
 /* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
 int dupl_set_gemm_tile(int32_t rows);

@@ -661,3 +661,46 @@ def test_backward_split_gemms_fp32_equivalent(dev, M, N, K):
     # an all-zero gradient does not poison the scale
     z16, _, a0 = ops.split_prepare(torch.zeros(64, 96, device=dev), scaled=True, want_rm=True, want_T=False)
     assert float(z16.planes._dupl_scale[0]) == 1.0 and float(z16.planes.abs().max()) == 0.0
+
+
+def test_split_kernels_are_deterministic_under_stream_concurrency(dev):
+    """The two students run on two HIP streams, so any two of the direct-to-LDS (DMA) kernels may share a CU.  Each kernel,
+    launched concurrently with another one on a second stream, must reproduce its solo result BIT FOR BIT -- incl. partial
+    query blocks of the attention kernel, whose idle waves still feed the DMA ring (a missing vmcnt wait on that path was a
+    real cross-wave race: intermittent 1e-3 CAM errors in two-stream mode only)."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(0)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def mk_gemm(M, N, K):
+        x, W = torch.randn(M, K, generator=g).to(dev), (torch.randn(N, K, generator=g) * 0.05).to(dev)
+        xs, Ws = ops.split16(x), ops.split16(W)
+        out = torch.empty(M, N, device=dev)
+        ops.linear16(xs, Ws, None, out=out)
+        torch.cuda.synchronize()
+        return (lambda: ops.linear16(xs, Ws, None, out=out)), out, out.clone()
+
+    def mk_attn(B, N):
+        qkv = torch.randn(B * N, 3 * 768, generator=g).to(dev)
+        q16 = ops.split16(qkv)
+        out = torch.empty(B * N, 768, device=dev)
+        ops.attention_fwd16(q16, B, N, 12, 64, 0.125, out=out)
+        torch.cuda.synchronize()
+        return (lambda: ops.attention_fwd16(q16, B, N, 12, 64, 0.125, out=out)), out, out.clone()
+
+    pairs = [("attention || attention", mk_attn(2, 785), mk_attn(1, 1765)),
+             ("gemm 128x128 || attention", mk_gemm(3924, 2304, 768), mk_attn(2, 785)),
+             ("gemm 128x64 || gemm 128x128", mk_gemm(1570, 768, 3072), mk_gemm(3924, 3072, 768))]
+    for name, (ra, oa, refa), (rb, ob, refb) in pairs:
+        bad = 0
+        for _ in range(12):
+            with torch.cuda.stream(s1):
+                for _ in range(3):
+                    ra()
+            with torch.cuda.stream(s2):
+                for _ in range(3):
+                    rb()
+            torch.cuda.synchronize()
+            bad += int(not (torch.equal(oa, refa) and torch.equal(ob, refb)))
+        print(f"{name}: {bad}/12 rounds deviate from the solo result")
+        assert bad == 0, name
