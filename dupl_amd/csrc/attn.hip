@@ -297,7 +297,7 @@ __global__ __launch_bounds__(ANT, 2) void attn_bwd_dq_kernel(const float* __rest
             for (int e = 0; e < 16; ++e) {
                 const bool kvld = kb + acc_row(e, hf) < N;
                 const float p = kvld ? fast_exp(s[e] - my_lse) : 0.f;
-                s[e] = p * (dp[e] - my_delta);  // dS^T[key][q]
+                s[e] = __fmul_rn(p, __fsub_rn(dp[e], my_delta));  // dS^T[key][q]; never contracted to fma(p, dp, -p*delta)
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(ANT, 2) void attn_bwd_dkv_kernel(const float* __res
                 const bool qvld = (qb + acc_row(e, hf) < N) && kv;
                 const float p = qvld ? fast_exp(s[e] - Ls[ql]) : 0.f;
                 s[e] = p;                        // P[q][key]
-                dp[e] = p * (dp[e] - Ds[ql]);    // dS[q][key]
+                dp[e] = __fmul_rn(p, __fsub_rn(dp[e], Ds[ql]));    // dS[q][key]; never contracted
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {

@@ -200,9 +200,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
             for (int e = 0; e < 16; ++e) {
                 const float pv = fast_exp(sM[kt2][e] - m_new);
                 psum += pv;
-                const _Float16 hh = (_Float16)pv;
+                float px = pv;
+                asm volatile("" : "+v"(px));         // one materialised fp32 value for both uses (see split_f32, common.h)
+                const _Float16 hh = (_Float16)px;
                 ph[2 * kt2 + (e >> 3)][e & 7] = hh;
-                pl[2 * kt2 + (e >> 3)][e & 7] = (_Float16)((pv - (float)hh) * DUPL_LO_SCALE);
+                pl[2 * kt2 + (e >> 3)][e & 7] = (_Float16)((px - (float)hh) * DUPL_LO_SCALE);
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;

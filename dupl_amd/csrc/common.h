@@ -94,8 +94,13 @@ __device__ __forceinline__ void atomic_min_f(float* addr, float v) {
 
 // f16x3 operand split (gemm_split.hip): x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048); saturating
 constexpr float DUPL_LO_SCALE = 2048.f;
+// The empty asm pins x as ONE materialised fp32 value.  Without it hipcc may fold the arithmetic that produced x into the
+// f16 conversion for one of the two uses below (v_fma_mixlo_f16 on the exact product) but not for the other
+// (v_cvt_pk_f16_f32 of the fp32-rounded product): where the two roundings differ, `hi` and the residual behind `lo`
+// disagree by one fp16 ulp of hi -- a rare, data-dependent 2^-11 relative error (found in the dk kernel).
 __device__ __forceinline__ void split_f32(float x, __half& hi, __half& lo) {
     x = fminf(fmaxf(x, -65504.f), 65504.f);
+    asm volatile("" : "+v"(x));
     hi = __float2half_rn(x);
     lo = __float2half_rn((x - __half2float(hi)) * DUPL_LO_SCALE);
 }

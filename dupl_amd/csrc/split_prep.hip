@@ -31,16 +31,17 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     }
 }
 
-// scale = 2^(15 - e), with amax in [2^(e-1), 2^e): amax * scale in [2^14, 2^15)   (1 for amax == 0 / non-finite)
-__device__ __forceinline__ void scale_from_amax(unsigned int bits, float& s, float& inv) {
+// scale = 2^(target - e), with amax in [2^(e-1), 2^e): amax * scale in [2^(target-1), 2^target)   (1 for amax == 0 /
+// non-finite).  target = 15 for GEMM operands; the attention backward uses 4 (dP = dO v^T is summed before its split).
+__device__ __forceinline__ void scale_from_amax(unsigned int bits, int target, float& s, float& inv) {
     const float a = __uint_as_float(bits);
     s = 1.f;
     inv = 1.f;
     if (a > 0.f && a < INFINITY) {
         int e;
         frexpf(a, &e);
-        s = ldexpf(1.f, 15 - e);
-        inv = ldexpf(1.f, e - 15);
+        s = ldexpf(1.f, target - e);
+        inv = ldexpf(1.f, e - target);
     }
 }
 
@@ -51,13 +52,13 @@ __device__ __forceinline__ void scale_from_amax(unsigned int bits, float& s, flo
 __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__ x, int ld, int R, int C, float* __restrict__ slot,
                                                        unsigned int* __restrict__ next_bits, __half* __restrict__ hi,
                                                        __half* __restrict__ lo, __half* __restrict__ hiT, __half* __restrict__ loT,
-                                                       int Rp) {
+                                                       int Rp, int target) {
     __shared__ unsigned int tile[64][65];            // (hi | lo << 16) per element; odd stride: conflict-free both ways
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     float s = 1.f;
     if (slot) {
         float inv;
-        scale_from_amax(reinterpret_cast<const unsigned int*>(slot)[2], s, inv);
+        scale_from_amax(reinterpret_cast<const unsigned int*>(slot)[2], target, s, inv);
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
             slot[0] = s;
             slot[1] = inv;
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
 }  // namespace
 
 extern "C" int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
-                                  void* hiT, void* loT, int32_t Rp, dupl_stream_t stream) {
+                                  void* hiT, void* loT, int32_t Rp, int32_t target_exp, dupl_stream_t stream) {
     (void)hipGetLastError();
     if (!x || R <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C || (!hi && !hiT) || ((hi == nullptr) != (lo == nullptr)) ||
-        ((hiT == nullptr) != (loT == nullptr)) || (hiT && (Rp < R || (Rp & 7))))
+        ((hiT == nullptr) != (loT == nullptr)) || (hiT && (Rp < R || (Rp & 7))) || target_exp < 1 || target_exp > 15)
         return DUPL_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15)) return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -127,6 +128,6 @@ extern "C" int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t
     }
     const int Rt = hiT ? Rp : R;
     hipLaunchKernelGGL(split_rt_kernel, dim3((C + 63) / 64, (Rt + 63) / 64), dim3(256), 0, s, x, ld, R, C, slot,
-                       (unsigned int*)next_bits, (__half*)hi, (__half*)lo, (__half*)hiT, (__half*)loT, Rp);
+                       (unsigned int*)next_bits, (__half*)hi, (__half*)lo, (__half*)hiT, (__half*)loT, Rp, target_exp);
     return dupl_launch_status();
 }

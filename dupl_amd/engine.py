@@ -286,6 +286,7 @@ class BlockSaved:
     ln2: Tensor = None
     pre1: Tensor = None
     h1: Tensor = None
+    qkv16: object = None      # f16x3 mode, head dim 64: the fp16 hi / lo planes of qkv (operands of the split attention backward)
 
 
 @dataclass
@@ -395,6 +396,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
             for (g0, B, N, _, _) in groups:
                 lse = ops.attention_fwd16(qkv16.rows_slice(g0, g0 + B * N), B, N, H, hd, scale, need_lse=save,
                                           out=att[g0:g0 + B * N] if save else None, out16=att16.rows_slice(g0, g0 + B * N))
+            qkv16_keep = qkv16 if save else None
             del qkv16
         else:   # other head dims (the 96-dim test backbone): exact-f32 attention kernel between split GEMMs
             qkv, _ = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"])
@@ -403,6 +405,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
             for (g0, B, N, _, _) in groups:
                 _, lse = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
             att16 = ops.split16(att)
+            qkv16_keep = None
         x_mid, _ = ops.linear16(att16, P.w16(p + "attn.proj.weight", D), W[p + "attn.proj.bias"], res=t)
         del att16
         ln2, ln2_16, m2, r2 = ops.layernorm_fwd16(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save, want_f32=save)
@@ -414,7 +417,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
         del h1_16
         if save:
             sv.blocks.append(BlockSaved(x_in=t, mean1=m1, rstd1=r1, ln1=ln1, qkv=qkv, lse=lse, att=att, x_mid=x_mid,
-                                        mean2=m2, rstd2=r2, ln2=ln2, pre1=pre1, h1=h1))
+                                        mean2=m2, rstd2=r2, ln2=ln2, pre1=pre1, h1=h1, qkv16=qkv16_keep))
         t = x_out
         if i == aux_idx and i != cfg.depth - 1:
             aux = t
@@ -521,7 +524,7 @@ def _prefix_saved(sv: EncoderSaved, b: int, rows: int) -> EncoderSaved:
         out.blocks.append(BlockSaved(x_in=s.x_in[:rows], mean1=s.mean1[:rows], rstd1=s.rstd1[:rows], ln1=s.ln1[:rows],
                                      qkv=s.qkv[:rows], lse=s.lse[:b], att=s.att[:rows], x_mid=s.x_mid[:rows],
                                      mean2=s.mean2[:rows], rstd2=s.rstd2[:rows], ln2=s.ln2[:rows], pre1=s.pre1[:rows],
-                                     h1=s.h1[:rows]))
+                                     h1=s.h1[:rows], qkv16=s.qkv16.rows_slice(0, rows) if s.qkv16 is not None else None))
     out.x_last, out.mean_f, out.rstd_f = sv.x_last[:rows], sv.mean_f[:rows], sv.rstd_f[:rows]
     return out
 
@@ -688,7 +691,10 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
                                    G[p + "norm2.weight"], G[p + "norm2.bias"], dres=dx)
         # attention
         datt = lin_bwd(P, dx_mid, s.att, p + "attn.proj")
-        dqkv = ops.attention_bwd(s.qkv, s.att, datt, s.lse, B, N, Hh, hd, scale)
+        if GEMM_MODE == "f16x3" and s.qkv16 is not None and N <= 2048:
+            dqkv = ops.attention_bwd16(s.qkv16, s.att, datt, s.lse, B, N, Hh, hd, scale)
+        else:
+            dqkv = ops.attention_bwd(s.qkv, s.att, datt, s.lse, B, N, Hh, hd, scale)
         dln1 = lin_bwd(P, dqkv, s.ln1, p + "attn.qkv")
         del dqkv, datt
         dx = ops.layernorm_bwd(dln1, s.x_in, W[p + "norm1.weight"], s.mean1, s.rstd1,

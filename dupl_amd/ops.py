@@ -130,7 +130,7 @@ def _scale_slot(device):
     return base + 16 * i, base + 16 * ((i + 1) % _RING) + 8, buf[i]
 
 
-def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad: int = 0):
+def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad: int = 0, target_exp: int = 15):
     """Backward-path operand preparation (csrc/split_prep.hip): fp32 [R, C] -> row-major planes [R, C] and / or transposed
     planes [C, Rp] (Rp = rows_pad >= R, zero-filled), optionally scaled by the power of two that brings max|x| into
     [2^14, 2^15) (gradients).  Returns (rm Split16 | None, T Split16 | None, alpha: int device pointer of 1 / scale | None;
@@ -144,7 +144,7 @@ def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad
     if scaled:
         slot, nxt, rec = _scale_slot(x.device)
     L().dupl_split_prepare(x.data_ptr(), x.stride(0), R, C, slot, nxt, rm.hi if rm else None, rm.lo if rm else None,
-                           T.hi if T else None, T.lo if T else None, Rp, _stream())
+                           T.hi if T else None, T.lo if T else None, Rp, target_exp, _stream())
     if scaled:
         for o in (rm, T):
             if o is not None:
@@ -307,6 +307,22 @@ def attention_fwd16(qkv16, B: int, N: int, H: int, hd: int, scale: float, need_l
                              out16.hi if out16 is not None else None, out16.lo if out16 is not None else None, _p(lse),
                              B, N, H, hd, npad, float(scale), _stream())
     return lse
+
+
+def attention_bwd16(qkv16, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, hd: int, scale: float) -> Tensor:
+    """Attention backward on the f16x3 split kernels (head dim 64, N <= 2048): qkv16 = the planes of the qkv GEMM output the
+    forward saved; out / dout fp32 [B*N, H*hd]; returns dqkv fp32 [B*N, 3*H*hd]."""
+    assert hd == 64 and N <= 2048 and qkv16.rows == B * N
+    dev = out.device
+    dout = dout.contiguous()
+    do16, _, alpha = split_prepare(dout, scaled=True, want_rm=True, want_T=False, target_exp=4)
+    npad = (N + 63) // 64 * 64
+    scratch = torch.empty((6, B * H * hd * npad), device=dev, dtype=torch.float16)
+    delta = torch.empty((B, H, N), device=dev, dtype=torch.float32)
+    dqkv = torch.empty((B * N, 3 * H * hd), device=dev, dtype=torch.float32)
+    L().dupl_attention_bwd16(qkv16.hi, qkv16.lo, out.data_ptr(), dout.data_ptr(), do16.hi, do16.lo, alpha - 4, lse.data_ptr(),
+                             delta.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(), B, N, H, hd, npad, float(scale), _stream())
+    return dqkv
 
 
 def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, hd: int, scale: float) -> Tensor:

@@ -91,12 +91,12 @@ int dupl_set_gemm16_group(int32_t gm);
 /* operand preparation for the backward split GEMMs (csrc/split_prep.hip): x [R][ld] fp32 (C columns) -> row-major planes
  * hi / lo [R][C] and / or transposed planes hiT / loT [C][Rp] (Rp >= R, multiple of 8; rows R.. are zeros).
  * slot != NULL (gradients, far below fp16's normal range): the tensor is scaled by the power of two that brings its
- * max-abs into [2^14, 2^15); slot = 4 floats of device memory {scale, 1 / scale, amax word, -} whose amax word must be
+ * max-abs into [2^(target_exp-1), 2^target_exp) (15 for GEMM operands); slot = 4 floats of device memory {scale, 1 / scale, amax word, -} whose amax word must be
  * ZERO on entry; pass slot + 1 as the GEMM's alpha_dev.  next_bits (optional): the amax word of the slot the next scaled
  * call on this stream will use -- it is zeroed by this call (a ring of slots then needs no memset).
  * No reference counterpart (the reference's autograd calls ATen GEMMs on fp32 operands). */
 int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
-                       void* hiT, void* loT, int32_t Rp, dupl_stream_t stream);
+                       void* hiT, void* loT, int32_t Rp, int32_t target_exp, dupl_stream_t stream);
 /* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 3: 128x64 on 4 waves, 5: 128x128 on 8 waves) */
 int dupl_set_gemm16_tile(int32_t t);
 /* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
@@ -345,6 +345,15 @@ int dupl_confusion_accum(const int64_t* gt, const int64_t* pred, int64_t n, int3
 /* utils/evaluate.py:4-6 (sklearn f1_score of one multi-hot row): sum[0] += 2TP/(2TP+FP+FN) of (logits > 0) vs label,
  * per row of (B,C). */
 int dupl_multilabel_f1_accum(const float* logits, const float* label, int32_t B, int32_t C, float* sum, dupl_stream_t s);
+
+/* Attention backward as fp32-equivalent f16x3 split products (csrc/attn_split_bwd.hip; head dim 64, N <= 2048): autograd of
+ * vit.py:123-135.  qkv_hi / qkv_lo: planes of the qkv GEMM output saved by the forward; out / dout: fp32 attention output
+ * and its gradient ([B*N][H*hd]); do_hi / do_lo + do_slot: dout as planes scaled with target_exp 4 (dupl_split_prepare;
+ * do_slot = its {scale, 1/scale,..} record); lse from the forward; delta: B*H*N floats of scratch; scratch_T: 6 planes of
+ * B*H*hd*Npad halfs (K^T, Q^T, dO^T); dqkv [B*N][3*H*hd] fp32 receives dq | dk | dv. */
+int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
+                         const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T, float* dqkv,
+                         int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, dupl_stream_t stream);
 
 /* ------------------------------------------------------------------ per-step strong augmentation
  * utils/imutils.py:305-317 augment_data_strong / utils/randomaug.py RandAugment on the device: planar uint8 images

@@ -704,3 +704,34 @@ def test_split_kernels_are_deterministic_under_stream_concurrency(dev):
             bad += int(not (torch.equal(oa, refa) and torch.equal(ob, refb)))
         print(f"{name}: {bad}/12 rounds deviate from the solo result")
         assert bad == 0, name
+
+
+@pytest.mark.parametrize("B,N", [(2, 197), (1, 785), (2, 64), (1, 130), (3, 50)])
+def test_attention_bwd16_is_fp32_equivalent(dev, B, N):
+    """dupl_attention_bwd16 (q / k / v planes saved by the forward, dO as power-of-two-scaled planes, P / dS split in
+    registers; dq, dk, dv kernels) vs fp64 autograd with realistic gradient magnitudes (1e-5): at least as close as the
+    exact-f32 MFMA backward kernels (bar 2x their error + 5e-7 relative), ragged N."""
+    from dupl_amd import ops
+    H, hd = 12, 64
+    D = H * hd
+    g = torch.Generator().manual_seed(B * 100 + N)
+    qkv = (torch.randn(B * N, 3 * D, generator=g) * 1.2).to(dev)
+    dout = (torch.randn(B * N, D, generator=g) * 2e-5).to(dev)
+    scale = hd ** -0.5
+    x = qkv.double().clone().requires_grad_(True)
+    q, k, v = (x.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+    ref_out = ((q @ k.transpose(-1, -2) * scale).softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+    ref_out.backward(dout.double())
+    ref = x.grad
+    out32, lse = ops.attention_fwd(qkv, B, N, H, hd, scale, need_lse=True)
+    d32 = ops.attention_bwd(qkv, out32, dout, lse, B, N, H, hd, scale)
+    qkv16 = ops.split16(qkv)
+    out16 = torch.empty(B * N, D, device=dev)
+    lse16 = ops.attention_fwd16(qkv16, B, N, H, hd, scale, need_lse=True, out=out16)
+    d16 = ops.attention_bwd16(qkv16, out16, dout, lse16, B, N, H, hd, scale)
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        sc = float(ref[:, sl].abs().max())
+        e16 = float((d16[:, sl].double() - ref[:, sl]).abs().max()) / sc
+        e32 = float((d32[:, sl].double() - ref[:, sl]).abs().max()) / sc
+        print(f"B{B} N{N} {name}: f16x3 {e16:.2e} f32 {e32:.2e}")
+        assert e16 <= 2.0 * e32 + 5e-7, name
