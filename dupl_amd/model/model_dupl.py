@@ -328,9 +328,15 @@ class siamese_network(nn.Module):
             x_aug = ops.resize_bilinear(inputs_aug.contiguous().float(), int(H * 0.75), int(W * 0.75))
 
         def one(net):
-            share = {}
-            cams = cam_helper._ms_cam(net._P, inputs, scales, share=share)
-            outs = net.forward_shared(share["x"], share["enc"]) if torch.is_grad_enabled() else net(inputs)
+            if torch.is_grad_enabled():
+                share = {}
+                cams = cam_helper._ms_cam(net._P, inputs, scales, share=share)
+                outs = net.forward_shared(share["x"], share["enc"])
+            else:
+                # no-grad callers (in-loop validation): nothing to share -- a saving pass would keep every block's
+                # activations alive only to drop them, and net(inputs) runs its own (cheap, non-saving) forward anyway
+                cams = cam_helper._ms_cam(net._P, inputs, scales)
+                outs = net(inputs)
             seg_aug = net(x_aug)[1] if x_aug is not None else None
             return cams, outs, seg_aug
 
