@@ -33,3 +33,12 @@ def install_reference_aliases(override: bool = False):
 
     for pkg in ("model", "utils", "datasets", "tools"):
         alias(f"dupl_amd.{pkg}", pkg)
+
+
+def set_deterministic(on: bool = True):
+    """Bit-reproducible steps (the reference's `torch.backends.cudnn.deterministic = True`, train_final_voc.py:95-102):
+    every accumulation that otherwise uses fp32 atomics -- split-K weight gradients, LayerNorm dgamma / dbeta, bias column
+    sums, the seg-loss backward scatter -- runs in a fixed order.  Costs throughput (the weight-gradient GEMMs lose their
+    k-split); off by default.  Also switched on by the environment variable DUPL_DETERMINISTIC=1."""
+    from ._lib import lib
+    lib().dupl_set_deterministic(1 if on else 0)

@@ -123,4 +123,6 @@ def lib() -> _Lib:
     global _LIB
     if _LIB is None:
         _LIB = _Lib()
+        if os.environ.get("DUPL_DETERMINISTIC", "0") == "1":
+            _LIB.dupl_set_deterministic(1)
     return _LIB

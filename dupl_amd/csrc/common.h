@@ -10,6 +10,10 @@
 
 #define DUPL_WAVE 64
 
+// dupl_set_deterministic (gemm.hip): 1 = every accumulation that otherwise uses fp32 atomics (split-K weight gradients,
+// LayerNorm dgamma / dbeta, bias column sums, seg-loss backward) runs in a fixed order -> bit-reproducible steps
+extern int g_dupl_deterministic;
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -250,6 +250,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
 
 }  // namespace
 
+int g_dupl_deterministic = 0;
+
+extern "C" int dupl_set_deterministic(int32_t on) {
+    g_dupl_deterministic = on ? 1 : 0;
+    return DUPL_OK;
+}
+
 static int g_group_m = 16;        // row-tiles per group of the block order (dupl_set_gemm_group)
 static int g_ncols_override = 0;  // 0 = heuristic, 64 / 128 = forced column tile of the 64-row kernels (dupl_set_gemm_ncols)
 static int g_tile_override = 0;   // 0 = heuristic, 64 / 128 = forced (tuning knob, dupl_set_gemm_tile)
@@ -304,6 +311,7 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
             if (ksplit < 1) ksplit = 1;
         }
     }
+    if (g_dupl_deterministic) ksplit = 1;          // no fp32 atomics: one block owns the whole reduction of its tile
     dim3 grid(nbm * nbn, d->batch, ksplit), block(NT);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool amc = d->flags & DUPL_GEMM_A_MCONTIG, bnc = d->flags & DUPL_GEMM_B_NCONTIG;

@@ -251,6 +251,7 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         const int maxs = (d->K / TBK + 7) / 8;
         if (ksplit > maxs) ksplit = maxs;
         if (ksplit < 1) ksplit = 1;
+        if (g_dupl_deterministic) ksplit = 1;      // no fp32 atomics
     }
     int tile = g16_tile;
     if (tile == 0) {

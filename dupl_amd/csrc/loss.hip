@@ -222,6 +222,68 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     }
 }
 
+// Deterministic backward of the fused upsample + CE: one block per low-res cell GATHERS the contributions of every
+// full-res pixel whose bilinear footprint touches the cell (a (3 fy) x (3 fx) window), in a fixed order, instead of the
+// pixel-side scatter with fp32 atomics above.  Same arithmetic per pixel; dlogits[b][cell][c] += sum.
+__global__ __launch_bounds__(256) void seg_loss_bwd_gather_kernel(const float* __restrict__ logits, const void* __restrict__ label,
+                                                                  int is_i64, int ignore, const float* __restrict__ sums,
+                                                                  const float* __restrict__ gscale, float* __restrict__ dlogits,
+                                                                  int C1, int h, int w, int H, int W, int flip, int balanced) {
+    extern __shared__ float acc_s[];               // [blockDim.x][C1 + 1] per-thread partial sums (odd stride)
+    __shared__ float red[16];
+    const int b = blockIdx.y, cell = blockIdx.x;
+    const int cy = cell / w, cx = cell - cy * w;   // cell in the (un-flipped) logits array
+    const int tx = flip ? w - 1 - cx : cx;         // the tap column index that maps onto this cell
+    // pixels with a tap on row cy: source coordinate ry in (cy - 1, cy + 1), ry = (h / H) (Y + 0.5) - 0.5 (clamped at 0)
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+    const int Y0 = max(0, (int)floorf((cy - 0.5f) * sy - 0.5f) - 1), Y1 = min(H, (int)ceilf((cy + 1.5f) * sy - 0.5f) + 2);
+    const int X0 = max(0, (int)floorf((tx - 0.5f) * sx - 0.5f) - 1), X1 = min(W, (int)ceilf((tx + 1.5f) * sx - 0.5f) + 2);
+    const int nw = X1 - X0, np = (Y1 - Y0) * nw;
+    float* acc = acc_s + threadIdx.x * (C1 + 1);
+    for (int c = 0; c < C1; ++c) acc[c] = 0.f;
+    const float g = gscale[0];
+    const float* L = logits + (long)b * h * w * C1;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+        const int Y = Y0 + i / nw, X = X0 + i % nw;
+        const long li = ((long)b * H + Y) * W + X;
+        const long lab = is_i64 ? (long)reinterpret_cast<const long long*>(label)[li] : (long)reinterpret_cast<const float*>(label)[li];
+        if (lab == ignore) continue;
+        const float ry = fmaxf(((float)h / (float)H) * (Y + 0.5f) - 0.5f, 0.f);
+        const float rx = fmaxf(((float)w / (float)W) * (X + 0.5f) - 0.5f, 0.f);
+        int y0 = (int)ry, x0 = (int)rx;
+        int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly = ry - y0, lx = rx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float wy = (y0 == cy ? hy : 0.f) + (y1 == cy ? ly : 0.f);
+        const float wx = (x0 == tx ? hx : 0.f) + (x1 == tx ? lx : 0.f);
+        const float wgt = wy * wx;
+        if (wgt == 0.f) continue;
+        if (flip) { x0 = w - 1 - x0; x1 = w - 1 - x1; }
+        const float* p00 = L + (long)(y0 * w + x0) * C1;
+        const float* p01 = L + (long)(y0 * w + x1) * C1;
+        const float* p10 = L + (long)(y1 * w + x0) * C1;
+        const float* p11 = L + (long)(y1 * w + x1) * C1;
+        float mx = -INFINITY, se = 0.f;
+        for (int c = 0; c < C1; ++c) {
+            const float z = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+            if (z > mx) { se = se * expf(mx - z) + 1.f; mx = z; } else se += expf(z - mx);
+        }
+        const float lse = mx + logf(se);
+        float coef;
+        if (balanced) coef = lab == 0 ? 0.5f * g / (sums[1] + 1e-6f) : 0.5f * g / (sums[3] + 1e-6f);
+        else coef = g / (sums[1] + sums[3]);
+        coef *= wgt;
+        for (int c = 0; c < C1; ++c) {
+            const float z = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+            acc[c] += coef * (expf(z - lse) - (c == lab ? 1.f : 0.f));
+        }
+    }
+    float* D = dlogits + ((long)b * h * w + cell) * C1;
+    for (int c = 0; c < C1; ++c) {
+        const float v = block_sum(acc[c], red);
+        if (threadIdx.x == 0) D[c] += v;
+    }
+}
+
 // Consistency-regularisation targets (train_final_voc.py:416-426): per full-res pixel of the bilinearly up-sampled
 // logits: pseudo = argmax_c, conf = max_c softmax; keep pseudo where the OTHER student's refined label is `ignore`
 // and conf > thr, else `ignore`.  count[0] += number of kept pixels.
@@ -421,6 +483,15 @@ extern "C" int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t
                                  int32_t W, int32_t flip, int32_t balanced, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!logits || !label || !sums || !gscale || !dlogits || b <= 0 || C1 <= 0 || H < h || W < w) return DUPL_ERR_ARG;
+    if (g_dupl_deterministic) {
+        int nthr = 256;                                        // <= 64 KB of dynamic LDS: [threads][C1 + 1] floats
+        while (nthr > 64 && (size_t)nthr * (C1 + 1) * sizeof(float) > 64 * 1024) nthr >>= 1;
+        if ((size_t)nthr * (C1 + 1) * sizeof(float) > 64 * 1024) return DUPL_ERR_ARG;
+        hipLaunchKernelGGL(seg_loss_bwd_gather_kernel, dim3(h * w, b), dim3(nthr), (size_t)nthr * (C1 + 1) * sizeof(float),
+                           (hipStream_t)s, logits, label, is_i64, ignore_index, sums, gscale, dlogits, C1, h, w, H, W, flip,
+                           balanced);
+        return dupl_launch_status();
+    }
     dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
     hipLaunchKernelGGL(seg_loss_kernel<1>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index,
                        const_cast<float*>(sums), gscale, dlogits, C1, h, w, H, W, flip, balanced);

@@ -167,6 +167,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     if (rg == 0 && col < N) atomicAdd(&out[col], (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
+// Deterministic dgamma / dbeta: one block per 64 columns walks all rows in a fixed order (no atomics).
+__global__ __launch_bounds__(256) void ln_dgb_det_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int D) {
+    __shared__ float rg_[4][64], rb_[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    float sg = 0.f, sb = 0.f;
+    if (col < D) {
+        for (long m = rg; m < rows; m += 4) {
+            const float d = dy[m * D + col];
+            sg += d * ((x[m * D + col] - mean[m]) * rstd[m]);
+            sb += d;
+        }
+    }
+    rg_[rg][cl] = sg;
+    rb_[rg][cl] = sb;
+    __syncthreads();
+    if (rg == 0 && col < D) {
+        if (dgamma) dgamma[col] += (rg_[0][cl] + rg_[1][cl]) + (rg_[2][cl] + rg_[3][cl]);
+        if (dbeta) dbeta[col] += (rb_[0][cl] + rb_[1][cl]) + (rb_[2][cl] + rb_[3][cl]);
+    }
+}
+
 __global__ void fill_kernel(float* p, float v, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long st = (long)gridDim.x * blockDim.x;
@@ -220,13 +244,19 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
     if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256)
         return DUPL_ERR_ARG;
     const int grid = (int)((rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS));
+    const bool det = g_dupl_deterministic && (dgamma || dbeta);
+    float* dg_k = det ? nullptr : dgamma;
+    float* db_k = det ? nullptr : dbeta;
 #define LN_BWD(MC) hipLaunchKernelGGL(layernorm_bwd_kernel<MC>, dim3(grid), dim3(256), 2 * D * sizeof(float), (hipStream_t)s, \
-                                      dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, D)
+                                      dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D)
     if (D <= 256) LN_BWD(1);
     else if (D <= 768) LN_BWD(3);
     else if (D <= 1024) LN_BWD(4);
     else LN_BWD(8);
 #undef LN_BWD
+    if (det)
+        hipLaunchKernelGGL(ln_dgb_det_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)s, dy, x, mean, rstd, dgamma, dbeta,
+                           (long)rows, D);
     return dupl_launch_status();
 }
 
@@ -238,6 +268,7 @@ extern "C" int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int
     long gy = (M + 63) / 64;       // 16 rows per thread-row-group pass: enough blocks to fill the chip on B*N ~ 3000 rows
     if (gy > 256) gy = 256;
     if (gy < 1) gy = 1;
+    if (g_dupl_deterministic) gy = 1;      // one block per 64 columns: a single, fixed-order addition per output
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (int)gy), dim3(256), 0, (hipStream_t)s, x, out, (long)M, N, ldx);
     return dupl_launch_status();
 }

@@ -72,6 +72,9 @@ def build_parser(dataset: str) -> argparse.ArgumentParser:
     p.add_argument("--start_iter", default=0, type=int,
                    help="first n_iter (lets a short run exercise phase B); the LR schedule starts there too")
     p.add_argument("--single_stream", action="store_true")
+    p.add_argument("--deterministic", action="store_true",
+                   help="bit-reproducible steps (dupl_amd.set_deterministic): what cudnn.deterministic = True asks for in "
+                        "the reference's setup_seed (train_final_voc.py:95-102); costs ~20 % throughput")
     return p
 
 
@@ -163,6 +166,9 @@ def train(args, dataset: str, loader=None, val_loader=None):
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    if getattr(args, "deterministic", False):
+        import dupl_amd
+        dupl_amd.set_deterministic(True)
     distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

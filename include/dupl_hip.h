@@ -24,6 +24,10 @@ typedef void* dupl_stream_t;
 
 /* library info: returns the ABI version (1).  Infrastructure, no reference counterpart. */
 int dupl_abi_version(void);
+/* on != 0: every accumulation that otherwise uses fp32 atomics (split-K weight gradients, LayerNorm dgamma / dbeta, bias
+ * column sums, seg-loss backward scatter) runs in a fixed order, so that two identical steps give bit-identical gradients
+ * (torch.use_deterministic_algorithms / cudnn.deterministic of train_final_voc.py:95-102).  Slower; default 0. */
+int dupl_set_deterministic(int32_t on);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 in / fp32 accumulate / fp32 out.

@@ -668,3 +668,53 @@ def test_run_to_run_gradient_spread_is_roundoff(dev):
                 worst = max(worst, float((a - b).abs().max()) / m)
     print(f"run-to-run gradient spread: {worst:.2e} of the tensor max (fp32 atomics)")
     assert worst <= 2e-6
+
+
+@pytest.mark.parametrize("gemm_mode", ["f16x3", "f32"], indirect=True)
+def test_deterministic_mode_is_bit_reproducible(dev, gemm_mode):
+    """dupl_amd.set_deterministic(True): two identical phase-B steps from the same state give BIT-IDENTICAL gradients for
+    every parameter of both students (torch.equal on the flat gradient buffer) and identical losses, in both GEMM modes and
+    with two student streams; the deterministic gradients agree with the default (atomic) path to round-off."""
+    import dupl_amd
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd import trainer
+    from oracle import dupl_oracle as O
+    model = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    model.load_state_dict(O.make_siamese_params(O.VIT_TINY, 21, seed=2), strict=True)
+    model.to(dev)
+    model.enable_dual_stream(True)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    inputs, cls_label, img_box = O.synthetic_batch(3, 20, 128, seed=31)
+
+    def step():
+        model.flat_storage.grad.zero_()
+        loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, 5000, trainer.StepArgs(),
+                                           cls_label_host=cls_label)
+        loss.sum().backward()
+        model.flat_storage.wait_streams()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), model.flat_storage.grad.clone()
+
+    l0, g0 = step()                      # default path (atomics)
+    dupl_amd.set_deterministic(True)
+    try:
+        l1, g1 = step()
+        l2, g2 = step()
+        l3, g3 = step()
+    finally:
+        dupl_amd.set_deterministic(False)
+    assert torch.equal(g1, g2) and torch.equal(g2, g3), "deterministic mode: gradients differ between identical steps"
+    assert float((l1 - l2).abs().max()) <= 1e-6 * float(l1.abs().max())
+    scale = float(g0.abs().max())
+    st = model.flat_storage
+    worst = 0.0
+    for s in (0, 1):
+        for key, (off, n) in st.layout.items():
+            a = g0[s * st.student_numel + off: s * st.student_numel + off + n]
+            b = g1[s * st.student_numel + off: s * st.student_numel + off + n]
+            m = float(a.abs().max())
+            if m > 1e-6 * scale:
+                worst = max(worst, float((a - b).abs().max()) / m)
+    print(f"deterministic vs default gradients: worst relative difference {worst:.2e}")
+    assert worst <= 2e-5

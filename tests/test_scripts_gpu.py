@@ -122,7 +122,8 @@ def test_bench_contract_line(dev):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert 0.15 < rf["frac"] < 1.0 and d["value"] > 10.0
+    det = bool(d["config"].get("deterministic"))        # no k-split: the weight-gradient launches run on few blocks
+    assert (0.02 if det else 0.15) < rf["frac"] < 1.0 and d["value"] > 10.0, (d["value"], rf, r.stderr[-1500:])
     # roofline.traffic is only quoted from a PMC summary tagged with THIS build's kernel-source digest
     from dupl_amd.build import source_digest
     assert rf["csrc_sha256"] == source_digest()[:16] and "traffic_source" in rf
