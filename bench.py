@@ -43,8 +43,10 @@ KERNEL_F16X3 = ("gemm_f16x3_kernel (csrc/gemm_split.hip): every Linear forward a
                 "fp16 hi / lo planes, 3 v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulate; peak = dense f16 MFMA peak / 3")
 KERNEL_F32 = "gemm_f32_kernel<false,false,...> (v_mfma_f32_32x32x2_f32; every Linear forward, all tile instantiations)"
 
-DTYPE = {"f16x3": "f32 storage / accumulation / results; forward Linear GEMMs as fp32-equivalent f16x3 split products on the f16 MFMA "
-                  "(error vs fp64 <= the f32 MFMA kernel's); attention, backward GEMMs and everything else in f32",
+DTYPE = {"f16x3": "f32 storage / accumulation / results; Linear GEMMs (forward, dgrad, wgrad), attention (forward, backward) and "
+                  "the decoder convs as fp32-equivalent f16x3 split products on the f16 MFMA (operands as fp16 hi / lo planes, "
+                  "3 products per block, fp32 accumulate; error vs fp64 <= the f32 MFMA kernels'); patch embedding, CAM heads, "
+                  "Gram, norms, losses, PAR, optimiser in f32",
          "f32": "f32"}
 CONFIG_BY_N = {1: ("voc", 4, "deit_base_patch16_224", "configs[1]"),
                2: ("voc", 2, "deit_base_patch16_224", "configs[2]"),
@@ -72,6 +74,8 @@ def parse():
                          "{physical cores, 64, 32})")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps after one warm-up step")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true",
+                    help="skip the second measurement of the same workload on the exact-f32 MFMA kernels (f16x3 runs only)")
     ap.add_argument("--pmc-profile", default=os.environ.get("DUPL_PMC_PROFILE", "profiles/r02_final_pmc_hbm.txt"),
                     help="PMC summary (tools/profile_round.sh) roofline.traffic is read from; ignored (traffic = null) "
                          "unless its '# csrc_sha256:' header matches the kernel sources of THIS build")
@@ -411,6 +415,17 @@ def main():
                         "timed region (same stream, same workload; per launch the minimum of the three, which drops "
                         "host-side gaps); algorithmic flops = 2*M*N*K per launch (fp32-equivalent)"}
 
+    # the same workload on the exact-f32 MFMA kernels (DUPL_GEMM=f32): the number to read if the f16x3 split products are
+    # not accepted as the reference's fp32 arithmetic
+    exact = None
+    if gemm_mode == "f16x3" and not args.no_exact_f32:
+        engine.set_gemm_mode("f32")
+        rx = wl.measure("exact-f32")
+        engine.set_gemm_mode("f16x3")
+        exact = {"value": round(rx["value"], 3), "unit": "img/s", "ms_per_step": round(rx["ms"], 2), "dtype": "f32",
+                 "loss": round(rx["loss"], 5),
+                 "note": "same workload, steps and warm-up with every GEMM / attention on v_mfma_f32_32x32x2_f32 (DUPL_GEMM=f32)"}
+
     weak4 = None
     if world > 1 and not args.no_weak4 and (dataset, batch) != ("voc", 4):
         del wl
@@ -441,7 +456,7 @@ def main():
                           "shared_scale1_encoder_pass": not args.no_share_encoder, "forward_gemm": gemm_mode,
                           "deterministic": os.environ.get("DUPL_DETERMINISTIC", "0") == "1",
                           "loss": round(res["loss"], 5)},
-               "comm": res["comm"], "weak_4img_per_gpu": weak4,
+               "comm": res["comm"], "weak_4img_per_gpu": weak4, "exact_f32_path": exact,
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec))
     if world > 1:

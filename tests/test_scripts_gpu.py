@@ -118,6 +118,9 @@ def test_bench_contract_line(dev):
     assert d["config"]["forward_gemm"] in ("f16x3", "f32") and ("f16x3" in d["dtype"]) == (d["config"]["forward_gemm"] == "f16x3")
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["config"]["global_batch"] * 1000.0 / d["ms_per_step"]) < 0.05 * d["value"]
+    if d["config"]["forward_gemm"] == "f16x3":      # second number: the same workload on the exact-f32 MFMA kernels
+        ex = d["exact_f32_path"]
+        assert ex["dtype"] == "f32" and 10.0 < ex["value"] < d["value"] and abs(ex["loss"] - d["config"]["loss"]) < 1e-3
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
