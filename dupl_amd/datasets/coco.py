@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-from .transforms import draw_geometry
+from .transforms import draw_geometry, draw_train_views
 from .voc import load_img_name_list, load_cls_label_list, _read_rgb, _read_label
 
 
@@ -56,6 +56,7 @@ class CocoClsDataset(CocoDataset):
         self.aug, self.ignore_index = aug, ignore_index
         self.rescale_range, self.crop_size, self.img_fliplr = rescale_range, crop_size, img_fliplr
         self.num_classes = num_classes
+        self.photometric = kwargs.get("photometric", True)    # global_view1's jitter / grayscale / blur (coco.py:117-132)
         self.label_list = load_cls_label_list(name_list_dir=name_list_dir)
 
     def __getitem__(self, idx):
@@ -65,8 +66,9 @@ class CocoClsDataset(CocoDataset):
         raw = torch.from_numpy(np.ascontiguousarray(image))
         if not self.aug:
             return name, raw, cls_label
-        return name, raw, cls_label, draw_geometry(image.shape[0], image.shape[1], self.rescale_range, self.crop_size,
-                                                   self.img_fliplr)
+        geo = draw_geometry(image.shape[0], image.shape[1], self.rescale_range, self.crop_size, self.img_fliplr)
+        geo.photometric = draw_train_views(image.shape[0], image.shape[1]) if self.photometric else None
+        return name, raw, cls_label, geo
 
 
 class CocoSegDataset(CocoDataset):

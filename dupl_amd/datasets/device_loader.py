@@ -6,9 +6,10 @@ reference's Pillow / numpy / ToTensor / Normalize chain for the geometric part.
 Why here and not in DataLoader workers: at > 100 img/s/GPU the reference's PIL workers (10-16 per rank) are the
 bottleneck; the workers of this build only decode JPEGs and draw random numbers.
 
-Not built (stated in DESIGN.md): the photometric jitter of `global_view1` (torchvision ColorJitter / RandomGrayscale
-+ PIL GaussianBlur, datasets/voc.py:101-114) -- torchvision is absent from this image, so it could not be pinned.
-`photometric`, if given, is called with the cropped uint8 (crop, crop, 3) device tensor and must return one."""
+The photometric view of the train items (`global_view1`: torchvision ColorJitter / RandomGrayscale + the reference's
+GaussianBlur, datasets/voc.py:101-114) runs between crop and normalisation in Pillow's arithmetic (csrc/photometric.hip)
+with the draws the item carries (`Geometry.photometric`, transforms.draw_train_views).  `photometric`, if given, is an
+extra user hook called with the uint8 (crop, crop, 3) device tensor after that and must return one."""
 from __future__ import annotations
 
 from typing import Callable, Iterable, List, Optional
@@ -18,7 +19,7 @@ import torch
 
 from .. import ops
 from .._lib import lib as _L
-from .transforms import Geometry, resample_coeffs
+from .transforms import Geometry, Photometric, resample_coeffs
 
 
 def _dev_i32(a: np.ndarray, device) -> torch.Tensor:
@@ -31,6 +32,7 @@ class DeviceTransform:
     def __init__(self, device):
         self.device = torch.device(device)
         self._coef_cache = {}
+        self._sum = None
 
     def _coeffs(self, n_in: int, n_out: int):
         key = (n_in, n_out)
@@ -57,6 +59,8 @@ class DeviceTransform:
         crop = torch.empty((g.crop, g.crop, 3), device=dev, dtype=torch.uint8)
         L.dupl_loader_resample_v_crop(tmp.data_ptr(), crop.data_ptr(), cy.data_ptr(), by.data_ptr(), ky, g.w2, g.h2,
                                       int(g.flip), g.h_pad, g.w_pad, g.h_start, g.w_start, g.crop, st)
+        if g.photometric is not None:
+            self.photometric_view(crop, g.photometric)
         if photometric is not None:
             crop = photometric(crop).contiguous()
             assert crop.dtype == torch.uint8 and tuple(crop.shape) == (g.crop, g.crop, 3)
@@ -64,6 +68,31 @@ class DeviceTransform:
             out = torch.empty((3, g.crop, g.crop), device=dev, dtype=torch.float32)
         L.dupl_loader_normalize(crop.data_ptr(), out.data_ptr(), g.crop, g.crop, 0, st)
         return out, crop
+
+    def photometric_view(self, crop: torch.Tensor, p: Photometric) -> torch.Tensor:
+        """global_view1 (datasets/voc.py:111-115) in place on a uint8 (S,S,3) device tensor: ColorJitter's four PIL ops in
+        the drawn order, RandomGrayscale, GaussianBlur."""
+        assert crop.dtype == torch.uint8 and crop.dim() == 3 and crop.shape[2] == 3 and crop.is_contiguous()
+        H, W = int(crop.shape[0]), int(crop.shape[1])
+        L, st, ptr = _L(), ops._stream(), crop.data_ptr()
+        if p.jitter:
+            for fn in p.order:
+                if fn == 0:
+                    L.dupl_photo_enhance(ptr, H, W, 2, float(p.brightness), None, st)
+                elif fn == 1:
+                    if self._sum is None:
+                        self._sum = torch.zeros(1, device=self.device, dtype=torch.int64)
+                    L.dupl_photo_enhance(ptr, H, W, 1, float(p.contrast), self._sum.data_ptr(), st)
+                elif fn == 2:
+                    L.dupl_photo_enhance(ptr, H, W, 0, float(p.saturation), None, st)
+                else:
+                    L.dupl_photo_hue(ptr, H * W, p.hue_shift, st)
+        if p.gray:
+            L.dupl_photo_grayscale(ptr, H * W, st)
+        if p.blur_radius is not None:
+            tmp = torch.empty_like(crop)
+            L.dupl_photo_gaussian_blur(ptr, tmp.data_ptr(), H, W, float(p.blur_radius), st)
+        return crop
 
     def val_item(self, raw: torch.Tensor) -> torch.Tensor:
         """transforms.normalize_img + HWC->CHW of the val items (datasets/voc.py:248-250): (h,w,3) uint8 -> (3,h,w)."""

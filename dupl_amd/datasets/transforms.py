@@ -7,17 +7,25 @@ Reference composition (datasets/voc.py:134-148 `__transforms`, identical in data
     image = transforms.random_fliplr(image)                          # random.random() > 0.5 -> np.fliplr
     image, img_box = transforms.random_crop(image, crop_size, mean_rgb=[0,0,0])
                                                                      # np.random.randint x2 (pad), random.randrange x2
-    ... photometric jitter (torchvision ColorJitter / RandomGrayscale + PIL GaussianBlur): NOT built, see DESIGN 0 (f-3)
+    local_image = local_view(image); image = global_view1(image)     # photometric views: torch.rand / randperm /
+                                                                     # uniform_ + random.random / uniform (below)
     image = T.Normalize(T.ToTensor(image))
+and, back in __getitem__ (voc.py:171-177), global_view2(pil_image) -- never read by the loop, but it consumes random numbers.
+
+Photometric views (voc.py:101-126): torchvision is a third-party dependency of the reference (0.14.1 in requirements.txt)
+that is absent from this image; the DRAW ORDER of its RandomApply / ColorJitter / RandomGrayscale / RandomResizedCrop is
+restated here from that version's published source (torchvision/transforms/transforms.py), the pixel arithmetic (Pillow's)
+is csrc/photometric.hip and is pinned against Pillow itself.
 """
 from __future__ import annotations
 
 import math
 import random
 from dataclasses import dataclass
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
+import torch
 
 PRECISION_BITS = 32 - 8 - 2      # Pillow src/libImaging/Resample.c
 
@@ -36,6 +44,7 @@ class Geometry:
     w_start: int
     crop: int
     img_box: np.ndarray          # int16 [y0, y1, x0, x1] inside the crop (transforms.py:191-195)
+    photometric: Optional["Photometric"] = None     # global_view1's draws (draw_train_views); None = geometry only
 
 
 def draw_geometry(h: int, w: int, rescale_range=(0.5, 2.0), crop_size: int = 448, img_fliplr: bool = True) -> Geometry:
@@ -56,6 +65,90 @@ def draw_geometry(h: int, w: int, rescale_range=(0.5, 2.0), crop_size: int = 448
     box = np.asarray([max(h_pad - h_start, 0), min(crop_size, h2 + h_pad - h_start),
                       max(w_pad - w_start, 0), min(crop_size, w2 + w_pad - w_start)], dtype=np.int16)
     return Geometry(h, w, h2, w2, flip, h_pad, w_pad, h_start, w_start, crop_size, box)
+
+
+@dataclass
+class Photometric:
+    """The draws of one `flip_and_color_jitter` + `GaussianBlur` view (datasets/voc.py:102-114)."""
+    jitter: bool                       # RandomApply([ColorJitter], p=0.8) fired
+    order: Tuple[int, ...]             # ColorJitter fn_idx: 0 brightness, 1 contrast, 2 saturation, 3 hue
+    brightness: float
+    contrast: float
+    saturation: float
+    hue: float
+    gray: bool                         # RandomGrayscale(p=0.2) fired
+    blur_radius: Optional[float]       # transforms.GaussianBlur: radius, or None when it did not fire
+
+    @property
+    def hue_shift(self) -> int:
+        """F_pil.adjust_hue: `np_h += np.uint8(hue_factor * 255)` -- the C cast truncates toward zero, uint8 wraps."""
+        return int(self.hue * 255) & 0xFF
+
+
+JITTER = dict(brightness=(1 - 0.4, 1 + 0.4), contrast=(1 - 0.4, 1 + 0.4), saturation=(1 - 0.2, 1 + 0.2), hue=(-0.1, 0.1))
+
+
+def _tv_uniform(lo: float, hi: float) -> float:
+    return float(torch.empty(1).uniform_(lo, hi))
+
+
+def draw_view(blur_p: float, jitter_p: float = 0.8, gray_p: float = 0.2, radius=(0.1, 2.0)) -> Photometric:
+    """One pass through Compose([RandomApply([ColorJitter(0.4, 0.4, 0.2, 0.1)], p), RandomGrayscale(p), GaussianBlur(p)]):
+    torch's global generator for the torchvision part (RandomApply.forward: `if self.p < torch.rand(1): return img`;
+    ColorJitter.get_params: randperm(4), then uniform_ for brightness, contrast, saturation, hue; RandomGrayscale.forward:
+    `torch.rand(1) < self.p`), Python's `random` for the reference's own GaussianBlur (transforms.py:20-28)."""
+    jitter = not (jitter_p < float(torch.rand(1)))
+    order, b, c, s_, h = (), 1.0, 1.0, 1.0, 0.0
+    if jitter:
+        order = tuple(int(i) for i in torch.randperm(4))
+        b = _tv_uniform(*JITTER["brightness"])
+        c = _tv_uniform(*JITTER["contrast"])
+        s_ = _tv_uniform(*JITTER["saturation"])
+        h = _tv_uniform(*JITTER["hue"])
+    gray = bool(float(torch.rand(1)) < gray_p)
+    blur = None
+    if random.random() <= blur_p:
+        blur = random.uniform(radius[0], radius[1])
+    return Photometric(jitter, order, b, c, s_, h, gray, blur)
+
+
+def draw_random_resized_crop(height: int, width: int, scale=(0.4, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    """torchvision 0.14.1 RandomResizedCrop.get_params: up to 10 x (uniform_ area, uniform_ log-ratio), randint x2 on
+    success, no draw for the central-crop fallback.  Returns (i, j, h, w)."""
+    area = height * width
+    log_ratio = torch.log(torch.tensor(ratio))
+    for _ in range(10):
+        target_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+        aspect_ratio = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+        w = int(round(math.sqrt(target_area * aspect_ratio)))
+        h = int(round(math.sqrt(target_area / aspect_ratio)))
+        if 0 < w <= width and 0 < h <= height:
+            i = torch.randint(0, height - h + 1, size=(1,)).item()
+            j = torch.randint(0, width - w + 1, size=(1,)).item()
+            return i, j, h, w
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+def draw_train_views(height: int, width: int) -> Photometric:
+    """Every photometric draw of one train item in the reference's order -- local_view (blur p = 0.5), global_view1
+    (p = 1.0) inside `__transforms` (voc.py:145-146), then global_view2 on the undistorted image in `__getitem__`
+    (voc.py:175: RandomResizedCrop, the jitter view with blur p = 0.1, Solarization's random.random()).  Only global_view1
+    reaches the training loop (`image`); the other two are drawn so the generators stay in step with the reference's."""
+    draw_view(0.5)                                   # local_view -> crops[2], never read (train_final_voc.py:180)
+    g1 = draw_view(1.0)
+    draw_random_resized_crop(height, width)          # global_view2 -> crops[1], never read
+    draw_view(0.1)
+    random.random()                                  # Solarization(p=0.2)
+    return g1
 
 
 def resample_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:

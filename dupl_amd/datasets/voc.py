@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-from .transforms import draw_geometry
+from .transforms import draw_geometry, draw_train_views
 
 
 def load_img_name_list(img_name_list_path):
@@ -72,6 +72,7 @@ class VOC12ClsDataset(VOC12Dataset):
         self.aug, self.ignore_index = aug, ignore_index
         self.rescale_range, self.crop_size, self.img_fliplr = rescale_range, crop_size, img_fliplr
         self.num_classes = num_classes
+        self.photometric = kwargs.get("photometric", True)    # global_view1's jitter / grayscale / blur (voc.py:101-114)
         self.label_list = load_cls_label_list(name_list_dir=name_list_dir)
 
     def __getitem__(self, idx):
@@ -82,6 +83,7 @@ class VOC12ClsDataset(VOC12Dataset):
         if not self.aug:
             return name, raw, cls_label
         geo = draw_geometry(image.shape[0], image.shape[1], self.rescale_range, self.crop_size, self.img_fliplr)
+        geo.photometric = draw_train_views(image.shape[0], image.shape[1]) if self.photometric else None
         return name, raw, cls_label, geo
 
 

@@ -395,6 +395,21 @@ int dupl_loader_resample_v_crop(const uint8_t* tmp, uint8_t* out, const int32_t*
  * (datasets/voc.py:96-99,165); mode 1: transforms.normalize_img of the val items (transforms.py:45-52, voc.py:248) */
 int dupl_loader_normalize(const uint8_t* in, float* out, int32_t H, int32_t W, int32_t mode, dupl_stream_t s);
 
+/* Photometric half of the train transform: global_view1 of VOC12ClsDataset / CocoClsDataset (datasets/voc.py:101-114,
+ * 145-146) = torchvision RandomApply([ColorJitter]) + RandomGrayscale + transforms.GaussianBlur (transforms.py:11-29), all
+ * of which run in Pillow's 8-bit arithmetic; here in place on the interleaved uint8 crop (H,W,3), bit-exact with Pillow
+ * (see csrc/photometric.hip).  The draws (which ops, order, factors) are made on the host in torchvision's order. */
+/* ColorJitter brightness (mode 2) / contrast (1) / saturation (0): PIL.ImageEnhance.{Brightness,Contrast,Color}(img)
+ * .enhance(factor); sum_scratch: 1 uint64 (contrast only) */
+int dupl_photo_enhance(uint8_t* img, int32_t H, int32_t W, int32_t mode, float factor, uint64_t* sum_scratch,
+                       dupl_stream_t s);
+/* ColorJitter hue: img.convert("HSV"), h += shift (uint8 wrap, shift = uint8(hue_factor * 255)), convert("RGB") */
+int dupl_photo_hue(uint8_t* img, int64_t n_px, int32_t shift, dupl_stream_t s);
+/* RandomGrayscale: img.convert("L") replicated to 3 channels */
+int dupl_photo_grayscale(uint8_t* img, int64_t n_px, dupl_stream_t s);
+/* transforms.GaussianBlur: img.filter(PIL.ImageFilter.GaussianBlur(radius)); tmp: H*W*3 bytes of scratch; result in img */
+int dupl_photo_gaussian_blur(uint8_t* img, uint8_t* tmp, int32_t H, int32_t W, float radius, dupl_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

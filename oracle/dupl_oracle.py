@@ -911,6 +911,188 @@ def loader_train_item(image: np.ndarray, rescale_range=(0.5, 2.0), crop_size: in
     return (t - mean) / std, box, np.ascontiguousarray(crop)                                             # T.Normalize
 
 
+# ---- photometric views of the train items (datasets/voc.py:101-126).  torchvision (0.14.1 in the reference's
+# requirements.txt) is a third-party dependency that is absent here: its transforms are restated from that version's
+# published source (torchvision/transforms/transforms.py, functional_pil.py) as compositions of the Pillow calls they make;
+# Pillow itself is present and is CALLED, like the reference does.
+
+def tv_adjust_hue(pil, hue_factor: float):
+    """functional_pil.adjust_hue: HSV round trip with `np_h += np.uint8(hue_factor * 255)` (C cast: truncation toward zero,
+    uint8 wrap-around)."""
+    from PIL import Image
+    assert -0.5 <= hue_factor <= 0.5
+    h, s_, v = pil.convert("HSV").split()
+    np_h = (np.asarray(h).astype(np.int32) + (int(hue_factor * 255) & 0xFF)) & 0xFF
+    return Image.merge("HSV", (Image.fromarray(np_h.astype(np.uint8), "L"), s_, v)).convert("RGB")
+
+
+def tv_color_jitter(pil, brightness=(0.6, 1.4), contrast=(0.6, 1.4), saturation=(0.8, 1.2), hue=(-0.1, 0.1), log=None):
+    """T.ColorJitter(0.4, 0.4, 0.2, 0.1).forward: get_params = randperm(4), then one uniform_ per factor in the order
+    brightness, contrast, saturation, hue; the four functional_pil ops (ImageEnhance.Brightness / Contrast / Color, hue)
+    applied in the permuted order."""
+    from PIL import ImageEnhance
+    fn_idx = torch.randperm(4)
+    b = float(torch.empty(1).uniform_(brightness[0], brightness[1]))
+    c = float(torch.empty(1).uniform_(contrast[0], contrast[1]))
+    s_ = float(torch.empty(1).uniform_(saturation[0], saturation[1]))
+    h = float(torch.empty(1).uniform_(hue[0], hue[1]))
+    if log is not None:
+        log.update(order=[int(i) for i in fn_idx], brightness=b, contrast=c, saturation=s_, hue=h)
+    for fn_id in fn_idx:
+        if fn_id == 0:
+            pil = ImageEnhance.Brightness(pil).enhance(b)
+        elif fn_id == 1:
+            pil = ImageEnhance.Contrast(pil).enhance(c)
+        elif fn_id == 2:
+            pil = ImageEnhance.Color(pil).enhance(s_)
+        else:
+            pil = tv_adjust_hue(pil, h)
+    return pil
+
+
+def tv_flip_and_color_jitter(pil, log=None):
+    """`self.flip_and_color_jitter` = Compose([T.RandomApply([T.ColorJitter(0.4, 0.4, 0.2, 0.1)], p=0.8),
+    T.RandomGrayscale(p=0.2)]) (datasets/voc.py:102-109)."""
+    from PIL import Image
+    log = {} if log is None else log
+    log["jitter"] = not (0.8 < float(torch.rand(1)))              # RandomApply.forward: `if self.p < torch.rand(1): return img`
+    if log["jitter"]:
+        pil = tv_color_jitter(pil, log=log)
+    log["gray"] = bool(float(torch.rand(1)) < 0.2)                # RandomGrayscale.forward
+    if log["gray"]:                                               # functional_pil.to_grayscale(img, 3)
+        l = np.asarray(pil.convert("L"), dtype=np.uint8)
+        pil = Image.fromarray(np.dstack([l, l, l]), "RGB")
+    return pil
+
+
+def photometric_view(pil, blur_p: float, log=None):
+    """Compose([flip_and_color_jitter, transforms.GaussianBlur(p=blur_p)]) = `local_view` (blur_p 0.5), `global_view1` (1.0)
+    and the tail of `global_view2` (0.1) without their normalize (datasets/voc.py:111-126; GaussianBlur:
+    datasets/transforms.py:11-29)."""
+    import random
+    from PIL import ImageFilter
+    log = {} if log is None else log
+    pil = tv_flip_and_color_jitter(pil, log)
+    log["blur_radius"] = None
+    if random.random() <= blur_p:
+        log["blur_radius"] = random.uniform(0.1, 2.0)
+        pil = pil.filter(ImageFilter.GaussianBlur(radius=log["blur_radius"]))
+    return pil
+
+
+def loader_train_item_photometric(image: np.ndarray, rescale_range=(0.5, 2.0), crop_size: int = 448, img_fliplr: bool = True):
+    """`__transforms` with aug=True INCLUDING the photometric views (datasets/voc.py:134-148): geometry as in
+    loader_train_item, then local_view (discarded, but it draws), global_view1, normalize.
+    Returns (inputs (3,S,S) float32, img_box, crop uint8 before the view, crop uint8 after it, log of global_view1's draws)."""
+    from PIL import Image
+    _, box, crop = loader_train_item(image, rescale_range, crop_size, img_fliplr)
+    photometric_view(Image.fromarray(crop), 0.5)
+    log = {}
+    after = np.array(photometric_view(Image.fromarray(crop), 1.0, log), dtype=np.uint8)
+    mean = torch.tensor((0.485, 0.456, 0.406), dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225), dtype=torch.float32).view(3, 1, 1)
+    t = torch.from_numpy(after).permute(2, 0, 1).to(torch.float32).div(255)
+    return (t - mean) / std, box, crop, after, log
+
+
+# Pillow's pixel arithmetic behind those calls, written out (what csrc/photometric.hip implements); checked against Pillow
+# itself in tests/test_oracle_golden.py -- exhaustively over all 2^24 colours for the HSV round trip.
+
+def pil_rgb2hsv_np(rgb: np.ndarray) -> np.ndarray:
+    """src/libImaging/Convert.c rgb2hsv_row: float variables, double constants (2.0 + rc - bc, h / 6.0 + 1.0, fmod and
+    h * 255.0 evaluate in double and round when stored)."""
+    f32, f64 = np.float32, np.float64
+    r, g, b = (rgb[..., i].astype(np.int32) for i in range(3))
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    cr = (maxc - minc).astype(f32)
+    safe = np.where(cr == 0, f32(1), cr)
+    s_ = cr / np.where(maxc == 0, 1, maxc).astype(f32)
+    rc, gc, bc = ((maxc - x).astype(f32) / safe for x in (r, g, b))
+    h = np.where(r == maxc, (bc - gc).astype(f64),
+                 np.where(g == maxc, 2.0 + rc.astype(f64) - bc.astype(f64), 4.0 + gc.astype(f64) - rc.astype(f64))).astype(f32)
+    h = np.fmod(h.astype(f64) / 6.0 + 1.0, 1.0).astype(f32)
+    uh = np.clip((h.astype(f64) * 255.0).astype(np.int32), 0, 255)
+    us = np.clip((s_.astype(f64) * 255.0).astype(np.int32), 0, 255)
+    gray = maxc == minc
+    return np.stack([np.where(gray, 0, uh), np.where(gray, 0, us), maxc], -1).astype(np.uint8)
+
+
+def pil_hsv2rgb_np(hsv: np.ndarray) -> np.ndarray:
+    """src/libImaging/Convert.c hsv2rgb (C round() = half away from zero)."""
+    f32, f64 = np.float32, np.float64
+    h, s_, v = hsv[..., 0].astype(f32), hsv[..., 1], hsv[..., 2].astype(np.int32)
+    h6 = h.astype(f64) * 6.0 / 255.0
+    i = np.floor(h6)
+    f = (h6 - i).astype(f32).astype(f64)
+    fs = (s_.astype(f32).astype(f64) / 255.0).astype(f32).astype(f64)
+    vf = v.astype(f32).astype(f64)
+
+    def rnd(x):
+        return np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5)).astype(np.int32)
+
+    p = np.clip(rnd(vf * (1.0 - fs)), 0, 255)
+    q = np.clip(rnd(vf * (1.0 - fs * f)), 0, 255)
+    t = np.clip(rnd(vf * (1.0 - fs * (1.0 - f))), 0, 255)
+    ii = i.astype(np.int32) % 6
+    r = np.choose(ii, [v, q, p, p, t, v])
+    g = np.choose(ii, [t, v, v, q, p, p])
+    b = np.choose(ii, [p, p, t, v, v, q])
+    z = s_ == 0
+    return np.stack([np.where(z, v, r), np.where(z, v, g), np.where(z, v, b)], -1).astype(np.uint8)
+
+
+def pil_hue_shift_np(rgb: np.ndarray, shift: int) -> np.ndarray:
+    hsv = pil_rgb2hsv_np(rgb)
+    hsv[..., 0] = (hsv[..., 0].astype(np.int32) + shift) & 0xFF
+    return pil_hsv2rgb_np(hsv)
+
+
+def pil_gaussian_box_radius(radius: float, passes: int = 3) -> float:
+    """src/libImaging/BoxBlur.c _gaussian_blur_radius: all variables float, the constants 12.0 / 1.0 / 2.0 double."""
+    f, d = np.float32, np.float64
+    r = f(radius)
+    sigma2 = f(f(r * r) / f(passes))
+    L = f(np.sqrt(12.0 * d(sigma2) + 1.0))
+    l = f(np.floor((d(L) - 1.0) / 2.0))
+    a = f(f(f(2) * l + f(1)) * f(f(l * f(l + f(1))) - f(f(3) * sigma2)))
+    a = f(a / f(f(6) * f(sigma2 - f(f(l + f(1)) * f(l + f(1))))))
+    return float(f(l + a))
+
+
+def pil_box_pass_np(img: np.ndarray, fr: float) -> np.ndarray:
+    """One ImagingHorizontalBoxBlur pass along axis 1 of a (H,W,C) uint8 array, in closed form: uint32 fixed point,
+    ww = (uint32)(2^24 / (2 fr + 1)) (float division), fw = (2^24 - (2 [fr] + 1) ww) / 2, window and far pixels clamped."""
+    fr32 = np.float32(fr)
+    radius = int(fr32)
+    ww = int(np.uint32(np.float32(1 << 24) / (fr32 * np.float32(2) + np.float32(1))))
+    fw = (((1 << 24) - (radius * 2 + 1) * ww) & 0xFFFFFFFF) // 2
+    W = img.shape[1]
+    x = np.arange(W)
+    acc = np.zeros(img.shape, np.int64)
+    for d in range(-radius, radius + 1):
+        acc += img[:, np.clip(x + d, 0, W - 1)]
+    far = img[:, np.clip(x - radius - 1, 0, W - 1)].astype(np.int64) + img[:, np.clip(x + radius + 1, 0, W - 1)]
+    bulk = (acc * ww + far * fw) & 0xFFFFFFFF
+    return (((bulk + (1 << 23)) & 0xFFFFFFFF) >> 24).astype(np.uint8)
+
+
+def pil_gaussian_blur_np(img: np.ndarray, radius: float) -> np.ndarray:
+    """ImageFilter.GaussianBlur(radius) on a (H,W,3) uint8 array: ImagingGaussianBlur = ImagingBoxBlur with 3 passes per
+    axis (horizontal passes, transpose, the same passes, transpose back)."""
+    if radius == 0:
+        return img.copy()
+    fr = pil_gaussian_box_radius(radius, 3)
+    if fr == 0:
+        return img.copy()
+    out = img
+    for _ in range(3):
+        out = pil_box_pass_np(out, fr)
+    t = out.transpose(1, 0, 2)
+    for _ in range(3):
+        t = pil_box_pass_np(t, fr)
+    return np.ascontiguousarray(t.transpose(1, 0, 2))
+
+
 def normalize_img(img: np.ndarray, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375)) -> np.ndarray:
     """datasets/transforms.py:45-52 (val items): float32 array of (uint8 - mean) / std, computed by numpy in float64 and
     rounded once on assignment; HWC in, HWC out (the caller transposes, voc.py:250)."""

@@ -117,6 +117,95 @@ def main():
     arrays["val_ramp"] = ramp
     arrays["val_ramp_norm"] = rn
     npz("loader", **arrays)
+    photometric_cases(ref_transforms, tns, Self, mean, std)
+
+
+def extract_class(path, name):
+    import textwrap
+    src = open(os.path.join(REF, path)).read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == name)
+    return textwrap.dedent(ast.get_source_segment(src, node))
+
+
+def photometric_cases(ref_transforms, tns, Self, mean, std):
+    """loader_photo.npz: `__transforms` (the reference's code) with the photometric views switched ON.  The views are
+    Compose([flip_and_color_jitter, GaussianBlur(p)]) (voc.py:102-126): GaussianBlur is the reference's own class
+    (ast-extracted, transforms.py:11-29, calls Pillow); flip_and_color_jitter is torchvision (absent here) -> the oracle's
+    restatement of torchvision 0.14.1 (O.tv_flip_and_color_jitter: RandomApply([ColorJitter]) + RandomGrayscale, every pixel
+    operation a Pillow call).  Also checks that the PRODUCT's host-side draws (dupl_amd/datasets/transforms.py)
+    consume the three generators exactly like this run does."""
+    from PIL import Image, ImageFilter
+    from dupl_amd.datasets import transforms as P
+    bns = {"random": random, "ImageFilter": ImageFilter}
+    exec(extract_class("datasets/transforms.py", "GaussianBlur"), bns)
+    RefBlur = bns["GaussianBlur"]
+
+    class SelfP(Self):
+        def __init__(self, rescale_range, crop_size):
+            super().__init__(rescale_range, crop_size)
+            self.blur_local, self.blur_g1 = RefBlur(p=0.5), RefBlur(p=1.0)
+            self.after, self.log = None, {}
+
+        def local_view(self, pil):
+            return self.blur_local(O.tv_flip_and_color_jitter(pil))
+
+        def global_view1(self, pil):
+            self.crops_u8.append(np.asarray(pil).copy())
+            out = self.blur_g1(O.tv_flip_and_color_jitter(pil, self.log))
+            self.after = np.asarray(out).copy()
+            return out
+
+    cases = [(187, 250, 224, (0.5, 2.0), 11), (166, 250, 224, (0.5, 2.0), 12), (250, 140, 224, (0.5, 2.0), 13),
+             (120, 90, 96, (0.5, 2.0), 14), (300, 400, 448, (0.5, 2.0), 15), (97, 131, 96, (1.9, 2.0), 18),
+             (200, 260, 160, (0.5, 2.0), 19), (240, 180, 160, (0.5, 2.0), 20), (150, 150, 128, (0.5, 2.0), 21),
+             (333, 211, 192, (0.5, 2.0), 22)]
+    arrays = {"n_cases": len(cases)}
+    seen = {"jitter": 0, "gray": 0, "orders": set()}
+    for i, (h, w, S, rr, seed) in enumerate(cases):
+        img = synth_image(h, w, 70 + i)
+
+        def reseed():
+            random.seed(seed)
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+
+        reseed()
+        me = SelfP(rr, S)
+        t, _, box = ref_transforms(me, img)
+        crop, after, log = me.crops_u8[0], me.after, me.log
+        state_ref = (random.random(), float(np.random.rand()), float(torch.rand(1)))
+        # the reference's own blur drew the radius: recover it by replaying the draws through the oracle
+        reseed()
+        ot, obox, ocrop, oafter, olog = O.loader_train_item_photometric(img, rr, S)
+        state_orc = (random.random(), float(np.random.rand()), float(torch.rand(1)))
+        assert torch.equal(ot, t) and np.array_equal(obox, box) and np.array_equal(ocrop, crop) and np.array_equal(oafter, after), i
+        assert state_ref == state_orc, "generators out of step after one item"
+        for k in ("jitter", "gray", "order", "brightness", "contrast", "saturation", "hue"):
+            assert olog.get(k) == log.get(k), (i, k)
+        # product-side draws: same numbers, same generator positions (up to the end of `__transforms`)
+        reseed()
+        geo = P.draw_geometry(h, w, rr, S, True)
+        P.draw_view(0.5)
+        pm = P.draw_view(1.0)
+        assert (random.random(), float(np.random.rand()), float(torch.rand(1))) == state_ref
+        assert pm.jitter == olog["jitter"] and pm.gray == olog["gray"] and pm.blur_radius == olog["blur_radius"]
+        if pm.jitter:
+            assert list(pm.order) == olog["order"] and (pm.brightness, pm.contrast, pm.saturation, pm.hue) == \
+                (olog["brightness"], olog["contrast"], olog["saturation"], olog["hue"])
+            seen["orders"].add(tuple(pm.order))
+        assert np.array_equal(geo.img_box, box)
+        seen["jitter"] += pm.jitter
+        seen["gray"] += pm.gray
+        arrays.update({f"img.{i}": img, f"seed.{i}": seed, f"crop_size.{i}": S, f"rescale.{i}": np.asarray(rr),
+                       f"after.{i}": after, f"img_box.{i}": box, f"inputs_sub.{i}": t[:, ::7, ::5].numpy(),
+                       f"jitter.{i}": int(pm.jitter), f"order.{i}": np.asarray(pm.order, dtype=np.int64),
+                       f"factors.{i}": np.asarray([pm.brightness, pm.contrast, pm.saturation, pm.hue], dtype=np.float64),
+                       f"gray.{i}": int(pm.gray), f"blur_radius.{i}": float(pm.blur_radius)})
+        print(f"  photometric case {i}: crop {S}, jitter {pm.jitter} order {pm.order} gray {pm.gray} blur {pm.blur_radius:.4f}, "
+              f"changed bytes {int((after != crop).sum())}")
+    print(f"  coverage: jitter fired {seen['jitter']}/{len(cases)}, gray {seen['gray']}, distinct op orders {len(seen['orders'])}")
+    assert seen["jitter"] >= 5 and seen["gray"] >= 1 and seen["jitter"] < len(cases)
+    npz("loader_photo", **arrays)
 
 
 if __name__ == "__main__":

@@ -299,3 +299,129 @@ def test_epoch_iterator_follows_reference_sampler_protocol():
     assert one.next() == 1
     with pytest.raises(RuntimeError, match="empty after a restart"):
         one.next()
+
+
+def _reseed(seed):
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def test_loader_photometric_golden_replays(golden_dir):
+    """tests/golden/loader_photo.npz: the reference's `__transforms` with its photometric views ON (oracle/gen_golden_loader.py:
+    the reference's own code + GaussianBlur class, torchvision 0.14.1's RandomApply / ColorJitter / RandomGrayscale restated
+    as the Pillow calls they make).  The oracle replays every case bit-exactly on the same seeds, and the product's host side
+    (datasets/transforms.py) draws the same numbers from the same three generators and leaves them in the same state."""
+    import random
+    from dupl_amd.datasets import transforms as P
+    g = np.load(os.path.join(golden_dir, "loader_photo.npz"))
+    for i in range(int(g["n_cases"])):
+        img, seed, S, rr = g[f"img.{i}"], int(g[f"seed.{i}"]), int(g[f"crop_size.{i}"]), tuple(g[f"rescale.{i}"])
+        _reseed(seed)
+        t, box, crop, after, log = O.loader_train_item_photometric(img, rr, S)
+        state = (random.random(), float(np.random.rand()), float(torch.rand(1)))
+        assert np.array_equal(after, g[f"after.{i}"]) and np.array_equal(box, g[f"img_box.{i}"])
+        assert np.array_equal(t[:, ::7, ::5].numpy(), g[f"inputs_sub.{i}"])
+        _reseed(seed)
+        geo = P.draw_geometry(img.shape[0], img.shape[1], rr, S)
+        P.draw_view(0.5)
+        pm = P.draw_view(1.0)
+        assert (random.random(), float(np.random.rand()), float(torch.rand(1))) == state
+        assert np.array_equal(geo.img_box, box)
+        assert int(pm.jitter) == int(g[f"jitter.{i}"]) and int(pm.gray) == int(g[f"gray.{i}"])
+        assert pm.blur_radius == float(g[f"blur_radius.{i}"]) == log["blur_radius"]
+        assert list(pm.order) == list(g[f"order.{i}"])
+        assert [pm.brightness, pm.contrast, pm.saturation, pm.hue] == list(g[f"factors.{i}"])
+        # the written-out Pillow arithmetic (what csrc/photometric.hip implements) applied with those draws == the golden
+        x = crop.copy()
+        if pm.jitter:
+            from PIL import Image, ImageEnhance
+            for fn in pm.order:
+                if fn == 3:
+                    x = O.pil_hue_shift_np(x, pm.hue_shift)
+                else:          # ImageEnhance arithmetic: pinned in tests/test_augment_gpu.py / oracle RandAugment goldens
+                    enh = (ImageEnhance.Brightness, ImageEnhance.Contrast, ImageEnhance.Color)[fn]
+                    x = np.array(enh(Image.fromarray(x)).enhance([pm.brightness, pm.contrast, pm.saturation][fn]))
+        if pm.gray:
+            l = ((x[..., 0].astype(np.int64) * 19595 + x[..., 1].astype(np.int64) * 38470 + x[..., 2].astype(np.int64) * 7471
+                  + 0x8000) >> 16).astype(np.uint8)
+            x = np.dstack([l, l, l])
+        x = O.pil_gaussian_blur_np(x, pm.blur_radius)
+        assert np.array_equal(x, g[f"after.{i}"]), f"case {i}"
+
+
+def test_photometric_draws_follow_torchvision_order():
+    """draw_view against a hand-rolled trace of the generators: RandomApply's torch.rand(1), ColorJitter.get_params'
+    randperm(4) + 4 uniform_, RandomGrayscale's torch.rand(1), then random.random() / random.uniform of the reference's
+    GaussianBlur; draw_train_views = local_view, global_view1, RandomResizedCrop, global_view2's view, Solarization."""
+    import random
+    from dupl_amd.datasets import transforms as P
+    for seed in range(40):
+        _reseed(seed)
+        pm = P.draw_view(0.5)
+        end = (float(torch.rand(1)), random.random())
+        _reseed(seed)
+        fired = not (0.8 < float(torch.rand(1)))
+        assert fired == pm.jitter
+        if fired:
+            assert tuple(int(v) for v in torch.randperm(4)) == pm.order
+            vals = [float(torch.empty(1).uniform_(a, b)) for a, b in ((0.6, 1.4), (0.6, 1.4), (0.8, 1.2), (-0.1, 0.1))]
+            assert vals == [pm.brightness, pm.contrast, pm.saturation, pm.hue]
+            assert 0.6 <= pm.brightness <= 1.4 and 0.8 <= pm.saturation <= 1.2 and -0.1 <= pm.hue <= 0.1
+            assert pm.hue_shift == (int(pm.hue * 255) & 0xFF) and 0 <= pm.hue_shift <= 255
+        assert (float(torch.rand(1)) < 0.2) == pm.gray
+        r = None
+        if random.random() <= 0.5:
+            r = random.uniform(0.1, 2.0)
+        assert r == pm.blur_radius
+        assert end == (float(torch.rand(1)), random.random())
+    _reseed(5)
+    g1 = P.draw_train_views(375, 500)
+    assert g1.blur_radius is not None and 0.1 <= g1.blur_radius <= 2.0      # global_view1: GaussianBlur(p=1.0)
+    i, j, h, w = P.draw_random_resized_crop(375, 500)
+    assert 0 <= i <= 375 - h and 0 <= j <= 500 - w and 0.39 * 375 * 500 <= h * w <= 375 * 500 * 1.01
+
+
+def test_photometric_pillow_arithmetic_restatement():
+    """The Pillow arithmetic written out in the oracle (and implemented in csrc/photometric.hip) against Pillow itself:
+    RGB -> HSV and HSV -> RGB over ALL 2^24 triples, the hue shift, GaussianBlur over 120 radii (including radii where a
+    double-precision reading of _gaussian_blur_radius would give another box weight) and odd image shapes."""
+    import random
+    from PIL import Image, ImageFilter
+    a = np.arange(1 << 24, dtype=np.uint32)
+    rgb = np.stack([(a >> 16) & 255, (a >> 8) & 255, a & 255], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    assert np.array_equal(O.pil_rgb2hsv_np(rgb), np.asarray(Image.fromarray(rgb).convert("HSV")))
+    assert np.array_equal(O.pil_hsv2rgb_np(rgb), np.asarray(Image.fromarray(rgb, "HSV").convert("RGB")))
+    sub = rgb[::16, ::16].copy()
+    for shift in (0, 1, 25, 128, 230, 255):
+        h, s_, v = Image.fromarray(sub).convert("HSV").split()
+        nh = ((np.asarray(h).astype(np.int32) + shift) & 255).astype(np.uint8)
+        ref = np.asarray(Image.merge("HSV", (Image.fromarray(nh, "L"), s_, v)).convert("RGB"))
+        assert np.array_equal(O.pil_hue_shift_np(sub, shift), ref)
+        assert np.array_equal(np.asarray(O.tv_adjust_hue(Image.fromarray(sub), 0.1)), O.pil_hue_shift_np(sub, 25))
+        assert np.array_equal(np.asarray(O.tv_adjust_hue(Image.fromarray(sub), -0.1)), O.pil_hue_shift_np(sub, (-25) & 255))
+    rng = np.random.RandomState(0)
+    random.seed(5)
+
+    def ww_of(fr):
+        return int(np.uint32(np.float32(1 << 24) / (np.float32(fr) * np.float32(2) + np.float32(1))))
+
+    def radius_in_double(r):
+        s2 = r * r / 3
+        L = np.sqrt(12.0 * s2 + 1.0)
+        l = np.floor((L - 1.0) / 2.0)
+        return l + (2 * l + 1) * (l * (l + 1) - 3.0 * s2) / (6.0 * (s2 - (l + 1) * (l + 1)))
+
+    radii = [0.1, 0.5, 1.0, 1.5, 2.0, 1.2247, 1.2248, 3.7, 9.3]
+    tricky = []
+    while len(tricky) < 60:
+        r = random.uniform(0.1, 2.0)
+        if ww_of(O.pil_gaussian_box_radius(r)) != ww_of(radius_in_double(r)):
+            tricky.append(r)
+    radii += tricky + [random.uniform(0.1, 2.0) for _ in range(51)]
+    for k, r in enumerate(radii):
+        h, w = [(64, 80), (33, 47), (5, 90), (70, 3)][k % 4]
+        img = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        ref = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=r)))
+        assert np.array_equal(O.pil_gaussian_blur_np(img, r), ref), (r, h, w)
