@@ -219,7 +219,9 @@ class GemmTimer:
         self.flops = {"f16x3": 0.0, "f32": 0.0}
         self.bytes = {"f16x3": 0.0, "f32": 0.0}
 
-    def _timed(self, kind, fn, M, N, K, batch=1):
+    def _timed(self, kind, fn, M, N, K, batch=1, mn_tensors=1):
+        """mn_tensors: how many [M, N] 4-byte-per-element tensors the launch reads or writes (fp32 result, result planes,
+        residual, stored pre-activation, activation-gradient operand, accumulated-into result)."""
         s = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
@@ -227,7 +229,7 @@ class GemmTimer:
         e1.record(s)
         self.pairs[kind].append((e0, e1))
         self.flops[kind] += 2.0 * M * N * K * batch
-        self.bytes[kind] += 4.0 * (M * K + N * K + M * N) * batch      # two fp16 planes = 4 bytes per element as well
+        self.bytes[kind] += 4.0 * (M * K + N * K + mn_tensors * M * N) * batch     # two fp16 planes = 4 bytes per element
         return r
 
     def install(self):
@@ -241,7 +243,11 @@ class GemmTimer:
             return timer._timed("f32", lambda: timer._orig(A, B, C, M, N, K, lda, ldb, ldc, **kw), M, N, K, kw.get("batch", 1))
 
         def timed16(x, W, *a, **kw):
-            return timer._timed("f16x3", lambda: timer._orig16(x, W, *a, **kw), x.rows, W.rows, x.cols)
+            f32_out = kw.get("want_f32", True) or kw.get("out") is not None
+            planes_out = kw.get("want16", False) or kw.get("out16") is not None
+            aux = sum(kw.get(k) is not None for k in ("res", "store_pre", "dgelu_of", "relumask_of"))
+            mn = int(f32_out) * (2 if kw.get("accumulate", False) else 1) + int(planes_out) + aux
+            return timer._timed("f16x3", lambda: timer._orig16(x, W, *a, **kw), x.rows, W.rows, x.cols, mn_tensors=mn)
 
         ops.gemm_raw, ops.linear16 = timed, timed16
 
@@ -407,6 +413,7 @@ def main():
                 "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_source": tnote, "csrc_sha256": csrc_digest()[:16],
                 "algorithmic_bytes_per_launch": round(gbytes / max(gn, 1)),
+                "traffic_over_algorithmic": (round(traffic * gn / gbytes, 2) if traffic else None),
                 "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
                 "kernel_share_of_step": round(gms / ms, 3),
                 "step_flop_per_img": {"reference_algorithm": flop_ref, "executed": flop_exec},
