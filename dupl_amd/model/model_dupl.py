@@ -28,6 +28,8 @@ from .backbone import encoder_config, load_pretrained_encoder
 from .decoder.conv_head import LargeFOV
 
 
+_STREAM_PAIRS = {}     # device -> the two student streams (see siamese_network.enable_dual_stream)
+
 class _Holder(nn.Module):
     """Bare container used to reproduce the reference's state_dict key hierarchy."""
 
@@ -306,8 +308,13 @@ class siamese_network(nn.Module):
         backward on the stream its forward ran on; the optimiser and the gradient exchange wait on both."""
         self._dual = bool(on)
         if on and self._store.data.is_cuda and not self._store.streams:
+            # one pair per device for the whole process, reused by every model and toggle: HIP maps streams onto a few hardware queues
+            # round-robin, and a second pair can land on queues that serialise against each other (measured: toggling
+            # off and on with fresh streams ran at single-stream speed)
             dev = self._store.data.device
-            self._store.streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            if dev not in _STREAM_PAIRS:
+                _STREAM_PAIRS[dev] = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            self._store.streams = list(_STREAM_PAIRS[dev])
         if not on:
             self._store.streams = []
         return self
