@@ -71,6 +71,10 @@ def build_parser(dataset: str) -> argparse.ArgumentParser:
                    help="auto (default): synthetic batches unless the dataset folder exists; 1 / 0 force it")
     p.add_argument("--start_iter", default=0, type=int,
                    help="first n_iter (lets a short run exercise phase B); the LR schedule starts there too")
+    p.add_argument("--resume", default=None, type=str,
+                   help="checkpoint directory of an earlier run: loads checkpoint.pth (reference format) and optimizer.pth "
+                        "(moments, bias-correction counters, schedule position) and continues at the saved n_iter")
+    p.add_argument("--stop_iter", default=None, type=int, help="leave the loop before this n_iter (time-boxed jobs + --resume)")
     p.add_argument("--single_stream", action="store_true")
     p.add_argument("--deterministic", action="store_true",
                    help="bit-reproducible steps (dupl_amd.set_deterministic): what cudnn.deterministic = True asks for in "
@@ -206,9 +210,18 @@ def train(args, dataset: str, loader=None, val_loader=None):
             val_loader = val_loader if val_loader is not None else built_val
     it = _EpochIterator(loader, args.max_iters) if loader is not None else None
     optim.global_step = args.start_iter       # a run that starts at n_iter = k is at step k of the LR schedule too
+    if getattr(args, "resume", None):
+        ck = torch.load(os.path.join(args.resume, "checkpoint.pth"), map_location="cpu")
+        model.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in ck.items()}, strict=True)
+        ost = torch.load(os.path.join(args.resume, "optimizer.pth"), map_location="cpu")
+        optim.load_state_dict(ost["optimizer"])
+        args.start_iter = int(ost["n_iter"])
+        if rank == 0:
+            logging.info("resumed from %s at n_iter %d" % (args.resume, args.start_iter))
+    last_iter = args.max_iters if getattr(args, "stop_iter", None) is None else min(args.max_iters, args.stop_iter)
     t0 = time.time()
     acc = {}
-    for n_iter in range(args.start_iter, args.max_iters):
+    for n_iter in range(args.start_iter, last_iter):
         if it is not None:
             _, inputs, cls_label, img_box, _ = it.next()
             cls_label = cls_label.float()
@@ -233,6 +246,7 @@ def train(args, dataset: str, loader=None, val_loader=None):
             os.makedirs(args.ckpt_dir, exist_ok=True)
             sd = wrapped.state_dict() if distributed else {"module." + k: v for k, v in model.state_dict().items()}
             torch.save(sd, os.path.join(args.ckpt_dir, "checkpoint.pth"))     # keys prefixed `module.` (train_final_voc.py:519)
+            torch.save({"n_iter": n_iter + 1, "optimizer": optim.state_dict()}, os.path.join(args.ckpt_dir, "optimizer.pth"))
         if (n_iter + 1) % args.eval_iters == 0 and rank == 0:
             # in-loop validation on rank 0 (train_final_voc.py:521-533); with no dataset mounted a few synthetic
             # native-size samples stand in for the val split so that the path is exercised end to end

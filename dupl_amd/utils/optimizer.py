@@ -102,3 +102,32 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
                               grp["weight_decay"])
         store.mark_dirty()       # parameters were rewritten through raw pointers: their f16x3 operand planes are stale
         self.global_step += 1
+
+    # ---- resume (the reference saves no optimiser state; --start_iter with a checkpoint is this build's own path) --------
+    def state_dict(self):
+        """Everything `step` depends on: schedule position, the flat moment buffers, the per-(student, segment) step
+        counts of the bias correction and which segments have received gradients."""
+        sd = {"global_step": self.global_step, "lr": [g["lr"] for g in self.param_groups]}
+        if self._flat is not None:
+            store, m, v, steps = self._flat
+            store.wait_streams()
+            sd.update(exp_avg=m.detach().clone(), exp_avg_sq=v.detach().clone(), steps=[list(r) for r in steps],
+                      seg_has_grad=[list(r) for r in store.seg_has_grad])
+        return sd
+
+    def load_state_dict(self, sd):
+        self.global_step = int(sd["global_step"])
+        for g, lr in zip(self.param_groups, sd["lr"]):
+            g["lr"] = lr
+        if "exp_avg" in sd:
+            if self._flat is None:
+                raise RuntimeError("bind(model.flat_storage) before load_state_dict: the moments live in flat buffers")
+            store, m, v, steps = self._flat
+            if sd["exp_avg"].numel() != m.numel():
+                raise ValueError(f"optimiser state of {sd['exp_avg'].numel()} elements for a model of {m.numel()}")
+            m.copy_(sd["exp_avg"].to(m.device))
+            v.copy_(sd["exp_avg_sq"].to(v.device))
+            for s_, row in enumerate(sd["steps"]):
+                steps[s_][:] = [int(x) for x in row]
+            for s_, row in enumerate(sd["seg_has_grad"]):
+                store.seg_has_grad[s_][:] = [bool(x) for x in row]

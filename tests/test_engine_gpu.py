@@ -246,6 +246,52 @@ def test_optimizer_step_matches_oracle(dev):
     assert worst < 1e-6   # fp32 round-off (fma contraction on the GPU vs separate mul/add in ATen's CPU AdamW)
 
 
+def test_optimizer_state_dict_resumes_bit_exactly(dev):
+    """state_dict / load_state_dict of the fused optimiser (schedule position, flat moments, per-segment bias-correction
+    counters, which segments have gradients): 2 steps + save + 2 steps == 2 steps, restore into a fresh model + optimiser,
+    2 steps, bit for bit."""
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.utils.optimizer import PolyWarmupAdamW
+    from oracle import dupl_oracle as O
+    pp = O.make_siamese_params(O.VIT_TINY, 21, seed=4)
+
+    def make():
+        model = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+        model.load_state_dict(pp, strict=True)
+        model.to(dev)
+        g = model.get_param_groups()
+        opt = PolyWarmupAdamW(params=[{"params": g[i], "lr": 6e-5 * (1 if i < 2 else 10), "weight_decay": 0.01} for i in range(4)],
+                              lr=6e-5, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=3, max_iter=20, warmup_ratio=1e-6,
+                              power=0.9).bind(model.flat_storage)
+        return model, opt
+
+    def step(model, opt, t):
+        st = model.flat_storage
+        opt.zero_grad()
+        gen = torch.Generator().manual_seed(100 + t)
+        st.grad.copy_((torch.randn(st.grad.numel(), generator=gen) * 0.01).to(dev))
+        for s in (0, 1):
+            st.seg_has_grad[s] = [False, True, True, True, t >= 1]
+        opt.step()
+
+    m1, o1 = make()
+    for t in range(2):
+        step(m1, o1, t)
+    sd_model = {k: v.clone() for k, v in m1.state_dict().items()}
+    sd_opt = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in o1.state_dict().items()}      # as torch.save would
+    for t in range(2, 4):
+        step(m1, o1, t)
+    m2, o2 = make()
+    m2.load_state_dict(sd_model, strict=True)
+    o2.load_state_dict(sd_opt)
+    assert o2.global_step == 2
+    for t in range(2, 4):
+        step(m2, o2, t)
+    a, b = m1.state_dict(), m2.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert o1.global_step == o2.global_step == 4 and [g["lr"] for g in o1.param_groups] == [g["lr"] for g in o2.param_groups]
+
+
 @pytest.mark.parametrize("tag", ["A", "B1", "B2"])
 def test_coco_schedule_step_matches_reference(dev, golden_dir, tag):
     """COCO schedule (train_final_coco.py:190-448), 81 classes, vs the reference composition

@@ -34,6 +34,27 @@ def test_train_final_voc_script_runs_all_phases(dev, tmp_path):
     assert all(k.startswith("module.branch") for k in sd) and len(sd) == 2 * 61   # tiny backbone: 61 tensors per student
 
 
+def test_resume_continues_an_interrupted_run_bit_exactly(dev, tmp_path):
+    """--stop_iter 2 (checkpoint.pth + optimizer.pth after iteration 2), then --resume to max_iters 4 == one uninterrupted
+    4-iteration run: same final checkpoint bit for bit (--deterministic; synthetic batches are a function of n_iter; phases
+    A -> B; the optimiser state carries moments, bias-correction counters and the schedule position)."""
+    common = ["--cam_iters", "1", "--gmm_iters", "50", "--max_iters", "4", "--warmup_iters", "2", "--eval_iters", "2",
+              "--log_iters", "1", "--deterministic"]
+    a, b = str(tmp_path / "interrupted"), str(tmp_path / "straight")
+    _run("train_final_voc.py", common + ["--stop_iter", "2", "--work_dir", a], 29641)
+    ck_a = [os.path.join(d, "checkpoint.pth") for d, _, fs in os.walk(a) if "checkpoint.pth" in fs and "optimizer.pth" in fs]
+    assert len(ck_a) == 1
+    first = torch.load(ck_a[0], map_location="cpu")
+    out = _run("train_final_voc.py", common + ["--resume", os.path.dirname(ck_a[0]), "--work_dir", a + "_2"], 29642)
+    assert "resumed from" in out and "Iter: 3;" in out and "Iter: 4;" in out and "Iter: 1;" not in out
+    _run("train_final_voc.py", common + ["--work_dir", b], 29643)
+    fin = lambda root: torch.load([os.path.join(d, "checkpoint.pth") for d, _, fs in os.walk(root) if "checkpoint.pth" in fs][0],
+                                  map_location="cpu")
+    sa, sb = fin(a + "_2"), fin(b)
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k], sb[k]) for k in sa)
+    assert any(not torch.equal(sa[k], first[k]) for k in sa)             # it did train after the resume
+
+
 def test_train_final_coco_script_runs(dev):
     out = _run("train_final_coco.py", ["--cam_iters", "2", "--gmm_iters", "1000", "--max_iters", "4", "--warmup_iters", "2",
                                        "--num_classes", "81"], 29612)
