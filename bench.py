@@ -412,6 +412,9 @@ def main():
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach / 1e12, 2),
                 "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_source": tnote, "csrc_sha256": csrc_digest()[:16],
+                "peak_definition": ("dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per fp32-equivalent multiply-add; "
+                                    f"executed MFMA rate = {3 * ach / 1e12:.1f} of 2500 TFLOP/s (the same fraction)")
+                if kind == "f16x3" else "f32 MFMA peak (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s",
                 "algorithmic_bytes_per_launch": round(gbytes / max(gn, 1)),
                 "traffic_over_algorithmic": (round(traffic * gn / gbytes, 2) if traffic else None),
                 "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
