@@ -23,10 +23,12 @@ from . import ops
 
 Tensor = torch.Tensor
 
-# Forward Linear layers of the encoder: "f16x3" (default) = the fp32-equivalent split GEMM on the f16 matrix cores
-# (csrc/gemm_split.hip: 3 f16 MFMAs per block, operands as fp16 hi / lo planes written by the producing kernels; closer to
-# an fp64-accumulated reference than the fp32 fmaf chain, every parity test holds in either mode), "f32" = the exact-f32
-# MFMA kernel (csrc/gemm.hip; DUPL_GEMM=f32 or set_gemm_mode).  Backward GEMMs and attention always run on f32 kernels.
+# Dense contractions of the step: "f16x3" (default) = fp32-equivalent split products on the f16 matrix cores for the encoder
+# and decoder-conv GEMMs (forward, data and weight gradients: csrc/gemm_split.hip, split_prep.hip) and the attention (forward
+# and backward, head dim 64: csrc/attn_split*.hip) -- 3 f16 MFMAs per block, operands as fp16 hi / lo planes written by the
+# producing kernels; closer to an fp64-accumulated reference than the fp32 fmaf chain, every parity test holds in either mode;
+# "f32" = the exact-f32 MFMA kernels for all of them (csrc/gemm.hip, attn.hip; DUPL_GEMM=f32 or set_gemm_mode).  Patch
+# embedding, CAM / classifier heads, conv8 and the PTC Gram run on the f32 kernels in both modes.
 GEMM_MODE = os.environ.get("DUPL_GEMM", "f16x3")
 
 
