@@ -45,8 +45,8 @@ KERNEL_F32 = "gemm_f32_kernel<false,false,...> (v_mfma_f32_32x32x2_f32; every Li
 
 DTYPE = {"f16x3": "f32 storage / accumulation / results; Linear GEMMs (forward, dgrad, wgrad), attention (forward, backward) and "
                   "the decoder convs as fp32-equivalent f16x3 split products on the f16 MFMA (operands as fp16 hi / lo planes, "
-                  "3 products per block, fp32 accumulate; error vs fp64 <= the f32 MFMA kernels'); patch embedding, CAM heads, "
-                  "Gram, norms, losses, PAR, optimiser in f32",
+                  "3 products per block, fp32 accumulate; error vs fp64 <= the f32 MFMA kernels'); CAM / classifier heads, conv8, "
+                  "Gram, patch-embedding weight gradient, norms, losses, PAR, optimiser in f32",
          "f32": "f32"}
 CONFIG_BY_N = {1: ("voc", 4, "deit_base_patch16_224", "configs[1]"),
                2: ("voc", 2, "deit_base_patch16_224", "configs[2]"),

@@ -27,8 +27,8 @@ Tensor = torch.Tensor
 # and decoder-conv GEMMs (forward, data and weight gradients: csrc/gemm_split.hip, split_prep.hip) and the attention (forward
 # and backward, head dim 64: csrc/attn_split*.hip) -- 3 f16 MFMAs per block, operands as fp16 hi / lo planes written by the
 # producing kernels; closer to an fp64-accumulated reference than the fp32 fmaf chain, every parity test holds in either mode;
-# "f32" = the exact-f32 MFMA kernels for all of them (csrc/gemm.hip, attn.hip; DUPL_GEMM=f32 or set_gemm_mode).  Patch
-# embedding, CAM / classifier heads, conv8 and the PTC Gram run on the f32 kernels in both modes.
+# "f32" = the exact-f32 MFMA kernels for all of them (csrc/gemm.hip, attn.hip; DUPL_GEMM=f32 or set_gemm_mode).  The CAM /
+# classifier heads, conv8, the PTC Gram and the patch-embedding weight gradient run on the f32 kernels in both modes.
 GEMM_MODE = os.environ.get("DUPL_GEMM", "f16x3")
 
 
