@@ -28,13 +28,13 @@ def load_cls_label_list(name_list_dir):
 def _read_rgb(path):
     from PIL import Image
     with Image.open(path) as im:
-        return np.asarray(im.convert("RGB"))
+        return np.array(im.convert("RGB"))      # a writable copy: the items become torch tensors
 
 
 def _read_label(path):
     from PIL import Image
     with Image.open(path) as im:
-        return np.asarray(im)
+        return np.array(im)
 
 
 class VOC12Dataset(Dataset):

@@ -70,7 +70,7 @@ def msc_seg_logits_coco(model, inputs, scales=(1.0, 1.25, 1.5), size=448):
     return accs[0], accs[1]
 
 
-def validate_coco(model, data_loader, args, num_classes=81, cat_list=None, process_group=None):
+def validate_coco(model, data_loader, args, num_classes=81, cat_list=None, process_group=None, keep_logits=None):
     """eval_seg_coco_ddp._validate on this rank's shard of the loader (the reference splits the val set round-robin over
     the ranks, tools/eval_seg_coco_ddp.py:239-245, and every rank scores its own shard).  With `process_group` (or an
     initialised default group) the per-rank confusion matrices are additionally summed over the ranks -- nc^2 int64
@@ -87,6 +87,8 @@ def validate_coco(model, data_loader, args, num_classes=81, cat_list=None, proce
         H, W = labels.shape[1:]
         for k in range(2):
             cms[k].update(labels, ops.upsample_argmax(seg[k], H, W))
+            if keep_logits is not None:          # eval_seg_coco_ddp.py:127-128 saves the summed low-resolution logits
+                keep_logits(data[0], k + 1, seg[k])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
         for c in cms:
             dist.all_reduce(c.hist, op=dist.ReduceOp.SUM, group=process_group)
@@ -116,3 +118,90 @@ def validate(model, data_loader, args, num_classes=21, cat_list=None, keep_logit
     if cat_list is not None:
         print(format_tabs(sc, ["Seg_1", "Seg_2"], cat_list=cat_list))
     return sc[0], sc[1]
+
+
+def build_parser():
+    """The flags of tools/eval_seg_voc.py:26-36 / tools/eval_seg_coco_ddp.py:31-46 (same names and defaults) + --dataset."""
+    import argparse
+    p = argparse.ArgumentParser()
+    p.add_argument("--dataset", default="voc", choices=("voc", "coco"))
+    p.add_argument("--infer_set", default="val", type=str)
+    p.add_argument("--pooling", default="gmp", type=str)
+    p.add_argument("--model_path", default="your_model_dir/checkpoints.pth", type=str)
+    p.add_argument("--backbone", default="deit_base_patch16_224", type=str)
+    p.add_argument("--data_folder", default="your_voc_dir", type=str, help="VOC: dataset folder")
+    p.add_argument("--img_folder", default="your_coco_dir/JPEGImages", type=str, help="COCO: image folder")
+    p.add_argument("--label_folder", default="your_coco_dir/SegmentationClass", type=str, help="COCO: label folder")
+    p.add_argument("--list_folder", default=None, type=str)
+    p.add_argument("--num_classes", default=None, type=int)
+    p.add_argument("--ignore_index", default=255, type=int)
+    p.add_argument("--scales", default=None, help="multi-scale list; default (1.0, 1.5, 1.25) VOC / (1.0, 1.25, 1.5) COCO")
+    p.add_argument("--save_logits", default=1, type=int,
+                   help="write <run>/segs/logits/<infer_set>/branch{1,2}/<name>.npy = {'msc_seg': ...} like the reference does for "
+                        "its DenseCRF stage (utils/dcrf.py, CPU, outside this package)")
+    return p
+
+
+def main(argv=None):
+    """tools/eval_seg_voc.py:154-193 (`validate`) / tools/eval_seg_coco_ddp.py:142-248 up to the CRF stage: build the val
+    loader, load the reference-format checkpoint strictly, run the multi-scale + flip inference of both students, print the
+    score tables; under torch.distributed.run the COCO split is sharded round-robin over the ranks and the confusion
+    matrices are summed."""
+    import os
+    import numpy as np
+    import torch.distributed as dist
+    from torch.utils.data import DataLoader, Subset
+    from ..datasets import voc, coco
+    from ..datasets.device_loader import DeviceValLoader, raw_collate
+    from ..model.model_dupl import siamese_network
+    args = build_parser().parse_args(argv)
+    is_voc = args.dataset == "voc"
+    args.num_classes = args.num_classes or (21 if is_voc else 81)
+    args.list_folder = args.list_folder or ("datasets/voc" if is_voc else "datasets/coco")
+    if isinstance(args.scales, str):
+        args.scales = tuple(float(v) for v in args.scales.strip("()[] ").split(","))
+    args.scales = args.scales or ((1.0, 1.5, 1.25) if is_voc else (1.0, 1.25, 1.5))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl")
+    if is_voc:
+        ds = voc.VOC12SegDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.infer_set, stage="val",
+                                 aug=False, ignore_index=args.ignore_index, num_classes=args.num_classes)
+    else:
+        ds = coco.CocoSegDataset(img_dir=args.img_folder, label_dir=args.label_folder, name_list_dir=args.list_folder,
+                                 split=args.infer_set, stage="val", aug=False, ignore_index=args.ignore_index)
+    if world > 1:
+        ds = Subset(ds, list(range(dist.get_rank(), len(ds), world)))        # eval_seg_coco_ddp.py:239-245
+    loader = DeviceValLoader(DataLoader(ds, batch_size=1, shuffle=False, num_workers=8, pin_memory=False, drop_last=False,
+                                        collate_fn=raw_collate), dev)
+    model = siamese_network(backbone=args.backbone, num_classes=args.num_classes, pretrained=False, aux_layer=-3)
+    load_checkpoint(model, args.model_path)
+    model.to(dev)
+    model.eval()
+    base_dir = args.model_path.split("checkpoints")[0]
+    logits_dir = os.path.join(base_dir, "segs/logits", args.infer_set)
+    keep = None
+    if args.save_logits:
+        for b in ("branch1", "branch2"):
+            os.makedirs(os.path.join(logits_dir, b), exist_ok=True)
+
+        def keep(name, branch, logits):
+            nm = name[0] if isinstance(name, (tuple, list)) else name
+            np.save(os.path.join(logits_dir, f"branch{branch}", str(nm) + ".npy"), {"msc_seg": logits.cpu().numpy()})
+
+    with torch.no_grad():
+        if is_voc:
+            s1, s2 = validate(model, loader, args, args.num_classes, voc.class_list, keep_logits=keep)
+        else:
+            s1, s2 = validate_coco(model, loader, args, args.num_classes, coco.class_list, keep_logits=keep)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print({"Seg_1 mIoU": s1["miou"], "Seg_2 mIoU": s2["miou"],
+               "next": f"DenseCRF over {logits_dir}/branch{1 if s1['miou'] > s2['miou'] else 2} (reference: crf_proc, CPU)"})
+    return s1, s2
+
+
+if __name__ == "__main__":
+    main()

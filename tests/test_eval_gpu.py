@@ -165,6 +165,45 @@ def test_msc_seg_inference_and_checkpoint(dev, golden_dir, tmp_path):
         assert abs(s["miou"] - ref) < 2e-3
 
 
+def test_eval_seg_cli_on_a_voc_folder(dev, tmp_path):
+    """`python -m dupl_amd.tools.eval_seg` (tools/eval_seg_voc.py's flags): a VOC-layout folder on disk (JPEGImages /
+    SegmentationClassAug / val.txt / cls_labels_onehot.npy), a reference-format checkpoint; the CLI's scores equal a direct
+    validate() over the same decoded files and the per-image logits are written where the reference's CRF stage reads them."""
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from dupl_amd.datasets import voc
+    from dupl_amd.datasets.device_loader import DeviceValLoader, raw_collate
+    from dupl_amd.tools import eval_seg
+    from dupl_amd.synthetic_val import synthetic_val_samples
+    root, lists, run = tmp_path / "VOC2012", tmp_path / "lists", tmp_path / "run" / "checkpoints"
+    for d in (root / "JPEGImages", root / "SegmentationClassAug", lists, run):
+        d.mkdir(parents=True)
+    names, cls = [], {}
+    for i, (x, lab, c) in enumerate(synthetic_val_samples(sizes=((75, 100), (96, 64), (110, 90), (64, 64)))):
+        nm = f"2007_{i:06d}"
+        img = ((x[0].permute(1, 2, 0).numpy() * 40 + 120).clip(0, 255)).astype(np.uint8)
+        Image.fromarray(img).save(root / "JPEGImages" / (nm + ".jpg"), quality=95)
+        Image.fromarray(lab[0].numpy().astype(np.uint8)).save(root / "SegmentationClassAug" / (nm + ".png"))
+        names.append(nm)
+        cls[nm] = c[0].numpy()
+    (lists / "val.txt").write_text("\n".join(names) + "\n")
+    np.save(lists / "cls_labels_onehot.npy", cls)
+    src, _ = _tiny_model(dev)
+    ckpt = str(run / "checkpoint.pth")
+    torch.save({"module." + k: v.detach().cpu() for k, v in src.state_dict().items()}, ckpt)
+    s1, s2 = eval_seg.main(["--dataset", "voc", "--model_path", ckpt, "--backbone", "tiny_test", "--data_folder", str(root),
+                            "--list_folder", str(lists), "--scales", "(1.0, 1.5, 1.25)"])
+    ds = voc.VOC12SegDataset(root_dir=str(root), name_list_dir=str(lists), split="val", stage="val", aug=False)
+    loader = DeviceValLoader(DataLoader(ds, batch_size=1, shuffle=False, num_workers=0, collate_fn=raw_collate), dev)
+    with torch.no_grad():
+        d1, d2 = eval_seg.validate(src, loader, types.SimpleNamespace(scales=(1.0, 1.5, 1.25)), num_classes=21)
+    assert s1["miou"] == d1["miou"] and s2["miou"] == d2["miou"] and 0.0 <= s1["miou"] <= 1.0
+    for b in ("branch1", "branch2"):
+        for nm, (x, lab, _) in zip(names, synthetic_val_samples(sizes=((75, 100), (96, 64), (110, 90), (64, 64)))):
+            z = np.load(tmp_path / "run" / "segs" / "logits" / "val" / b / (nm + ".npy"), allow_pickle=True).item()["msc_seg"]
+            assert z.shape == (1, 21) + tuple(lab.shape[1:]) and np.isfinite(z).all()
+
+
 def test_coco_style_msc_inference(dev, golden_dir):
     """tools/eval_seg_coco_ddp.py:76-125 (resize to a square, sum over scales at logit size, up-sample the sum) vs the
     reference composition in val_tiny.npz; 21-class tiny model, the ConfusionMatrix path of validate_coco."""
