@@ -55,6 +55,49 @@ def test_resume_continues_an_interrupted_run_bit_exactly(dev, tmp_path):
     assert any(not torch.equal(sa[k], first[k]) for k in sa)             # it did train after the resume
 
 
+def _fake_voc(tmp_path, n_train=5, n_val=3):
+    """A VOC2012-layout folder with synthetic JPEGs / label PNGs, the two split lists and cls_labels_onehot.npy."""
+    import numpy as np
+    from PIL import Image
+    from oracle.gen_golden_loader import synth_image
+    root, lists = tmp_path / "VOC2012", tmp_path / "lists"
+    for d in (root / "JPEGImages", root / "SegmentationClassAug", lists):
+        d.mkdir(parents=True)
+    cls, splits = {}, {"train_aug": [], "val": []}
+    sizes = [(120, 160), (150, 110), (96, 96), (140, 200), (175, 125), (100, 130), (128, 128), (90, 140)]
+    for i in range(n_train + n_val):
+        nm = f"2008_{i:06d}"
+        h, w = sizes[i % len(sizes)]
+        Image.fromarray(synth_image(h, w, 200 + i)).save(root / "JPEGImages" / (nm + ".jpg"), quality=92)
+        lab = np.zeros((h, w), np.uint8)
+        c1, c2 = 1 + (3 * i) % 20, 1 + (7 * i + 5) % 20
+        lab[h // 4: h // 2, w // 4: w // 2] = c1
+        lab[h // 2: 3 * h // 4, w // 2: 7 * w // 8] = c2
+        lab[:3] = 255
+        Image.fromarray(lab).save(root / "SegmentationClassAug" / (nm + ".png"))
+        one = np.zeros(20, np.float32)
+        one[[c1 - 1, c2 - 1]] = 1.0
+        cls[nm] = one
+        splits["train_aug" if i < n_train else "val"].append(nm)
+    for k, v in splits.items():
+        (lists / (k + ".txt")).write_text("\n".join(v) + "\n")
+    np.save(lists / "cls_labels_onehot.npy", cls)
+    return str(root), str(lists)
+
+
+def test_train_final_voc_on_a_dataset_folder(dev, tmp_path):
+    """The launcher against a VOC-layout folder on disk: datasets.voc.VOC12ClsDataset in DataLoader workers (JPEG decode +
+    the geometry / photometric draws), DistributedSampler + epoch restarts (5 images, 2 per step -> 2 steps per epoch, 7
+    iterations), the device transform, phases A -> B, checkpoint and in-loop validation over the folder's val split."""
+    root, lists = _fake_voc(tmp_path)
+    out = _run("train_final_voc.py", ["--data_folder", root, "--list_folder", lists, "--num_workers", "2", "--cam_iters", "3",
+                                      "--gmm_iters", "100", "--max_iters", "7", "--warmup_iters", "2", "--log_iters", "1",
+                                      "--eval_iters", "7", "--work_dir", str(tmp_path / "work")], 29651)
+    assert "Iter: 7;" in out and "val cls score" in out and "mIoU" in out
+    ckpts = [os.path.join(d, f) for d, _, fs in os.walk(tmp_path / "work") for f in fs if f == "checkpoint.pth"]
+    assert len(ckpts) == 1
+
+
 def test_train_final_coco_script_runs(dev):
     out = _run("train_final_coco.py", ["--cam_iters", "2", "--gmm_iters", "1000", "--max_iters", "4", "--warmup_iters", "2",
                                        "--num_classes", "81"], 29612)
