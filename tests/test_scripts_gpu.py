@@ -104,6 +104,43 @@ def test_train_final_coco_script_runs(dev):
     assert "Iter: 4;" in out
 
 
+def test_train_final_coco_on_a_dataset_folder(dev, tmp_path):
+    """train_final_coco.py against an MSCOCO-layout tree (<img>/{train2014,val2014}, <labels>/{train2014,val2014}, train.txt /
+    val_part.txt, 80-class cls_labels_onehot.npy, one grey-scale JPEG): CocoClsDataset / CocoSegDataset through workers, the
+    COCO schedule, validate_siamase_coco over the folder's val split."""
+    import numpy as np
+    from PIL import Image
+    from oracle.gen_golden_loader import synth_image
+    img, lab, lists = tmp_path / "coco" / "JPEGImages", tmp_path / "coco" / "SegmentationClass", tmp_path / "lists"
+    for d in (img / "train2014", img / "val2014", lab / "train2014", lab / "val2014", lists):
+        d.mkdir(parents=True)
+    cls, splits = {}, {"train": [], "val_part": []}
+    for i in range(7):
+        sub, split = ("train2014", "train") if i < 5 else ("val2014", "val_part")
+        nm = f"COCO_{sub}_{i:012d}"
+        h, w = [(120, 160), (150, 110), (96, 128)][i % 3]
+        im = synth_image(h, w, 300 + i)
+        pil = Image.fromarray(im).convert("L") if i == 1 else Image.fromarray(im)       # coco.py:24-28: grey JPEGs occur
+        pil.save(img / sub / (nm + ".jpg"), quality=92)
+        m = np.zeros((h, w), np.uint8)
+        c1, c2 = 1 + (11 * i) % 80, 1 + (29 * i + 3) % 80
+        m[h // 4: h // 2, w // 4: w // 2] = c1
+        m[h // 2: 3 * h // 4, w // 2: 7 * w // 8] = c2
+        Image.fromarray(m).save(lab / sub / (nm + ".png"))
+        one = np.zeros(80, np.float32)
+        one[[c1 - 1, c2 - 1]] = 1.0
+        cls[nm] = one
+        splits[split].append(nm)
+    for k, v in splits.items():
+        (lists / (k + ".txt")).write_text("\n".join(v) + "\n")
+    np.save(lists / "cls_labels_onehot.npy", cls)
+    out = _run("train_final_coco.py", ["--img_folder", str(img), "--label_folder", str(lab), "--list_folder", str(lists),
+                                       "--num_workers", "2", "--num_classes", "81", "--cam_iters", "2", "--gmm_iters", "100",
+                                       "--max_iters", "5", "--warmup_iters", "2", "--log_iters", "1", "--eval_iters", "5",
+                                       "--work_dir", str(tmp_path / "work")], 29652)
+    assert "Iter: 5;" in out and "val cls score" in out and "mIoU" in out
+
+
 def test_ddp_exchange_on_gpu_world1(dev):
     """RCCL all-reduce path (forced at world 1) gives the same gradients as the plain step; exercises the post-backward
     hooks, the autograd-engine finalise callback and the stream ordering with two student streams."""
