@@ -1,12 +1,11 @@
+"""Throughput of the device-side train transform (datasets/device_loader.py): gpurun -- python tools/loader_bench.py"""
 import sys, os, time, random, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dupl_amd.datasets.transforms import draw_geometry, draw_train_views
 from dupl_amd.datasets.device_loader import DeviceTransform
-from oracle.gen_golden_loader import synth_image
-from oracle import dupl_oracle as O
 dev = torch.device("cuda:0")
 tf = DeviceTransform(dev)
-imgs = [torch.from_numpy(synth_image(375, 500, i)) for i in range(8)]
+imgs = [torch.from_numpy(np.random.RandomState(i).randint(0, 256, size=(375, 500, 3)).astype(np.uint8)) for i in range(8)]
 random.seed(0); np.random.seed(0); torch.manual_seed(0)
 geos = []
 for i in range(64):
@@ -22,10 +21,3 @@ for photo in (False, True):
             g.photometric = p
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"device train transform, 375x500 -> 448^2, photometric={photo}: {64 / dt:.0f} img/s ({dt / 64 * 1e3:.2f} ms/img incl. H2D of the raw image)")
-# the reference's CPU chain (PIL) for the same items, one process
-random.seed(0); np.random.seed(0); torch.manual_seed(0)
-t0 = time.perf_counter()
-for i in range(16):
-    O.loader_train_item_photometric(imgs[i % 8].numpy(), (0.5, 2.0), 448)
-dt = time.perf_counter() - t0
-print(f"oracle / PIL chain on one host core: {16 / dt:.1f} img/s ({dt / 16 * 1e3:.1f} ms/img)")
