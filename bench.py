@@ -176,7 +176,7 @@ def csrc_digest() -> str:
     return source_digest()
 
 
-def pmc_traffic_per_launch(path, kernel_prefix="gemm_f32_kernel<false, false"):
+def pmc_traffic_per_launch(path, kernel_prefix="gemm_f32_kernel<false, false", gemm_mode=None):
     """HBM-side bytes per launch of the dominant kernel from a PMC summary written by tools/profile_round.sh (separate
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same workload, tools/rocpd_pmc.py).  FETCH_SIZE is
     doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md 'HBM'); it counts L2->fabric requests, i.e.
@@ -196,6 +196,9 @@ def pmc_traffic_per_launch(path, kernel_prefix="gemm_f32_kernel<false, false"):
     if tag.get("csrc_sha256") != have:
         return None, (f"{path} is stale or untagged (its csrc_sha256 {tag.get('csrc_sha256', 'missing')[:12]} != "
                       f"{have[:12]} of this build): re-run tools/profile_round.sh")
+    if gemm_mode is not None and tag.get("gemm_mode", "f16x3") != gemm_mode:
+        return None, (f"{path} was measured in {tag.get('gemm_mode', 'f16x3')} mode, this run is in {gemm_mode} mode: its per-kernel "
+                      "traffic belongs to another launch mix")
     calls = fetch_kib = write_kib = 0.0
     for line in lines:
         if line.startswith(kernel_prefix):      # every column-tile instantiation of the NT kernel
@@ -407,7 +410,7 @@ def main():
             peak, kname, prefix = PEAK_F16_MFMA / 3.0, KERNEL_F16X3, "gemm_f16x3_kernel"
         else:
             peak, kname, prefix = PEAK_F32_MFMA, KERNEL_F32, "gemm_f32_kernel<false, false"
-        traffic, tnote = pmc_traffic_per_launch(args.pmc_profile, prefix) if (dataset, batch) == ("voc", 4) else \
+        traffic, tnote = pmc_traffic_per_launch(args.pmc_profile, prefix, gemm_mode) if (dataset, batch) == ("voc", 4) else \
             (None, "the committed PMC passes are of the VOC 4 img/GPU workload")
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach / 1e12, 2),
                 "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
