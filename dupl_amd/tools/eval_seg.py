@@ -120,22 +120,28 @@ def validate(model, data_loader, args, num_classes=21, cat_list=None, keep_logit
     return sc[0], sc[1]
 
 
-def build_parser():
-    """The flags of tools/eval_seg_voc.py:26-36 / tools/eval_seg_coco_ddp.py:31-46 (same names and defaults) + --dataset."""
+def build_parser(dataset: str = "voc"):
+    """The flags of tools/eval_seg_voc.py:26-36 (dataset "voc") or tools/eval_seg_coco_ddp.py:31-46 ("coco"): same names and
+    defaults (tests/golden/cli_flags.json), plus --dataset and --save_logits."""
     import argparse
+    voc_ = dataset == "voc"
     p = argparse.ArgumentParser()
-    p.add_argument("--dataset", default="voc", choices=("voc", "coco"))
-    p.add_argument("--infer_set", default="val", type=str)
+    p.add_argument("--dataset", default=dataset, choices=("voc", "coco"))
+    p.add_argument("--infer_set", default="val" if voc_ else "val_part", type=str)
     p.add_argument("--pooling", default="gmp", type=str)
     p.add_argument("--model_path", default="your_model_dir/checkpoints.pth", type=str)
-    p.add_argument("--backbone", default="deit_base_patch16_224", type=str)
-    p.add_argument("--data_folder", default="your_voc_dir", type=str, help="VOC: dataset folder")
-    p.add_argument("--img_folder", default="your_coco_dir/JPEGImages", type=str, help="COCO: image folder")
-    p.add_argument("--label_folder", default="your_coco_dir/SegmentationClass", type=str, help="COCO: label folder")
-    p.add_argument("--list_folder", default=None, type=str)
-    p.add_argument("--num_classes", default=None, type=int)
+    p.add_argument("--backbone", default="deit_base_patch16_224" if voc_ else "vit_base_patch16_224", type=str)
+    if voc_:
+        p.add_argument("--data_folder", default="your_voc_dir", type=str, help="dataset folder")
+    else:
+        p.add_argument("--img_folder", default="your_coco_dir", type=str, help="image folder")
+        p.add_argument("--label_folder", default="your_coco_seg_dir", type=str, help="label folder")
+        p.add_argument("--backend", default="nccl")
+        p.add_argument("--crop_size", default=448, type=int)
+    p.add_argument("--list_folder", default="datasets/voc" if voc_ else "datasets/coco", type=str)
+    p.add_argument("--num_classes", default=21 if voc_ else 81, type=int)
     p.add_argument("--ignore_index", default=255, type=int)
-    p.add_argument("--scales", default=None, help="multi-scale list; default (1.0, 1.5, 1.25) VOC / (1.0, 1.25, 1.5) COCO")
+    p.add_argument("--scales", default=[1.0, 1.5, 1.25] if voc_ else [1.0, 1.25, 1.5], help="multi-scale list")
     p.add_argument("--save_logits", default=1, type=int,
                    help="write <run>/segs/logits/<infer_set>/branch{1,2}/<name>.npy = {'msc_seg': ...} like the reference does for "
                         "its DenseCRF stage (utils/dcrf.py, CPU, outside this package)")
@@ -154,19 +160,20 @@ def main(argv=None):
     from ..datasets import voc, coco
     from ..datasets.device_loader import DeviceValLoader, raw_collate
     from ..model.model_dupl import siamese_network
-    args = build_parser().parse_args(argv)
-    is_voc = args.dataset == "voc"
-    args.num_classes = args.num_classes or (21 if is_voc else 81)
-    args.list_folder = args.list_folder or ("datasets/voc" if is_voc else "datasets/coco")
+    import argparse
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--dataset", default="voc", choices=("voc", "coco"))
+    is_voc = pre.parse_known_args(argv)[0].dataset == "voc"
+    args = build_parser("voc" if is_voc else "coco").parse_args(argv)
     if isinstance(args.scales, str):
-        args.scales = tuple(float(v) for v in args.scales.strip("()[] ").split(","))
-    args.scales = args.scales or ((1.0, 1.5, 1.25) if is_voc else (1.0, 1.25, 1.5))
+        args.scales = [float(v) for v in args.scales.strip("()[] ").split(",")]
+    args.scales = tuple(args.scales)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl")
+        dist.init_process_group(getattr(args, "backend", "nccl"))
     if is_voc:
         ds = voc.VOC12SegDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.infer_set, stage="val",
                                  aug=False, ignore_index=args.ignore_index, num_classes=args.num_classes)

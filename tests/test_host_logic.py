@@ -236,3 +236,27 @@ def test_vit21k_flat_checkpoint_and_strictness(tmp_path):
         network("tiny_test", num_classes=21, pretrained=str(tmp_path / "prefixed.pth"), aux_layer=-3)
     with pytest.raises(RuntimeError):
         m.branch1.to("cpu")
+
+
+def test_command_line_flags_match_the_reference(golden_dir):
+    """the launchers keep the reference's argparse surface.  tests/golden/cli_flags.json holds every add_argument
+    of train_final_voc.py / train_final_coco.py / tools/eval_seg_voc.py / tools/eval_seg_coco_ddp.py (read with ast,
+    oracle/gen_golden_cli.py): each flag exists here with the same default -- except --pretrained (no URL download in this
+    build: a local checkpoint path or False)."""
+    import json
+    from dupl_amd import train_main
+    from dupl_amd.tools import eval_seg
+    g = json.load(open(os.path.join(golden_dir, "cli_flags.json")))
+    parsers = {"train_final_voc.py": train_main.build_parser("voc"), "train_final_coco.py": train_main.build_parser("coco"),
+               "tools/eval_seg_voc.py": eval_seg.build_parser("voc"), "tools/eval_seg_coco_ddp.py": eval_seg.build_parser("coco")}
+    n = 0
+    for script, parser in parsers.items():
+        mine = {a.option_strings[0]: a for a in parser._actions if a.option_strings and a.option_strings[0] != "-h"}
+        for name, rec in g[script].items():
+            assert name in mine, (script, name)
+            if "default" in rec and name != "--pretrained":
+                d = mine[name].default
+                assert (list(d) == list(rec["default"])) if isinstance(rec["default"], (list, tuple)) else (d == rec["default"]), \
+                    (script, name, d, rec["default"])
+            n += 1
+    assert n >= 95
