@@ -141,9 +141,11 @@ __global__ void cam_to_label_kernel(const float* __restrict__ cam, const float* 
 }
 
 // denormalize_img2: IEEE mul then add (NO fma contraction: the uint8 truncation makes 1-ulp differences visible)
-__global__ void denormalize_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int HW) {
-    const float mean[3] = {123.675f, 116.28f, 103.53f};
-    const float stdv[3] = {58.395f, 57.12f, 57.375f};
+struct MeanStd { float mean[3], stdv[3]; };
+
+__global__ void denormalize_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int HW, const MeanStd ms) {
+    const float* mean = ms.mean;
+    const float* stdv = ms.stdv;
     const long total = (long)B * 3 * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i / HW) % 3);
@@ -221,9 +223,12 @@ extern "C" int dupl_cam_to_label(const float* cam, const float* cls_label, const
     return dupl_launch_status();
 }
 
-extern "C" int dupl_denormalize_img(const float* x, float* out, int32_t B, int32_t HW, dupl_stream_t s) {
+extern "C" int dupl_denormalize_img(const float* x, float* out, int32_t B, int32_t HW, const float* mean_std, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !out || B <= 0 || HW <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(denormalize_kernel, dim3(ew_grid((long)B * 3 * HW)), dim3(256), 0, (hipStream_t)s, x, out, B, HW);
+    MeanStd ms = {{123.675f, 116.28f, 103.53f}, {58.395f, 57.12f, 57.375f}};     // imutils.py:17 defaults
+    if (mean_std)
+        for (int c = 0; c < 3; ++c) { ms.mean[c] = mean_std[c]; ms.stdv[c] = mean_std[3 + c]; }
+    hipLaunchKernelGGL(denormalize_kernel, dim3(ew_grid((long)B * 3 * HW)), dim3(256), 0, (hipStream_t)s, x, out, B, HW, ms);
     return dupl_launch_status();
 }

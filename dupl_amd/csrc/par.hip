@@ -115,17 +115,22 @@ __global__ __launch_bounds__(256) void par_propagate_kernel(const float* __restr
 __global__ __launch_bounds__(256) void refine_pre_kernel(const float* __restrict__ cams, const float* __restrict__ thr_map,
                                                          const float* __restrict__ thr, const int* __restrict__ job_img,
                                                          const int* __restrict__ job_K, const int* __restrict__ keys, int Kmax,
-                                                         float* __restrict__ masks, int C, int H, int W) {
+                                                         float* __restrict__ masks, int C, int H, int W, int h, int w) {
     const int job = blockIdx.y;
     const int K = job_K[job], b = job_img[job];
-    const int h = H / 2, w = W / 2, hw = h * w;
+    const int hw = h * w;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hw) return;
     const int y = p / w, x = p - y * w;
-    const long o00 = (long)(2 * y) * W + 2 * x;
+    // F.interpolate(size=[H // down_scale, W // down_scale], bilinear, align_corners=False): 4 taps around
+    // src = (in / out) (dst + 0.5) - 0.5 (clamped at 0); down_scale = 2 gives taps 2y, 2y + 1 with weights 0.5 / 0.5
+    const float ry = fmaxf(((float)H / (float)h) * (y + 0.5f) - 0.5f, 0.f), rx = fmaxf(((float)W / (float)w) * (x + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)ry, x0 = (int)rx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = ry - y0, lx = rx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const long o00 = (long)y0 * W + x0, o01 = (long)y0 * W + x1, o10 = (long)y1 * W + x0, o11 = (long)y1 * W + x1;
     auto down = [&](const float* pl) {
-        const float a = pl[o00], bb = pl[o00 + 1], c = pl[o00 + W], d = pl[o00 + W + 1];
-        return 0.5f * (0.5f * a + 0.5f * bb) + 0.5f * (0.5f * c + 0.5f * d);
+        return hy * (hx * pl[o00] + lx * pl[o01]) + ly * (hx * pl[o10] + lx * pl[o11]);
     };
     const int* kj = keys + job * Kmax;
     float mx = -INFINITY;
@@ -143,21 +148,20 @@ __global__ __launch_bounds__(256) void refine_pre_kernel(const float* __restrict
     for (int k = 0; k < K; ++k) out[(long)k * hw] /= sum;
 }
 
-// refine post: masks (K,h,w) -> bilinear x2 (align_corners False) -> first argmax -> keys -> box paste (float labels)
+// refine post: masks (K,h,w) -> bilinear up to (H,W) (align_corners False) -> first argmax -> keys -> box paste (float labels)
 __global__ __launch_bounds__(256) void refine_post_kernel(const float* __restrict__ masks, const int* __restrict__ job_img,
                                                           const int* __restrict__ job_K, const int* __restrict__ keys, int Kmax,
                                                           const int* __restrict__ box, float ignore, float* __restrict__ label,
-                                                          int h, int w) {
+                                                          int h, int w, int H, int W) {
     const int job = blockIdx.y;
     const int K = job_K[job], b = job_img[job];
-    const int H = 2 * h, W = 2 * w;
     const int P = blockIdx.x * blockDim.x + threadIdx.x;
     if (P >= H * W) return;
     const int Y = P / W, X = P - Y * W;
     float* out = label + (long)job * H * W + P;
     const int y0b = box[4 * b], y1b = box[4 * b + 1], x0b = box[4 * b + 2], x1b = box[4 * b + 3];
     if (!(Y >= y0b && Y < y1b && X >= x0b && X < x1b)) { *out = ignore; return; }
-    const float ry = fmaxf(0.5f * (Y + 0.5f) - 0.5f, 0.f), rx = fmaxf(0.5f * (X + 0.5f) - 0.5f, 0.f);
+    const float ry = fmaxf(((float)h / (float)H) * (Y + 0.5f) - 0.5f, 0.f), rx = fmaxf(((float)w / (float)W) * (X + 0.5f) - 0.5f, 0.f);
     const int y0 = (int)ry, x0 = (int)rx;
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
     const float ly = ry - y0, lx = rx - x0, hy = 1.f - ly, hx = 1.f - lx;
@@ -209,22 +213,24 @@ extern "C" int dupl_par_propagate(const float* aff, const float* in, float* out,
 
 extern "C" int dupl_refine_pre(const float* cams, const float* thr_map, const float* thr, const int32_t* job_img,
                                const int32_t* job_K, const int32_t* keys, int32_t njobs, int32_t Kmax, float* masks, int32_t C,
-                               int32_t H, int32_t W, dupl_stream_t s) {
+                               int32_t H, int32_t W, int32_t h, int32_t w, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
-    if (!cams || (!thr_map && !thr) || !job_img || !job_K || !keys || !masks || njobs <= 0 || Kmax <= 0 || (H & 1) || (W & 1))
+    if (!cams || (!thr_map && !thr) || !job_img || !job_K || !keys || !masks || njobs <= 0 || Kmax <= 0 || h <= 0 || w <= 0 ||
+        h > H || w > W)
         return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(refine_pre_kernel, dim3(((H / 2) * (W / 2) + 255) / 256, njobs), dim3(256), 0, (hipStream_t)s, cams,
-                       thr_map, thr, job_img, job_K, keys, Kmax, masks, C, H, W);
+    hipLaunchKernelGGL(refine_pre_kernel, dim3((h * w + 255) / 256, njobs), dim3(256), 0, (hipStream_t)s, cams,
+                       thr_map, thr, job_img, job_K, keys, Kmax, masks, C, H, W, h, w);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_refine_post(const float* masks, const int32_t* job_img, const int32_t* job_K, const int32_t* keys,
                                 int32_t njobs, int32_t Kmax, const int32_t* box, float ignore_index, float* label, int32_t h,
-                                int32_t w, dupl_stream_t s) {
+                                int32_t w, int32_t H, int32_t W, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
-    if (!masks || !job_img || !job_K || !keys || !box || !label || njobs <= 0 || Kmax <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(refine_post_kernel, dim3((4 * h * w + 255) / 256, njobs), dim3(256), 0, (hipStream_t)s, masks, job_img,
-                       job_K, keys, Kmax, box, ignore_index, label, h, w);
+    if (!masks || !job_img || !job_K || !keys || !box || !label || njobs <= 0 || Kmax <= 0 || h <= 0 || w <= 0 || H < h || W < w)
+        return DUPL_ERR_ARG;
+    hipLaunchKernelGGL(refine_post_kernel, dim3((int)(((long)H * W + 255) / 256), njobs), dim3(256), 0, (hipStream_t)s, masks,
+                       job_img, job_K, keys, Kmax, box, ignore_index, label, h, w, H, W);
     return dupl_launch_status();
 }
 

@@ -428,12 +428,18 @@ def cam_to_label(cam: Tensor, cls_label: Tensor, img_box: Optional[Tensor], high
     return valid, label
 
 
-def denormalize_img(x: Tensor) -> Tensor:
+def denormalize_img(x: Tensor, mean=None, std=None) -> Tensor:
     B, C, H, W = x.shape
     assert C == 3
     x = _chk(x.contiguous())
     out = torch.empty_like(x)
-    L().dupl_denormalize_img(x.data_ptr(), out.data_ptr(), B, H * W, _stream())
+    ms = None
+    if mean is not None or std is not None:
+        m = list(mean) if mean is not None else [123.675, 116.28, 103.53]
+        sd = list(std) if std is not None else [58.395, 57.12, 57.375]
+        assert len(m) == 3 and len(sd) == 3
+        ms = (ctypes.c_float * 6)(*m, *sd)
+    L().dupl_denormalize_img(x.data_ptr(), out.data_ptr(), B, H * W, ms, _stream())
     return out
 
 
@@ -474,21 +480,25 @@ def par_propagate(aff: Tensor, masks: Tensor, job_img: Tensor, job_K: Tensor, di
     return a
 
 
-def refine_pre(cams: Tensor, thr_map: Optional[Tensor], thr: Optional[Tensor], job_img: Tensor, job_K: Tensor, keys: Tensor) -> Tensor:
+def refine_pre(cams: Tensor, thr_map: Optional[Tensor], thr: Optional[Tensor], job_img: Tensor, job_K: Tensor, keys: Tensor,
+               down_scale: int = 2) -> Tensor:
     b, C, H, W = cams.shape
     _chk(cams)
     njobs, Kmax = keys.shape
-    masks = zeros((njobs, Kmax, H // 2, W // 2), cams.device)
+    h, w = H // down_scale, W // down_scale
+    masks = zeros((njobs, Kmax, h, w), cams.device)
     L().dupl_refine_pre(cams.data_ptr(), _p(thr_map), _p(thr), job_img.data_ptr(), job_K.data_ptr(), keys.data_ptr(), njobs, Kmax,
-                        masks.data_ptr(), C, H, W, _stream())
+                        masks.data_ptr(), C, H, W, h, w, _stream())
     return masks
 
 
-def refine_post(masks: Tensor, job_img: Tensor, job_K: Tensor, keys: Tensor, box: Tensor, ignore_index: float) -> Tensor:
+def refine_post(masks: Tensor, job_img: Tensor, job_K: Tensor, keys: Tensor, box: Tensor, ignore_index: float,
+                out_size=None) -> Tensor:
     njobs, Kmax, h, w = masks.shape
-    label = torch.empty((njobs, 2 * h, 2 * w), device=masks.device, dtype=torch.float32)
+    H, W = out_size if out_size is not None else (2 * h, 2 * w)
+    label = torch.empty((njobs, H, W), device=masks.device, dtype=torch.float32)
     L().dupl_refine_post(masks.data_ptr(), job_img.data_ptr(), job_K.data_ptr(), keys.data_ptr(), njobs, Kmax, box.data_ptr(),
-                         float(ignore_index), label.data_ptr(), h, w, _stream())
+                         float(ignore_index), label.data_ptr(), h, w, H, W, _stream())
     return label
 
 

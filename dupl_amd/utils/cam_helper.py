@@ -127,8 +127,8 @@ def _refine(ref_mod, images, cams, cls_labels, thr_scalar: Optional[float], thr_
     """Shared body of refine_cams_with_bkg_v2 / refine_cams_with_dynamic_thres (cam_helper.py:338-431).
     Jobs: for every image, one PAR run with the high threshold and one with the low threshold; the colour affinity
     is built once per image and shared (the reference rebuilds it per run)."""
-    if down_scale != 2:
-        raise NotImplementedError("the HIP refine kernels implement the reference's down_scale=2")
+    down_scale = int(down_scale)
+    assert down_scale >= 1
     images = images.contiguous().float()
     cams = cams.contiguous().float()
     dev = cams.device
@@ -152,18 +152,18 @@ def _refine(ref_mod, images, cams, cls_labels, thr_scalar: Optional[float], thr_
     tab_d = ops.to_device_async(tab, torch.int32, dev)
     job_img, job_K, keys = tab_d[:njobs], tab_d[njobs:2 * njobs], tab_d[2 * njobs:].view(njobs, Kmax)
     box = _box_i32(img_box, dev)
-    half = ops.resize_bilinear(images, H // 2, W // 2)
+    half = ops.resize_bilinear(images, H // down_scale, W // down_scale)
     aff = ref_mod.affinity(half)
     thr_low = torch.full((b,), float(low_thre), device=dev, dtype=torch.float32)
     if thr_map is not None:
-        m_h = ops.refine_pre(cams, thr_map.to(dev).contiguous().float(), None, job_img[:b], job_K[:b], keys[:b])
+        m_h = ops.refine_pre(cams, thr_map.to(dev).contiguous().float(), None, job_img[:b], job_K[:b], keys[:b], down_scale)
     else:
         thr_hi = torch.full((b,), float(thr_scalar), device=dev, dtype=torch.float32)
-        m_h = ops.refine_pre(cams, None, thr_hi, job_img[:b], job_K[:b], keys[:b])
-    m_l = ops.refine_pre(cams, None, thr_low, job_img[b:], job_K[b:], keys[b:])
+        m_h = ops.refine_pre(cams, None, thr_hi, job_img[:b], job_K[:b], keys[:b], down_scale)
+    m_l = ops.refine_pre(cams, None, thr_low, job_img[b:], job_K[b:], keys[b:], down_scale)
     masks = torch.cat([m_h, m_l], dim=0)
     masks = ref_mod.propagate(aff, masks, job_img, job_K)
-    lab = ops.refine_post(masks, job_img, job_K, keys, box, float(ignore_index))
+    lab = ops.refine_post(masks, job_img, job_K, keys, box, float(ignore_index), out_size=(H, W))
     return ops.refine_merge(lab[:b].contiguous(), lab[b:].contiguous(), float(ignore_index))
 
 

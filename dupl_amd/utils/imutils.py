@@ -13,9 +13,7 @@ AUGMENT_LIST = (("AutoContrast", 0, 1), ("Equalize", 0, 1), ("Posterize", 0, 6),
 
 def denormalize_img(imgs=None, mean=None, std=None):
     """(x*std+mean) -> uint8 truncation (returned as a uint8 tensor like the reference)."""
-    if mean is not None or std is not None:
-        raise NotImplementedError("the HIP kernel bakes in the reference's default ImageNet mean/std")
-    return (ops.denormalize_img(imgs.contiguous().float()) * 255.0).round().to(imgs.device).byte()
+    return (ops.denormalize_img(imgs.contiguous().float(), mean, std) * 255.0).round().to(imgs.device).byte()
 
 
 def denormalize_img2(imgs=None):

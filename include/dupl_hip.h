@@ -205,8 +205,9 @@ int dupl_cam_minmax_normalise(float* cam, float* mm, int32_t planes, int32_t HW,
 int dupl_cam_to_label(const float* cam, const float* cls_label, const int32_t* img_box, const float* high_thre,
                       float bkg_thre, float low_thre, int32_t ignore_mid, int32_t ignore_index,
                       int64_t* label, float* valid_cam, int32_t b, int32_t C, int32_t h, int32_t w, dupl_stream_t s);
-/* denormalize_img2 (imutils.py:17-31): out = float(uint8_trunc(x*std+mean))/255, IEEE mul+add (no fma) */
-int dupl_denormalize_img(const float* x, float* out, int32_t B, int32_t HW, dupl_stream_t s);
+/* denormalize_img / denormalize_img2 (imutils.py:17-31): out = float(uint8_trunc(x*std+mean))/255, IEEE mul+add (no fma);
+ * mean_std: HOST pointer to {mean[3], std[3]} or NULL for the reference's defaults (ImageNet, 0-255 scale) */
+int dupl_denormalize_img(const float* x, float* out, int32_t B, int32_t HW, const float* mean_std, dupl_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * PAR (model/PAR.py:26-91) and the refine wrappers (cam_helper.py:338-440).
@@ -220,17 +221,18 @@ int dupl_par_affinity(const float* imgs, float* aff, const int32_t* dilations, i
 int dupl_par_propagate(const float* aff, const float* in, float* out, const int32_t* job_img, const int32_t* job_K,
                        const int32_t* dilations, int32_t ndil, int32_t njobs, int32_t Kmax, int32_t h, int32_t w,
                        dupl_stream_t s);
-/* refine pre (cam_helper.py:358-367,406-415): per job, channel 0 = background threshold (thr[j], or the 2x-downsampled
+/* refine pre (cam_helper.py:358-367,406-415): per job, channel 0 = background threshold (thr[j], or the down-sampled
  * thr_map[img] (b,1,H,W) when non-NULL), channel k>0 = cams[img][keys[j][k]-1] (cams (b,C,H,W) already multiplied by the
- * image labels); bilinear /2; softmax over the K channels -> masks [njobs][Kmax][H/2][W/2]. keys DEVICE [njobs][Kmax]. */
+ * image labels); bilinear (H,W) -> (h,w) = (H // down_scale, W // down_scale), align_corners False; softmax over the K
+ * channels -> masks [njobs][Kmax][h][w]. keys DEVICE [njobs][Kmax]. */
 int dupl_refine_pre(const float* cams, const float* thr_map, const float* thr, const int32_t* job_img,
                     const int32_t* job_K, const int32_t* keys, int32_t njobs, int32_t Kmax, float* masks, int32_t C,
-                    int32_t H, int32_t W, dupl_stream_t s);
-/* refine post (cam_helper.py:434-440 + box paste :376-379): bilinear x2 -> first argmax -> keys -> float label
- * [njobs][2h][2w], ignore_index outside box[job_img[j]] (box DEVICE (b,4) int32). */
+                    int32_t H, int32_t W, int32_t h, int32_t w, dupl_stream_t s);
+/* refine post (cam_helper.py:434-440 + box paste :376-379): bilinear (h,w) -> (H,W) -> first argmax -> keys -> float label
+ * [njobs][H][W], ignore_index outside box[job_img[j]] (box DEVICE (b,4) int32). */
 int dupl_refine_post(const float* masks, const int32_t* job_img, const int32_t* job_K, const int32_t* keys,
                      int32_t njobs, int32_t Kmax, const int32_t* box, float ignore_index, float* label, int32_t h,
-                     int32_t w, dupl_stream_t s);
+                     int32_t w, int32_t H, int32_t W, dupl_stream_t s);
 /* merge (cam_helper.py:381-383): out = lab_h; out[lab_h==0] = ignore; out[lab_h+lab_l==0] = 0 */
 int dupl_refine_merge(const float* lab_h, const float* lab_l, float* out, float ignore_index, int64_t n, dupl_stream_t s);
 

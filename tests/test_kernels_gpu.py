@@ -294,6 +294,43 @@ def test_par_and_refine(dev, golden_dir):
     assert np.abs(outm.cpu().numpy()[:, :, ::2, ::2] - gold["out_sub"]).max() < 2e-5
 
 
+@pytest.mark.parametrize("S,down_scale", [(224, 4), (224, 1), (210, 4), (160, 3)])
+def test_refine_other_down_scales_and_denormalize_with_custom_stats(dev, S, down_scale):
+    """The two boundary parameters the training scripts leave at their defaults: refine_cams_*(down_scale=...) (any integer,
+    sizes that are not multiples of it: bilinear (H,W) -> (H // ds, W // ds) -> PAR -> back to (H,W), cam_helper.py:338-440)
+    against the oracle with the tie-margin proof, and denormalize_img(mean, std) (imutils.py:17-25) bit-exact."""
+    from dupl_amd.utils.cam_helper import refine_cams_with_dynamic_thres, refine_cams_with_bkg_v2
+    from dupl_amd.utils import imutils
+    from dupl_amd.model.PAR import PAR
+    from oracle import dupl_oracle as O
+    from parity_util import assert_labels_equal_up_to_ties
+    b, C = 2, 20
+    inputs, cls_label, img_box = O.synthetic_batch(b, C, S, seed=40 + S + down_scale)
+    img_dn = O.denormalize_img2(inputs.clone())
+    cams = O.synthetic_cams(b, C, S, S, seed=8 + down_scale)
+    rep = cls_label[:, :, None, None]
+    par = PAR(num_iter=10, dilations=list(O.PAR_DILATIONS)).to(dev)
+    r_v2 = refine_cams_with_bkg_v2(par, img_dn.to(dev), cams=(cams * rep).to(dev), cls_labels=cls_label.to(dev), high_thre=0.65,
+                                   low_thre=0.25, ignore_index=255, img_box=img_box, down_scale=down_scale)
+    o_v2, m_v2 = O.refine_cams(img_dn, cams * rep, cls_label, 0.65, 0.25, 255, img_box, down_scale=down_scale, return_margin=True)
+    assert tuple(r_v2.shape) == (b, S, S)
+    assert_labels_equal_up_to_ties(r_v2, o_v2.numpy().astype(np.int64), m_v2, f"refine v2, down_scale {down_scale}, {S}^2")
+    hm = torch.stack([torch.ones(S, S) * 0.62, torch.ones(S, S) * 0.68]).unsqueeze(1)
+    r_dyn = refine_cams_with_dynamic_thres(par, img_dn.to(dev), cams=(cams * rep).to(dev), cls_labels=cls_label.to(dev),
+                                           high_thre_map=hm.to(dev), low_thre=0.25, ignore_index=255, img_box=img_box,
+                                           down_scale=down_scale)
+    o_dyn, m_dyn = O.refine_cams(img_dn, cams * rep, cls_label, hm, 0.25, 255, img_box, down_scale=down_scale, return_margin=True)
+    assert_labels_equal_up_to_ties(r_dyn, o_dyn.numpy().astype(np.int64), m_dyn, f"refine dynamic, down_scale {down_scale}, {S}^2")
+    # denormalize_img with non-default statistics: x * std + mean in fp32 (rounded product, rounded sum), uint8 truncation
+    mean, std = [120.5, 110.25, 100.0], [60.0, 55.5, 50.25]
+    got = imutils.denormalize_img(inputs.to(dev), mean=mean, std=std)
+    ref = torch.zeros_like(inputs)
+    for c in range(3):
+        ref[:, c] = inputs[:, c] * std[c] + mean[c]
+    assert got.dtype == torch.uint8 and torch.equal(got.cpu(), ref.type(torch.uint8))
+    assert torch.equal(imutils.denormalize_img(inputs.to(dev)).cpu(), (O.denormalize_img2(inputs.clone()) * 255).round().byte())
+
+
 # ------------------------------------------------------------------------------------------ losses
 def test_loss_kernels(dev, golden_dir):
     import os
