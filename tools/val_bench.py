@@ -16,3 +16,10 @@ for rep in range(2):
     out = train_helper.validate_siamase(model=model, data_loader=samples, args=args, return_item=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"validate_siamase: {len(samples)} images (native ~375x500, crop 448, ViT-B/16 x 2 students, ms-CAM 3 scales + seg) in {dt:.2f} s = {len(samples) / dt:.1f} img/s")
+from dupl_amd.tools import eval_seg
+with torch.no_grad():
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eval_seg.validate(model, samples, types.SimpleNamespace(scales=(1.0, 1.5, 1.25)), num_classes=21)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"tools.eval_seg.validate (VOC protocol: native size, scales 1.0 / 1.5 / 1.25 x flip, both students): {len(samples) / dt:.1f} img/s")
