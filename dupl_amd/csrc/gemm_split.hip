@@ -19,7 +19,12 @@
 // k-tile: the DMA of tile t+1 runs under the MFMAs of tile t.  Accumulating GEMMs (weight gradients) split K over
 // gridDim.y and add with fp32 atomics.
 #include "common.h"
+#include <type_traits>
 #include "../../include/dupl_hip.h"
+
+#ifndef G16_ABL
+#define G16_ABL 0   // ablation builds only (tools/gemm16_abl.sh): 1 no DMA, 2 no MFMA, 4 no epilogue global traffic, 8 no epilogue
+#endif
 
 namespace {
 
@@ -40,6 +45,205 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
         reinterpret_cast<uint2*>(hi)[i] = *reinterpret_cast<uint2*>(h);
         reinterpret_cast<uint2*>(lo)[i] = *reinterpret_cast<uint2*>(l);
     }
+}
+
+
+// Epilogue shared by the split GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) +
+// 4 * (lane >> 5).  (mw, nw): first row / column of this wave's tile; interior: block-uniform, no per-element edge tests.
+template <int WM, int WN>
+__device__ __forceinline__ void gemm16_epilogue(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN], f32x16 (&accX)[WM][WN],
+                                                const int mw, const int nw, const bool interior, const int l31, const int hf,
+                                                const int ksplit) {
+    const int fl = p.flags;
+    const bool f_pre = fl & DUPL_GEMM_STORE_PRE, f_gelu = fl & DUPL_GEMM_GELU, f_relu = fl & DUPL_GEMM_RELU;
+    const bool f_acc = fl & DUPL_GEMM_ACCUM, f_dgelu = fl & DUPL_GEMM_MUL_DGELU, f_rmask = fl & DUPL_GEMM_MUL_RELUMASK;
+    const float alpha = p.alpha_dev ? *p.alpha_dev : 1.f;      // inverse operand scale(s) of scaled gradient planes
+    __half* Ch = static_cast<__half*>(p.C_hi);
+    __half* Cl = static_cast<__half*>(p.C_lo);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = nw + j * 32 + l31;
+        if (!interior && col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int rbase = mw + i * 32 + 4 * hf;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int row = rbase + (e & 3) + 8 * (e >> 2);
+                asm volatile("" : "+v"(row));        // keep the address arithmetic of element e AT element e: hoisted and
+                                                     // CSE'd across the 16 x WM x WN elements it spills (144 VGPRs at 2 x 2 tiles)
+                if (!interior && row >= p.M) continue;
+                float v = (accM[i][j][e] + accX[i][j][e] * LO_INV) * alpha + bv;
+                if (f_pre) p.aux[(size_t)row * p.ldaux + col] = v;
+                if (f_gelu) v = gelu_f(v);
+                if (f_relu) v = fmaxf(v, 0.f);
+                if (f_dgelu) v *= gelu_grad_f(p.aux[(size_t)row * p.ldaux + col]);
+                if (f_rmask) v = p.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
+                if (p.res) v += p.res[(size_t)row * p.ldr + col];
+                if (f_acc) {
+                    float* cp = p.C + (size_t)row * p.ldc + col;
+                    if (ksplit > 1) unsafeAtomicAdd(cp, v);
+                    else *cp += v;
+                    continue;
+                }
+                if (p.C) p.C[(size_t)row * p.ldc + col] = v;
+                if (Ch) {
+                    __half h, l;
+                    split_f32(v, h, l);
+                    Ch[(size_t)row * p.ldo + col] = h;
+                    Cl[(size_t)row * p.ldo + col] = l;
+                }
+            }
+        }
+    }
+}
+
+
+// Epilogue through LDS (ring kernel): the wave parks its (alpha-scaled, main + cross / 2048) tile in its own LDS region
+// [32 WM][32 WN] floats and walks it back row-wise, one float4 (4 consecutive columns) per lane -- 64 lanes = 4 rows x 256
+// contiguous bytes at 32 WN = 64 -- so that every global access of the epilogue (C, planes, aux, res) is a full-width
+// vector access on whole 128-byte lines instead of 2 x 128-byte dword rows (fp32) / 2 x 64 bytes (planes) per
+// instruction, and the epilogue is a short runtime loop instead of 16 WM WN unrolled element bodies.
+// LDS banking: the b32 writes of one MFMA register cover 32 consecutive floats per half-wave; the b128 reads of a 16-lane
+// group cover two row segments that tile all 64 banks (unpadded rows of 32 / 64 floats) -- both conflict-free.
+// Vector path needs N, ldc, ldo, ldr, ldaux multiples of 4 and 16-byte (8 for planes) aligned bases: `vec`, block-uniform;
+// otherwise, and in edge columns, the same values go out element-wise.
+// WMP: MFMA row tiles per pass (the region holds 32 WMP rows; the WM / WMP passes reuse it, same wave, in order).  SINGLE: the
+// cross terms were accumulated into accM (unscaled lo planes), accX is unused.
+template <int WM, int WN, int WMP, bool SINGLE>
+__device__ __forceinline__ void gemm16_epilogue_lds(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN], f32x16 (&accX)[SINGLE ? 1 : WM][SINGLE ? 1 : WN],
+                                                    float* __restrict__ tile, const int mw0, const int nw, const int lane,
+                                                    const int ksplit) {
+    constexpr int TW = 32 * WN, TH = 32 * WMP, LPR = TW / 4, RPI = 64 / LPR;
+    static_assert(WM % WMP == 0, "passes");
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int fl = p.flags;
+    const bool f_pre = fl & DUPL_GEMM_STORE_PRE, f_gelu = fl & DUPL_GEMM_GELU, f_relu = fl & DUPL_GEMM_RELU;
+    const bool f_acc = fl & DUPL_GEMM_ACCUM, f_dgelu = fl & DUPL_GEMM_MUL_DGELU, f_rmask = fl & DUPL_GEMM_MUL_RELUMASK;
+    const float alpha = p.alpha_dev ? *p.alpha_dev : 1.f;
+#pragma unroll
+    for (int ps = 0; ps < WM / WMP; ++ps) {
+    const int mw = mw0 + ps * TH;
+#pragma unroll
+    for (int i = 0; i < WMP; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v;
+                if constexpr (SINGLE) v = accM[ps * WMP + i][j][e] * alpha;
+                else v = (accM[ps * WMP + i][j][e] + accX[ps * WMP + i][j][e] * LO_INV) * alpha;
+                tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf) * TW + j * 32 + l31] = v;
+            }
+    __half* Ch = static_cast<__half*>(p.C_hi);
+    __half* Cl = static_cast<__half*>(p.C_lo);
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = !(p.N & 3) && !(p.ldc & 3) && !(p.ldo & 3) && !(p.ldr & 3) && !(p.ldaux & 3) && a16(p.C) && a16(p.res) &&
+                     a16(p.aux) && a16(p.bias) && !(reinterpret_cast<uintptr_t>(Ch) & 7) && !(reinterpret_cast<uintptr_t>(Cl) & 7);
+    if (f_acc) {
+        // C += tile (weight gradients; split-K partials meet in fp32 atomics): lane = column, so that one instruction adds
+        // to 32 WN consecutive floats of a row -- whole lines per atomic request instead of 16-byte-strided lanes
+        constexpr int RPA = 64 / TW;        // rows per instruction
+        const int ca = lane % TW, ra = lane / TW;
+        if (nw + ca >= p.N) continue;
+        for (int r = ra; r < TH; r += RPA) {
+            const int row = mw + r;
+            if (row >= p.M) break;
+            float* cp = p.C + (size_t)row * p.ldc + nw + ca;
+            const float v = tile[r * TW + ca];
+            if (ksplit > 1) unsafeAtomicAdd(cp, v);
+            else *cp += v;
+        }
+        continue;
+    }
+    const int cl = (lane % LPR) * 4, rl = lane / LPR;
+    const int col = nw + cl;
+    const int nv = min(4, p.N - col);          // valid columns of this lane's float4 (<= 0: none)
+    if (nv <= 0) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < nv) bv[c] = p.bias[col + c];
+    }
+    const bool fast = vec && nv == 4;
+    for (int r = rl; r < TH; r += RPI) {
+        const int row = mw + r;
+        if (row >= p.M) break;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tile + r * TW + cl);
+        if (G16_ABL & 4) {
+            if (t[0] + t[1] + t[2] + t[3] == 123.456f) p.C[0] = 1.f;
+            continue;
+        }
+        float v[4] = {t[0] + bv[0], t[1] + bv[1], t[2] + bv[2], t[3] + bv[3]};
+        float* auxp = p.aux + (size_t)row * p.ldaux + col;
+        if (f_pre) {
+            if (fast) *reinterpret_cast<f32x4*>(auxp) = f32x4{v[0], v[1], v[2], v[3]};
+            else
+                {
+_Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) auxp[c] = v[c]; }
+        }
+        if (f_gelu) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
+        }
+        if (f_relu) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+        }
+        if (f_dgelu | f_rmask) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            if (fast) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(auxp);
+                a[0] = q[0]; a[1] = q[1]; a[2] = q[2]; a[3] = q[3];
+            } else
+                {
+_Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) a[c] = auxp[c]; }
+            if (f_dgelu) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] *= gelu_grad_f(a[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = a[c] > 0.f ? v[c] : 0.f;
+            }
+        }
+        if (p.res) {
+            const float* rp = p.res + (size_t)row * p.ldr + col;
+            if (fast) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(rp);
+                v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+            } else
+                {
+_Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) v[c] += rp[c]; }
+        }
+        if (p.C) {
+            float* cp = p.C + (size_t)row * p.ldc + col;
+            if (fast) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            else
+                {
+_Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) cp[c] = v[c]; }
+        }
+        if (Ch) {
+            __half h[4], l[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) split_f32(v[c], h[c], l[c]);
+            __half* hp = Ch + (size_t)row * p.ldo + col;
+            __half* lp = Cl + (size_t)row * p.ldo + col;
+            if (fast) {
+                *reinterpret_cast<uint2*>(hp) = *reinterpret_cast<const uint2*>(h);
+                *reinterpret_cast<uint2*>(lp) = *reinterpret_cast<const uint2*>(l);
+            } else
+                {
+_Pragma("unroll") for (int c = 0; c < 4; ++c)
+                    if (c < nv) {
+                        hp[c] = h[c];
+                        lp[c] = l[c];
+                    }
+                }
+        }
+    }
+    }   // passes
 }
 
 // WM x WN: 32x32 MFMA tiles per wave; NWM x NWN: waves per block.  Block tile (32 WM NWM) x (32 WN NWN) x 32.
@@ -152,47 +356,292 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINB) void gemm_f16x3_kernel(const 
         }
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    const int fl = p.flags;
-    const bool f_pre = fl & DUPL_GEMM_STORE_PRE, f_gelu = fl & DUPL_GEMM_GELU, f_relu = fl & DUPL_GEMM_RELU;
-    const bool f_acc = fl & DUPL_GEMM_ACCUM, f_dgelu = fl & DUPL_GEMM_MUL_DGELU, f_rmask = fl & DUPL_GEMM_MUL_RELUMASK;
-    const float alpha = p.alpha_dev ? *p.alpha_dev : 1.f;      // inverse operand scale(s) of scaled gradient planes
-    __half* Ch = static_cast<__half*>(p.C_hi);
-    __half* Cl = static_cast<__half*>(p.C_lo);
-    const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;    // block-uniform: no per-element edge tests
+    gemm16_epilogue<WM, WN>(p, accM, accX, m0 + wm * (32 * WM), n0 + wn * (32 * WN), m0 + BM <= p.M && n0 + BN <= p.N, l31, hf,
+                            ksplit);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Ring-pipelined variant (round 3).  Same operand format, fragment layout and epilogue as gemm_f16x3_kernel; what changes
+// is the staging pipeline and the tile:
+//   * block tile 256 x 128 x 32 (48 KB per k-tile: A 2 x 16 KB, B 2 x 8 KB) -> 32 B/clk/CU of L2->LDS stream at MFMA peak
+//     instead of 42.7 for 128 x 128, and 8 (wave 64 x 64) or 12 (wave 128 x 64) fragment reads per 12 / 24 MFMAs instead
+//     of 6 per 6;
+//   * STAGES = 3 LDS stages (144 KB, one block per CU) filled by direct-to-LDS DMA TWO k-tiles ahead; the only wait in the
+//     loop is a COUNTED `s_waitcnt vmcnt(PPW)` (this wave's pieces of tile t have landed, those of tile t+1 stay in flight)
+//     followed by a raw s_barrier -- never vmcnt(0), never __syncthreads() (whose fence would drain the DMA queue).
+//     Hazards: RAW -- tile t is read only after every wave waited for its own pieces of t and passed the barrier of
+//     iteration t; WAR -- the DMA of tile t+2 into stage (t+2) % 3 = (t-1) % 3 is issued after that same barrier, which
+//     every wave reaches only after its last fragment read of tile t-1 returned (the MFMAs that consumed it precede it).
+// s_waitcnt immediate (gfx9 encoding): lgkmcnt(0), expcnt untouched, vmcnt(n)
+#define WAIT_LGKM0_VM(n) ((((n) & 15) | (((n) >> 4) << 14)) | (7 << 4))
+
+// issue-order hints (hipcc keeps ds_read / MFMA / DMA clusters apart otherwise): NMF MFMAs spread over NR fragment reads
+// (phase A) or over NR reads + ND DMA pieces (phase B: reads and DMA alternate while both remain)
+template <int NMF, int NR, int R = 0>
+__device__ __forceinline__ void sched_mfma_ds() {
+    if constexpr (R < NR) {
+        constexpr int nm = (R + 1) * NMF / NR - R * NMF / NR;
+        if constexpr (nm > 0) __builtin_amdgcn_sched_group_barrier(0x008, nm, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        sched_mfma_ds<NMF, NR, R + 1>();
+    }
+}
+template <int NMF, int NR, int ND, int S = 0, int RD = 0, int DD = 0>
+__device__ __forceinline__ void sched_mfma_ds_dma() {
+    constexpr int NS = NR + ND;
+    if constexpr (S < NS) {
+        constexpr int nm = (S + 1) * NMF / NS - S * NMF / NS;
+        if constexpr (nm > 0) __builtin_amdgcn_sched_group_barrier(0x008, nm, 0);
+        // next slot: a read if reads are behind their share, else a DMA piece
+        constexpr bool rd = RD < NR && (DD >= ND || RD * ND <= DD * NR);
+        if constexpr (rd) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            sched_mfma_ds_dma<NMF, NR, ND, S + 1, RD + 1, DD>();
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            sched_mfma_ds_dma<NMF, NR, ND, S + 1, RD, DD + 1>();
+        }
+    }
+}
+
+// the loads of phase B in the order sched_mfma_ds_dma asks for
+template <int NR, int ND, int RD = 0, int DD = 0, class FR, class FD, class A, class B>
+__device__ __forceinline__ void loads_b(FR& read_item, FD& dma_item, const char* st, const int cs, A& fa, B& fb, char* dst) {
+    if constexpr (RD + DD < NR + ND) {
+        constexpr bool rd = RD < NR && (DD >= ND || RD * ND <= DD * NR);
+        if constexpr (rd) {
+            read_item(std::integral_constant<int, RD>{}, st, cs, fa, fb);
+            loads_b<NR, ND, RD + 1, DD>(read_item, dma_item, st, cs, fa, fb, dst);
+        } else {
+            dma_item(std::integral_constant<int, DD>{}, dst);
+            loads_b<NR, ND, RD, DD + 1>(read_item, dma_item, st, cs, fa, fb, dst);
+        }
+    }
+}
+
+template <int WM, int WN, int NWM, int NWN, int WPS, int STAGES = 3, bool SINGLE = false>
+__global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_ring_kernel(const dupl_gemm16_desc p, const int g_gm) {
+    constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, NW = NWM * NWN;
+    constexpr int PA = BM / 16, PB = BN / 16;
+    constexpr int NP = 2 * PA + 2 * PB;
+    constexpr int STAGE = NP * 1024;
+    constexpr int PPW = NP / NW;
+    constexpr int NMF = 3 * WM * WN, NR = 2 * (WM + WN);
+    static_assert(NP % NW == 0, "pieces must divide over the waves");
+    static_assert(STAGES * STAGE <= 160 * 1024, "LDS");
+    static_assert((STAGES - 1) * PPW <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int l31 = lane & 31, hf = lane >> 5;
+
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nblk = nbm * nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int gspan = g_gm * nbn;
+    const int gid = lid / gspan, gin = lid - gid * gspan;
+    const int gfirst = gid * g_gm;
+    const int gsz = min(nbm - gfirst, g_gm);
+    const int tm = gfirst + gin % gsz, tn = gin / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int ntk = p.K / TBK;
+    const int ksplit = gridDim.y;
+    const int per = (ntk + ksplit - 1) / ksplit;
+    const int tb = blockIdx.y * per, te = min(ntk, tb + per);
+    if (tb >= te) return;
+    const int nt = te - tb;
+    if (G16_ABL & 16)
+        if (tid == 0 && p.aux) {
+            long long* q = reinterpret_cast<long long*>(p.aux) + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8;
+            q[0] = clock64();
+            q[4] = wall_clock64();
+        }
+
+    // ---- DMA plan (as gemm_f16x3_kernel): piece g = wave + NW * i
+    const int prow = lane >> 2;
+    const int jsrc = (lane & 3) ^ ((prow >> 2) & 3);
+    const char* gp[PPW];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int col = n0 + wn * (32 * WN) + j * 32 + l31;
-        if (!interior && col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+    for (int i = 0; i < PPW; ++i) {
+        const int g = wave + NW * i;
+        const __half* plane;
+        int ld, r0, R, q;
+        if (g < PA) { plane = static_cast<const __half*>(p.A_hi); ld = p.lda; r0 = m0; R = p.M; q = g; }
+        else if (g < 2 * PA) { plane = static_cast<const __half*>(p.A_lo); ld = p.lda; r0 = m0; R = p.M; q = g - PA; }
+        else if (g < 2 * PA + PB) { plane = static_cast<const __half*>(p.B_hi); ld = p.ldb; r0 = n0; R = p.N; q = g - 2 * PA; }
+        else { plane = static_cast<const __half*>(p.B_lo); ld = p.ldb; r0 = n0; R = p.N; q = g - 2 * PA - PB; }
+        const int row = min(r0 + q * 16 + prow, R - 1);
+        gp[i] = reinterpret_cast<const char*>(plane + (size_t)row * ld) + jsrc * 16 + (size_t)tb * (TBK * 2);
+    }
+    auto issue = [&](int buf) __attribute__((always_inline)) {   // next k-tile of this block -> stage buf
+        char* dst = smem + buf * STAGE + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const int rbase = m0 + wm * (32 * WM) + i * 32 + 4 * hf;
+        for (int i = 0; i < PPW; ++i) {
+            if (!(G16_ABL & 1))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[i],
+                                                 (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
+            gp[i] += TBK * 2;
+        }
+    };
+
+    // ---- fragment addresses (bytes inside a stage): plane base + row * 64 + ((s*2 + hf) ^ ((row >> 2) & 3)) * 16
+    const int sw = (l31 >> 2) & 3;
+    const int a_row = (wm * (32 * WM) + l31) * 64, b_row = 2 * PA * 1024 + (wn * (32 * WN) + l31) * 64;
+    const int c0 = ((0 | hf) ^ sw) * 16, c1 = ((2 | hf) ^ sw) * 16;
+
+    f32x16 accM[WM][WN], accX[SINGLE ? 1 : WM][SINGLE ? 1 : WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = rbase + (e & 3) + 8 * (e >> 2);
-                if (!interior && row >= p.M) continue;
-                float v = (accM[i][j][e] + accX[i][j][e] * LO_INV) * alpha + bv;
-                if (f_pre) p.aux[(size_t)row * p.ldaux + col] = v;
-                if (f_gelu) v = gelu_f(v);
-                if (f_relu) v = fmaxf(v, 0.f);
-                if (f_dgelu) v *= gelu_grad_f(p.aux[(size_t)row * p.ldaux + col]);
-                if (f_rmask) v = p.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
-                if (p.res) v += p.res[(size_t)row * p.ldr + col];
-                if (f_acc) {
-                    float* cp = p.C + (size_t)row * p.ldc + col;
-                    if (ksplit > 1) unsafeAtomicAdd(cp, v);
-                    else *cp += v;
-                    continue;
-                }
-                if (p.C) p.C[(size_t)row * p.ldc + col] = v;
-                if (Ch) {
-                    __half h, l;
-                    split_f32(v, h, l);
-                    Ch[(size_t)row * p.ldo + col] = h;
-                    Cl[(size_t)row * p.ldo + col] = l;
-                }
+                accM[i][j][e] = 0.f;
+                if constexpr (!SINGLE) accX[i][j][e] = 0.f;
             }
+    // two fragment sets: F0 = k-step 0 of a tile, F1 = k-step 1; [0, W) hi planes, [W, 2 W) lo planes
+    h8 f0a[2 * WM], f0b[2 * WN], f1a[2 * WM], f1b[2 * WN];
+    auto read_frags = [&](const char* st, const int cs, h8(&fa)[2 * WM], h8(&fb)[2 * WN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            fa[i] = *reinterpret_cast<const h8*>(st + a_row + i * 2048 + cs);
+            fa[WM + i] = *reinterpret_cast<const h8*>(st + PA * 1024 + a_row + i * 2048 + cs);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            fb[j] = *reinterpret_cast<const h8*>(st + b_row + j * 2048 + cs);
+            fb[WN + j] = *reinterpret_cast<const h8*>(st + PB * 1024 + b_row + j * 2048 + cs);
+        }
+    };
+    // three passes (main, cross hi x lo, cross lo x hi), kept apart for the MFMA pipe: an accumulator is touched once per
+    // pass, WM WN MFMAs apart (sched_barrier: nothing but MFMAs is pinned, reads and DMA may cross)
+    constexpr int XMFMA = 0x7ff & ~0x8;
+    auto mfmas = [&](const h8(&fa)[2 * WM], const h8(&fb)[2 * WN]) __attribute__((always_inline)) {
+        if (G16_ABL & 2) {
+#pragma unroll
+            for (int i = 0; i < 2 * WM; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < 2 * WN; ++j) asm volatile("" ::"v"(fb[j]));
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], accM[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(XMFMA);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if constexpr (SINGLE) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[WN + j], accM[i][j], 0, 0, 0);
+                else accX[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[WN + j], accX[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(XMFMA);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if constexpr (SINGLE) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WM + i], fb[j], accM[i][j], 0, 0, 0);
+                else accX[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WM + i], fb[j], accX[i][j], 0, 0, 0);
+            }
+    };
+    // phase B: fragment reads of the next tile and DMA pieces alternate IN SOURCE ORDER (an LDS read and an LDS-DMA write
+    // are ordered for the compiler, so the issue-order hints can only follow the source)
+    auto read_item = [&](auto rc, const char* st, const int cs, h8(&fa)[2 * WM], h8(&fb)[2 * WN]) __attribute__((always_inline)) {
+        constexpr int R = decltype(rc)::value;
+        if constexpr (R < WM) fa[R] = *reinterpret_cast<const h8*>(st + a_row + R * 2048 + cs);
+        else if constexpr (R < 2 * WM) fa[R] = *reinterpret_cast<const h8*>(st + PA * 1024 + a_row + (R - WM) * 2048 + cs);
+        else if constexpr (R < 2 * WM + WN) fb[R - 2 * WM] = *reinterpret_cast<const h8*>(st + b_row + (R - 2 * WM) * 2048 + cs);
+        else fb[R - 2 * WM] = *reinterpret_cast<const h8*>(st + PB * 1024 + b_row + (R - 2 * WM - WN) * 2048 + cs);
+    };
+    auto dma_item = [&](auto dc, char* dst) __attribute__((always_inline)) {
+        constexpr int I = decltype(dc)::value;
+        if (!(G16_ABL & 1))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[I],
+                                             (__attribute__((address_space(3))) void*)(dst + I * (NW * 1024)), 16, 0, 0);
+        gp[I] += TBK * 2;
+    };
+    // ---- pipeline.  Tile t lives in stage t % 3.  Iteration t:
+    //   phase A:  read F1(t)                      | MFMAs on F0(t)
+    //   lgkmcnt(0); vmcnt(PPW): my pieces of tile t+1 landed (tile t+2 may still fly); s_barrier
+    //   phase B:  read F0(t+1), DMA tile t+3 -> stage t % 3 (whose last reads, F1(t), every wave retired before the barrier)
+    //                                             | MFMAs on F1(t)
+    // never vmcnt(0) and never __syncthreads() in the steady state; the last three iterations run without DMA.
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s)
+        if (s < nt) issue(s);
+    if (nt >= STAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(smem, c0, f0a, f0b);
+    if (G16_ABL & 16)
+        if (tid == 0 && p.aux) reinterpret_cast<long long*>(p.aux)[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8 + 1] = clock64();
+    int rb = 0;
+    int t = 0;
+    for (; t + STAGES < nt; ++t) {
+        const char* st = smem + rb * STAGE;
+        const int nb = rb + 1 == STAGES ? 0 : rb + 1;
+        read_frags(st, c1, f1a, f1b);
+        mfmas(f0a, f0b);
+        sched_mfma_ds<NMF, NR>();
+        __builtin_amdgcn_s_waitcnt(WAIT_LGKM0_VM((STAGES - 2) * PPW));   // the builtin, so that hipcc knows F1 has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        loads_b<NR, PPW>(read_item, dma_item, smem + nb * STAGE, c0, f0a, f0b, smem + rb * STAGE + wave * 1024);
+        mfmas(f1a, f1b);
+        sched_mfma_ds_dma<NMF, NR, PPW>();
+        rb = nb;
+    }
+    for (; t < nt; ++t) {
+        const char* st = smem + rb * STAGE;
+        const int nb = rb + 1 == STAGES ? 0 : rb + 1;
+        read_frags(st, c1, f1a, f1b);
+        mfmas(f0a, f0b);
+        sched_mfma_ds<NMF, NR>();
+        if (t + 1 < nt) {
+            __builtin_amdgcn_s_waitcnt(WAIT_LGKM0_VM(0));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            read_frags(smem + nb * STAGE, c0, f0a, f0b);
+        }
+        mfmas(f1a, f1b);
+        rb = nb;
+    }
+
+    // every wave is done reading the stages and no DMA is in flight -> reuse the LDS for the epilogue tiles
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    constexpr int WMP = (NW * (32 * WM) * (32 * WN) * 4 <= STAGES * STAGE) ? WM : WM / 2;   // epilogue passes
+    static_assert(NW * (32 * WMP) * (32 * WN) * 4 <= STAGES * STAGE, "epilogue tiles must fit the stages");
+    if (G16_ABL & 16)
+        if (tid == 0 && p.aux) reinterpret_cast<long long*>(p.aux)[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8 + 2] = clock64();
+    if (G16_ABL & 8) {
+        float sum = 0.f;   // keep every accumulator live
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += accM[i][j][e] + (SINGLE ? 0.f : accX[SINGLE ? 0 : i][SINGLE ? 0 : j][e]);
+        if (sum == 123.456f) p.C[0] = 1.f;
+        return;
+    }
+    gemm16_epilogue_lds<WM, WN, WMP, SINGLE>(p, accM, accX, reinterpret_cast<float*>(smem) + wave * ((32 * WMP) * (32 * WN)),
+                                             m0 + wm * (32 * WM), n0 + wn * (32 * WN), lane, ksplit);
+    if (G16_ABL & 16) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0 && p.aux) {
+            long long* q = reinterpret_cast<long long*>(p.aux) + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8;
+            q[3] = clock64();
+            q[5] = wall_clock64();
         }
     }
 }
@@ -200,6 +649,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINB) void gemm_f16x3_kernel(const 
 }  // namespace
 
 static int g16_group_m = 8;
+static int g16_group_ring = 2;   // row tiles (256 rows) per group of the ring kernel's block order: 512-row A bands stay in an
+                                  // XCD's L2 while it sweeps the columns (2 / 3: 320, 4: 312, 8: 304, 16: 285 TF/s-eq on 15696 x 3072 x 768)
 static int g16_tile = 0;     // 0 = heuristic; 3: 128x64 on 4 waves; 5: 128x128 on 8 waves (wave tile 64x32 in both).  Measured
                              // and dropped: 64x64 wave tiles on 4 / 8 waves (2 waves / SIMD: -10..25 %), 256x128 on 16 waves
 
@@ -218,11 +669,12 @@ extern "C" int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, d
 extern "C" int dupl_set_gemm16_group(int32_t gm) {
     if (gm < 1 || gm > 4096) return DUPL_ERR_ARG;
     g16_group_m = gm;
+    g16_group_ring = gm;
     return DUPL_OK;
 }
 
 extern "C" int dupl_set_gemm16_tile(int32_t t) {
-    if (t != 0 && t != 3 && t != 5) return DUPL_ERR_ARG;
+    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9) return DUPL_ERR_ARG;
     g16_tile = t;
     return DUPL_OK;
 }
@@ -255,14 +707,23 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
     }
     int tile = g16_tile;
     if (tile == 0) {
-        // 128 x 128 tiles unless they leave most of the 512 block slots (2 per CU) empty: then 128 x 64 (twice the blocks)
-        // 128 x 128 on 8 waves (4 waves / SIMD: +10..25 % over 4 waves on K = 768, profiles/r02_gemm16_tiles.txt) unless
-        // that leaves most of the 512 block slots empty: then 128 x 64 on 4 waves (twice the blocks)
+        // Measured on the shapes of the step with both students' launches in flight (tools/gemm16_bench -2 -w 200,
+        // profiles/r03_gemm16_tiles.txt), sustained clocks: the 256 x 128 ring kernel (tile 6) wins wherever it gets
+        // >= ~100 blocks (>= 64 when K >= 2048: long blocks amortise their prologue / epilogue), the weight gradients
+        // (split-K partials: short blocks, atomics) and the mid-size grids stay on 128 x 128 (tile 5), grids that would
+        // leave most of its 512 block slots empty on 128 x 64 (tile 3)
+        const long b256 = (long)((d->M + 255) / 256) * ((d->N + 127) / 128);
         const long b128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * ksplit;
-        tile = b128 < 200 ? 3 : 5;
+        if (!accum && (b256 >= 100 || (b256 >= 64 && d->K >= 2048))) tile = 6;
+        else tile = b128 < 200 ? 3 : 5;
     }
     auto blocks = [&](int bm, int bn) { return dim3((unsigned)(((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn)), (unsigned)ksplit); };
-    if (tile == 3) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 2, 2>), blocks(128, 64), dim3(256), 0, s, *d, g16_group_m);
+    // 8 / 9: experimental single-accumulator 256 x 256 forms (need UNSCALED lo planes: timing probes only, tools/gemm16_bench)
+    if (tile == 8) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), blocks(256, 256), dim3(512), 0, s, *d, g16_group_ring);
+    else if (tile == 9) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 4, 2, 2, 1, 2, true>), blocks(256, 256), dim3(256), 0, s, *d, g16_group_ring);
+    else if (tile == 6) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
+    else if (tile == 7) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 2, 1>), blocks(256, 128), dim3(256), 0, s, *d, g16_group_ring);
+    else if (tile == 3) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 2, 2>), blocks(128, 64), dim3(256), 0, s, *d, g16_group_m);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 4, 4>), blocks(128, 128), dim3(512), 0, s, *d, g16_group_m);
     return dupl_launch_status();
 }
