@@ -651,6 +651,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_ring_kernel(co
 static int g16_group_m = 8;
 static int g16_group_ring = 2;   // row tiles (256 rows) per group of the ring kernel's block order: 512-row A bands stay in an
                                   // XCD's L2 while it sweeps the columns (2 / 3: 320, 4: 312, 8: 304, 16: 285 TF/s-eq on 15696 x 3072 x 768)
+static int g16_concurrency = 1;  // how many streams feed split GEMMs at a time (dupl_set_gemm16_concurrency)
 static int g16_tile = 0;     // 0 = heuristic; 3: 128x64 on 4 waves; 5: 128x128 on 8 waves (wave tile 64x32 in both).  Measured
                              // and dropped: 64x64 wave tiles on 4 / 8 waves (2 waves / SIMD: -10..25 %), 256x128 on 16 waves
 
@@ -670,6 +671,12 @@ extern "C" int dupl_set_gemm16_group(int32_t gm) {
     if (gm < 1 || gm > 4096) return DUPL_ERR_ARG;
     g16_group_m = gm;
     g16_group_ring = gm;
+    return DUPL_OK;
+}
+
+extern "C" int dupl_set_gemm16_concurrency(int32_t n) {
+    if (n < 1 || n > 8) return DUPL_ERR_ARG;
+    g16_concurrency = n;
     return DUPL_OK;
 }
 
@@ -707,14 +714,18 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
     }
     int tile = g16_tile;
     if (tile == 0) {
-        // Measured on the shapes of the step with both students' launches in flight (tools/gemm16_bench -2 -w 200,
-        // profiles/r03_gemm16_tiles.txt), sustained clocks: the 256 x 128 ring kernel (tile 6) wins wherever it gets
-        // >= ~100 blocks (>= 64 when K >= 2048: long blocks amortise their prologue / epilogue), the weight gradients
-        // (split-K partials: short blocks, atomics) and the mid-size grids stay on 128 x 128 (tile 5), grids that would
-        // leave most of its 512 block slots empty on 128 x 64 (tile 3)
+        // Measured on the shapes of the step (tools/gemm16_bench -w 200 with and without -2, profiles/r03_gemm16_tiles.txt),
+        // sustained clocks.  The 256 x 128 ring kernel (tile 6) is one block per CU: it wins where its grid fills the chip
+        // or where a long K amortises the un-overlapped prologue / epilogue of a block.  With a second stream feeding the
+        // chip (the two students: dupl_set_gemm16_concurrency(2)) that is >= ~100 blocks (>= 64 when K >= 2048); alone,
+        // >= ~900 blocks (>= 128 when K >= 1536).  The weight gradients (split-K partials: short blocks, atomics) and
+        // the mid-size grids stay on 128 x 128 (tile 5, two blocks per CU), grids that would leave most of its 512 block
+        // slots empty on 128 x 64 (tile 3).
         const long b256 = (long)((d->M + 255) / 256) * ((d->N + 127) / 128);
         const long b128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * ksplit;
-        if (!accum && (b256 >= 100 || (b256 >= 64 && d->K >= 2048))) tile = 6;
+        const bool ring = g16_concurrency >= 2 ? (b256 >= 100 || (b256 >= 64 && d->K >= 2048))
+                                               : (b256 >= 900 || (b256 >= 128 && d->K >= 1536));
+        if (!accum && ring) tile = 6;
         else tile = b128 < 200 ? 3 : 5;
     }
     auto blocks = [&](int bm, int bn) { return dim3((unsigned)(((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn)), (unsigned)ksplit); };

@@ -317,6 +317,10 @@ class siamese_network(nn.Module):
             self._store.streams = list(_STREAM_PAIRS[dev])
         if not on:
             self._store.streams = []
+        # the split GEMM picks its tile for the number of launches that share the chip (csrc/gemm_split.hip)
+        from .. import ops
+        if self._store.data.is_cuda:
+            ops.L().dupl_set_gemm16_concurrency(2 if (on and self._store.streams) else 1)
         return self
 
     def ms_cam_and_forward(self, inputs, scales, inputs_aug=None):

@@ -101,8 +101,12 @@ int dupl_set_gemm16_group(int32_t gm);
  * No reference counterpart (the reference's autograd calls ATen GEMMs on fp32 operands). */
 int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
                        void* hiT, void* loT, int32_t Rp, int32_t target_exp, dupl_stream_t stream);
-/* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 3: 128x64 on 4 waves, 5: 128x128 on 8 waves) */
+/* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 3: 128x64 on 4 waves, 5: 128x128 on 8 waves, 6 / 7: 256x128 ring
+ * kernel on 8 / 4 waves; 8 / 9: single-accumulator 256x256 timing probes, results only valid for unscaled lo planes) */
 int dupl_set_gemm16_tile(int32_t t);
+/* hint for the tile heuristic (no reference counterpart): how many streams issue split GEMMs concurrently -- 2 while the two
+ * students of siamese_network run on their own streams (model_dupl.py:157-213 runs them back to back), else 1 */
+int dupl_set_gemm16_concurrency(int32_t n);
 /* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
 int dupl_set_gemm_tile(int32_t rows);
 /* tuning knob (no reference counterpart): column tile of the 64-row GEMM kernels, 64 or 128 (0 = heuristic on the grid) */
