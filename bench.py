@@ -362,6 +362,20 @@ class Workload:
             e = torch.tensor([sum(ex)], device=self.dev, dtype=torch.float64)
             dist.all_reduce(e, op=dist.ReduceOp.MAX)
             comm["comm_exposed_ms"] = round(float(e.item()), 3)
+            # self-validation of the exchange (the first real multi-GPU run must prove itself): every rank started from
+            # rank 0's broadcast and applied the same averaged gradients, so the parameter buffers must be bit-identical --
+            # two order-sensitive 64-bit checksums of the raw bits, compared over all ranks
+            bits = self.model.flat_storage.data.view(torch.int32).to(torch.int64)
+            idx = torch.arange(bits.numel(), device=self.dev, dtype=torch.int64)
+            cs = torch.stack([bits.sum(), (bits * ((idx % 65521) + 1)).sum()])
+            gathered = [torch.zeros_like(cs) for _ in range(world)]
+            dist.all_gather(gathered, cs)
+            same = all(bool(torch.equal(g, gathered[0])) for g in gathered)
+            comm["param_checksum"] = [int(v) for v in cs.tolist()]
+            comm["params_identical_on_all_ranks"] = same
+            comm["world_matches_gpus"] = (world == args.gpus == dist.get_world_size())
+            assert same, f"parameter buffers diverged across ranks after {args.warmup + args.steps + 1} steps: {[g.tolist() for g in gathered]}"
+            assert comm["world_matches_gpus"], (world, args.gpus, dist.get_world_size())
         ms = dt / args.steps * 1e3
         value = world * self.batch * args.steps / dt
         log(f"[{label}] timed region: {args.steps} steps in {dt:.3f} s -> {value:.2f} img/s")

@@ -60,6 +60,10 @@ class GradReducer:
     def broadcast_parameters(self, src: int = 0):
         if self.world > 1:
             dist.broadcast(self.store.data, src=src, group=self.pg)
+            # a c10d collective does not bump the tensor's version counter: tell the fp16 operand-plane cache
+            # (FlatStorage.ensure_w16 / w16T) that the parameters changed.  Every non-autograd writer of store.data
+            # (raw-pointer kernels, collectives) must do the same.
+            self.store.mark_dirty()
 
     def _issue(self, lo: int, hi: int):
         """all-reduce grad[lo:hi] in pieces of at most bucket_elems (returns immediately)."""

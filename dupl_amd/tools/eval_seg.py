@@ -114,8 +114,13 @@ def validate(model, data_loader, args, num_classes=21, cat_list=None, keep_logit
             cms[k].update(labels, ops.argmax_channels(seg[k]))
             if keep_logits is not None:
                 keep_logits(data[0], k + 1, seg[k])
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # main() shards the split over the ranks for both datasets: the score is of the summed confusion matrices
+        for c in cms:
+            dist.all_reduce(c.hist, op=dist.ReduceOp.SUM)
     sc = [c.scores() for c in cms]
-    if cat_list is not None:
+    if cat_list is not None and (not dist.is_initialized() or dist.get_rank() == 0):
         print(format_tabs(sc, ["Seg_1", "Seg_2"], cat_list=cat_list))
     return sc[0], sc[1]
 

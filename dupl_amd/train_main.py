@@ -160,6 +160,26 @@ def setup_seed(seed):
     random.seed(seed)
 
 
+def _save_resume_state(ckpt_dir, wrapped, model, optim, n_iter):
+    """checkpoint.pth (keys prefixed `module.`, train_final_voc.py:519) + optimizer.pth + checkpoint.n_iter, each written to a
+    temporary file and renamed into place, the iteration tag last: a job killed mid-save leaves either the previous
+    consistent triple or a tag that --resume can check against optimizer.pth."""
+    os.makedirs(ckpt_dir, exist_ok=True)
+    sd = wrapped.state_dict() if wrapped is not None else {"module." + k: v for k, v in model.state_dict().items()}
+
+    def put(obj, name):
+        tmp = os.path.join(ckpt_dir, name + ".tmp")
+        torch.save(obj, tmp)
+        os.replace(tmp, os.path.join(ckpt_dir, name))
+
+    put(sd, "checkpoint.pth")
+    put({"n_iter": n_iter, "optimizer": optim.state_dict()}, "optimizer.pth")
+    tmp = os.path.join(ckpt_dir, "checkpoint.n_iter.tmp")
+    with open(tmp, "w") as f:
+        f.write(str(n_iter))
+    os.replace(tmp, os.path.join(ckpt_dir, "checkpoint.n_iter"))
+
+
 def train(args, dataset: str, loader=None, val_loader=None):
     from .ddp import DistributedDataParallel
     from .model.model_dupl import siamese_network
@@ -212,8 +232,15 @@ def train(args, dataset: str, loader=None, val_loader=None):
     optim.global_step = args.start_iter       # a run that starts at n_iter = k is at step k of the LR schedule too
     if getattr(args, "resume", None):
         ck = torch.load(os.path.join(args.resume, "checkpoint.pth"), map_location="cpu")
-        model.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in ck.items()}, strict=True)
         ost = torch.load(os.path.join(args.resume, "optimizer.pth"), map_location="cpu")
+        tag = os.path.join(args.resume, "checkpoint.n_iter")
+        if os.path.exists(tag):     # written last by _save_resume_state: model and optimiser files of the same iteration
+            with open(tag) as f:
+                saved_at = int(f.read().strip())
+            if saved_at != int(ost["n_iter"]):
+                raise RuntimeError(f"{args.resume}: checkpoint.pth was written at n_iter {saved_at}, optimizer.pth at "
+                                   f"{int(ost['n_iter'])} (a save was interrupted): refusing to resume from mixed state")
+        model.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in ck.items()}, strict=True)
         optim.load_state_dict(ost["optimizer"])
         args.start_iter = int(ost["n_iter"])
         if rank == 0:
@@ -242,11 +269,9 @@ def train(args, dataset: str, loader=None, val_loader=None):
                          % (n_iter + 1, el, optim.param_groups[0]["lr"], float(acc["cls_loss"]) / n, float(acc["ptc_loss"]) / n,
                             float(acc["seg_loss"]) / n, float(acc["sim_loss"]) / n))
             acc = {}
-        if (n_iter + 1) % args.eval_iters == 0 and rank == 0 and args.save_ckpt:
-            os.makedirs(args.ckpt_dir, exist_ok=True)
-            sd = wrapped.state_dict() if distributed else {"module." + k: v for k, v in model.state_dict().items()}
-            torch.save(sd, os.path.join(args.ckpt_dir, "checkpoint.pth"))     # keys prefixed `module.` (train_final_voc.py:519)
-            torch.save({"n_iter": n_iter + 1, "optimizer": optim.state_dict()}, os.path.join(args.ckpt_dir, "optimizer.pth"))
+        leaving = n_iter + 1 == last_iter and last_iter < args.max_iters     # --stop_iter: keep what the job has done
+        if ((n_iter + 1) % args.eval_iters == 0 or leaving) and rank == 0 and args.save_ckpt:
+            _save_resume_state(args.ckpt_dir, wrapped if distributed else None, model, optim, n_iter + 1)
         if (n_iter + 1) % args.eval_iters == 0 and rank == 0:
             # in-loop validation on rank 0 (train_final_voc.py:521-533); with no dataset mounted a few synthetic
             # native-size samples stand in for the val split so that the path is exercised end to end

@@ -459,7 +459,8 @@ def test_single_student_gradients_vs_oracle_autograd(dev, S, second):
 
 
 @pytest.mark.parametrize("gemm_mode,case", [("f16x3", "voc_B"), ("f16x3", "coco_B2"), ("f16x3", "voc_C"), ("f16x3", "voc_B_bs4"),
-                                            ("f16x3", "coco_B2_bs2_vit21k"), ("f32", "voc_B"), ("f32", "voc_B_bs4")],
+                                            ("f16x3", "voc_B_bs2"), ("f16x3", "coco_B2_bs2_vit21k"), ("f32", "voc_B"),
+                                            ("f32", "voc_B_bs4")],
                          indirect=["gemm_mode"])
 def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     """BASELINE configs at FULL size: dual-student ViT-B/16, 448^2 -- the whole step (ms-CAM at three scales, dual
@@ -467,7 +468,8 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     forward/backward, the GMM filter and the consistency loss; coco_B2 has 81 classes and the COCO schedule) against the
     CPU oracle run on this box's host cores (~10-40 s per image).  voc_B_bs4 is EXACTLY the bench workload (BASELINE
     configs[1]: 4 images on one GPU, the batch at which the GEMM launcher picks its production tile / split-K
-    instantiations); coco_B2_bs2_vit21k is the per-GPU batch of configs[3]/[4] (2 images, 81 classes) built through the
+    instantiations); voc_B_bs2 is the per-rank workload of configs[2] (VOC bs 4 on 2 GPUs = 2 images per GPU, PAR +
+    multi-scale CAM {0.5, 1.0, 1.5}: other GEMM grids, other tile choices); coco_B2_bs2_vit21k is the per-GPU batch of configs[3]/[4] (2 images, 81 classes) built through the
     `vit_base_patch16_224` factory of configs[4].  Bars: CAM max-abs-diff < 1e-3 (north_star), identical pseudo-label
     maps, refined label maps identical except at PROVEN argmax ties (oracle decision margin < 1e-5 at every
     mismatching pixel), loss pieces 1e-4, gradients of a spread of tensors 2e-3.  gemm_mode: the forward Linears on the
@@ -481,8 +483,8 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     cfg = O.VIT_BASE
     coco = case.startswith("coco")
     NC = 81 if coco else 21
-    n_iter = {"voc_B": 5000, "coco_B2": 20000, "voc_C": 9000, "voc_B_bs4": 5000, "coco_B2_bs2_vit21k": 20000}[case]
-    nimg = {"voc_B_bs4": 4, "coco_B2_bs2_vit21k": 2}.get(case, 1)
+    n_iter = {"voc_B": 5000, "coco_B2": 20000, "voc_C": 9000, "voc_B_bs4": 5000, "voc_B_bs2": 5000, "coco_B2_bs2_vit21k": 20000}[case]
+    nimg = {"voc_B_bs4": 4, "voc_B_bs2": 2, "coco_B2_bs2_vit21k": 2}.get(case, 1)
     backbone = "vit_base_patch16_224" if case.endswith("vit21k") else "deit_base_patch16_224"
     targs = trainer.coco_step_args() if coco else trainer.StepArgs()
     oargs = O.coco_step_args() if coco else O.StepArgs()
@@ -577,8 +579,8 @@ def test_ragged_shapes_step_vs_oracle(dev, b, H, W):
         assert float((out[k].cpu() - pc[k]).abs().max()) < 1e-4, k
     for k in ("pseudo_label_aux_1", "pseudo_label_aux_2"):
         assert torch.equal(out[k].cpu().long(), pc[k].long()), k
-    for k in ("refined_1", "refined_2"):
-        assert int((out[k].cpu().long() != pc[k].long()).sum()) <= 4, k
+    for k in ("refined_1", "refined_2"):   # identical up to PROVEN ties (oracle decision margin), never a count budget
+        assert_labels_equal_up_to_ties(out[k], pc[k], pc["refined_margin_" + k[-1]], f"ragged {b}x{H}x{W} {k}", max_frac=1e-3)
     for k in watch:
         got = model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True).cpu()
         e = float((got - leaf[k].grad).abs().max() / leaf[k].grad.abs().max())

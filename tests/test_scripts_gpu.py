@@ -141,10 +141,16 @@ def test_train_final_coco_on_a_dataset_folder(dev, tmp_path):
     assert "Iter: 5;" in out and "val cls score" in out and "mIoU" in out
 
 
-def test_ddp_exchange_on_gpu_world1(dev):
+@pytest.mark.parametrize("delay", [0, 1])
+def test_ddp_exchange_on_gpu_world1(dev, delay):
     """RCCL all-reduce path (forced at world 1) gives the same gradients as the plain step; exercises the post-backward
-    hooks, the autograd-engine finalise callback and the stream ordering with two student streams."""
+    hooks, the autograd-engine finalise callback and the stream ordering with two student streams.
+    delay = 1: after every bucket hand-off a ~10 ms spin kernel is queued on the student stream, so the producers of the
+    NEXT bucket run long after the host has already called all_reduce on it -- a missing dependency of RCCL's stream on
+    the producing stream (ddp.py: all_reduce(async_op=True) relies on the current stream being the student's) would reduce
+    stale memory and the comparison with the plain step fails; a second GPU is not needed to see that."""
     code = r'''
+DELAY = int(__import__("os").environ.get("DUPL_TEST_DELAY", "0"))
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["DUPL_ROOT"])
 from oracle import dupl_oracle as O
@@ -172,6 +178,8 @@ for n_iter in (5000, 9000):          # phase B: one forward per student; phase C
             def spy(lo, hi, issue=issue, store=m.flat_storage):
                 snaps.append((lo, hi, store.grad[lo:hi].clone()))   # stream-ordered snapshot at issue time
                 issue(lo, hi)
+                if DELAY:
+                    torch.cuda._sleep(20_000_000)                    # stall the producing stream before the next bucket
             w.reducer._issue = spy
         loss, out = trainer.compute_losses(w, par, inputs.to(dev), cls_label.to(dev), img_box, n_iter, trainer.StepArgs(), cls_label,
                                            inputs_aug=aug if n_iter >= 8000 else None)
@@ -194,8 +202,8 @@ for n_iter in (5000, 9000):          # phase B: one forward per student; phase C
     assert len(snaps) >= 2 * 4, "per-layer buckets were not used"
 dist.destroy_process_group()
 '''
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DUPL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613",
-               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DUPL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29613 + delay),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", DUPL_TEST_DELAY=str(delay))
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DDP_REL_ERR" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
@@ -368,6 +376,8 @@ def test_bench_multi_rank_control_flow(dev):
     cm = d["comm"]
     assert cm["world"] == 2 and cm["backend"] == "gloo" and cm["allreduce_bytes"] == cm["grad_bytes_per_rank"] > 7.0e8
     assert cm["allreduce_calls"] >= 16 and cm["comm_exposed_ms"] >= 0.0
+    # the run validates its own exchange: bit-identical parameter buffers on all ranks after the steps, world == --gpus
+    assert cm["params_identical_on_all_ranks"] is True and cm["world_matches_gpus"] is True and len(cm["param_checksum"]) == 2
     # second field: the N = 1 workload (VOC, 4 img/GPU) on both ranks = the weak-scaling point
     w4 = d["weak_4img_per_gpu"]
     assert w4 is not None and w4["comm"]["world"] == 2 and "4 img/GPU" in w4["workload"]
