@@ -484,6 +484,9 @@ def main():
                           "deterministic": os.environ.get("DUPL_DETERMINISTIC", "0") == "1",
                           "loss": round(res["loss"], 5)},
                "comm": res["comm"], "weak_4img_per_gpu": weak4, "exact_f32_path": exact,
+               # f16x3 operand planes have fp16's range: sites whose operands could leave it (rigorous bounds from the
+               # parameters, engine.RangeGuard) run on the exact-f32 kernels; 0 = the whole step ran on the split kernels
+               "range_guard": (wl.model.flat_storage.guard.summary() if gemm_mode == "f16x3" else None),
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec))
     if world > 1:

@@ -102,8 +102,12 @@ constexpr float DUPL_LO_SCALE = 2048.f;
 // f16 conversion for one of the two uses below (v_fma_mixlo_f16 on the exact product) but not for the other
 // (v_cvt_pk_f16_f32 of the fp32-rounded product): where the two roundings differ, `hi` and the residual behind `lo`
 // disagree by one fp16 ulp of hi -- a rare, data-dependent 2^-11 relative error (found in the dk kernel).
+// Range: finite |x| > 65504 saturates -- tensors that could get there are kept off this path by the range guard
+// (engine.RangeGuard, csrc/range.hip); NaN / Inf propagate as in fp32 arithmetic (hi = NaN / Inf, lo = NaN), they are not
+// laundered into finite values (fmaxf(NaN, a) = a would do that).
 __device__ __forceinline__ void split_f32(float x, __half& hi, __half& lo) {
-    x = fminf(fmaxf(x, -65504.f), 65504.f);
+    const float c = fminf(fmaxf(x, -65504.f), 65504.f);
+    x = fabsf(x) <= 3.0e38f ? c : x;
     asm volatile("" : "+v"(x));
     hi = __float2half_rn(x);
     lo = __float2half_rn((x - __half2float(hi)) * DUPL_LO_SCALE);

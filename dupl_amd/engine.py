@@ -150,6 +150,7 @@ class FlatStorage:
         self.dirty = 0
         self._w16_key = [None] * n_students
         self._w16T: Dict = {}
+        self.guard = RangeGuard(self)
 
     def wait_streams(self):
         """Make the current stream wait for everything queued on the student streams."""
@@ -186,7 +187,10 @@ class FlatStorage:
         n, base = self.student_numel, student * self.student_numel
         ops.L().dupl_split_f16x2(self.data.data_ptr() + 4 * base, self.data16.data_ptr() + 2 * base,
                                  self.data16.data_ptr() + 2 * (self.data.numel() + base), n, ops._stream())
+        old = self._w16_key[student]
         self._w16_key[student] = key
+        # the operands changed: re-check their range (synchronously unless this was an optimiser step)
+        self.guard.params_changed(student, rewritten=(old is None or old[0] != key[0] or old[2] != key[2]))
 
     def w16T(self, student: int, key: str, rows: int):
         """Operand planes of the TRANSPOSE of parameter `key` ([rows, cols] -> planes [cols, rows]): the B operand of the data
@@ -234,6 +238,175 @@ class FlatStorage:
         out.append((s + self.seg_bounds[SEG_BACKBONE][0], s + self.block_range(i - 1)[1], "stem"))
         out.append((s + self.seg_bounds[SEG_NORM][0], s + self.seg_bounds[SEG_NORM][1], "stem"))
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# range guard of the f16x3 operand planes
+# ------------------------------------------------------------------------------------------------
+F16_MAX = 65504.0
+
+
+class RangeGuard:
+    """Keeps every tensor that is written as fp16 hi / lo planes inside fp16's exponent range BY CONSTRUCTION.
+
+    The split format x = hi + lo / 2048 (csrc/gemm_split.hip) saturates at |x| = 65504, the reference's fp32 at 3.4e38
+    (deit.py:102-108 loads pretrained weights: outlier channels are real).  For every Linear / attention of a student a
+    rigorous bound on its operands follows from the parameters alone (csrc/range.hip):
+        LayerNorm out  |y_j| <= max|gamma| sqrt(D) + max|beta|,  ||y||_2 <= max|gamma| sqrt(D) + ||beta||_2
+        Linear out     |(W y + b)_j| <= ||y||_2 max_j ||W_j||_2 + max|b|;   GELU, ReLU, softmax-weighted means: |f(x)| <= |x|
+    A site whose operand bound (activation side or weight max-abs), times `margin`, exceeds 65504 runs on the exact-f32
+    MFMA kernels instead -- forward and backward, its producer then hands it fp32 instead of planes -- so an operand
+    beyond fp16's range gets the fp32 answer, never a clamp.  Gradients are scaled from their own max-abs on the device
+    (split_prepare) and cannot saturate.  The image itself is the one operand without a parameter bound: the patch
+    embedding assumes |pixel| <= 65504 / margin (normalised images are < 3).
+
+    Freshness: a wholesale parameter rewrite (load_state_dict, .copy_: torch version counter / address change) is checked
+    synchronously before the next forward; optimiser steps (raw-pointer writes, FlatStorage.mark_dirty) move a weight by
+    <= lr per step, so they are re-checked every `period` steps from an ASYNCHRONOUS device -> pinned-host copy (no
+    host-device synchronisation on the step path) -- what `margin` = 2 is for."""
+
+    SITES = ("qkv", "attn", "proj", "fc1", "fc2")
+
+    def __init__(self, store: "FlatStorage", margin: float = 2.0, period: int = 8):
+        self.store, self.margin, self.period = store, float(margin), int(period)
+        cfg = store.cfg
+        self.entries: List[Tuple[str, int, int]] = []        # (key, rows, cols) in table order
+        D, Hd, dd = cfg.embed_dim, cfg.embed_dim * cfg.mlp_ratio, cfg.decoder_dim
+
+        def add(key, rows):
+            n = store.layout[key][1]
+            self.entries.append((key, rows, n // rows))
+
+        add("encoder.patch_embed.proj.weight", D)
+        for i in range(cfg.depth):
+            p = f"encoder.blocks.{i}."
+            for k, r in ((p + "norm1.weight", 1), (p + "norm1.bias", 1), (p + "attn.qkv.weight", 3 * D), (p + "attn.qkv.bias", 1),
+                         (p + "attn.proj.weight", D), (p + "norm2.weight", 1), (p + "norm2.bias", 1), (p + "mlp.fc1.weight", Hd),
+                         (p + "mlp.fc1.bias", 1), (p + "mlp.fc2.weight", D)):
+                add(k, r)
+        for k, r in (("encoder.norm.weight", 1), ("encoder.norm.bias", 1), ("decoder.conv6.weight", dd), ("decoder.conv7.weight", dd)):
+            add(k, r)
+        self.index = {k: i for i, (k, _, _) in enumerate(self.entries)}
+        self._table = None          # device descriptor table (offsets relative to a student's base)
+        self._dev_out = None        # [n_students, n, 2] device floats
+        self._host = None           # pinned mirror
+        self._event = None
+        self._pending = False
+        self._steps = [0] * store.n_students
+        self.safe: List[Optional[dict]] = [None] * store.n_students      # per student: site flags, None = not computed yet
+        self.headroom = float("inf")   # min over sites of 65504 / (margin * bound) at the last check (< 1: some site is on f32)
+        self.checks = 0
+
+    # ---- device side
+    def _ensure_buffers(self):
+        dev = self.store.data.device
+        if self._table is None or self._table.device != dev:
+            import numpy as np
+            tab = np.zeros((len(self.entries), 2), dtype=np.int64)     # {int64 offset, int32 rows | int32 cols << 32}
+            for i, (k, rows, cols) in enumerate(self.entries):
+                tab[i, 0] = self.store.layout[k][0]
+                tab[i, 1] = rows | (cols << 32)
+            self._table = torch.from_numpy(tab).to(dev)
+            self._dev_out = torch.zeros((self.store.n_students, len(self.entries), 2), device=dev, dtype=torch.float32)
+            self._host = torch.zeros((self.store.n_students, len(self.entries), 2), dtype=torch.float32).pin_memory()
+            self._event = torch.cuda.Event()
+
+    def _launch(self, students):
+        self._ensure_buffers()
+        st = self.store
+        for s in students:
+            ops.L().dupl_param_bounds(st.data.data_ptr() + 4 * s * st.student_numel, self._table.data_ptr(), len(self.entries),
+                                      self._dev_out[s].data_ptr(), ops._stream())
+        self._host.copy_(self._dev_out, non_blocking=True)
+        self._event.record()
+        self._pending = True
+
+    def _harvest(self, wait: bool):
+        if not self._pending:
+            return
+        if wait:
+            self._event.synchronize()
+        elif not self._event.query():
+            return
+        self._pending = False
+        self.headroom = float("inf")
+        for s in range(self.store.n_students):
+            self.safe[s] = self._decide(self._host[s].double().numpy())
+        self.checks += 1
+
+    # ---- host side
+    def _decide(self, v):
+        """v[e] = (max-abs, largest row L2 norm) per table entry -> {site: f16-safe?}."""
+        cfg = self.store.cfg
+        sq = float(cfg.embed_dim) ** 0.5
+        lim = F16_MAX / self.margin
+        ix = self.index
+        worst = [0.0]
+
+        def ok(*bounds):
+            b = max(bounds)
+            worst[0] = max(worst[0], b)
+            return bool(b <= lim)           # NaN / inf -> False
+
+        def amax(k):
+            return v[ix[k], 0]
+
+        def rown(k):
+            return v[ix[k], 1]
+
+        out = {"patch": ok(amax("encoder.patch_embed.proj.weight")), "blocks": []}
+        for i in range(cfg.depth):
+            p = f"encoder.blocks.{i}."
+            g1, g2 = amax(p + "norm1.weight"), amax(p + "norm2.weight")
+            el1, n1 = g1 * sq + amax(p + "norm1.bias"), g1 * sq + rown(p + "norm1.bias")
+            el2, n2 = g2 * sq + amax(p + "norm2.bias"), g2 * sq + rown(p + "norm2.bias")
+            e_qkv = n1 * rown(p + "attn.qkv.weight") + amax(p + "attn.qkv.bias")
+            e_h = n2 * rown(p + "mlp.fc1.weight") + amax(p + "mlp.fc1.bias")
+            out["blocks"].append({
+                "qkv": ok(el1, amax(p + "attn.qkv.weight")),
+                "attn": ok(e_qkv),
+                "proj": ok(e_qkv, amax(p + "attn.proj.weight")),
+                "fc1": ok(el2, amax(p + "mlp.fc1.weight")),
+                "fc2": ok(e_h, amax(p + "mlp.fc2.weight")),
+            })
+        gf = amax("encoder.norm.weight")
+        elf, nf = gf * sq + amax("encoder.norm.bias"), gf * sq + rown("encoder.norm.bias")
+        e_c6 = 3.0 * nf * rown("decoder.conv6.weight")                   # 9 taps: ||patch||_2 <= 3 max ||token||_2
+        out["conv6"] = ok(elf, amax("decoder.conv6.weight"))
+        out["conv7"] = ok(e_c6, amax("decoder.conv7.weight"))
+        self.headroom = min(self.headroom, float(lim / max(worst[0], 1e-30)))
+        return out
+
+    def params_changed(self, student: int, rewritten: bool):
+        """Called by FlatStorage.ensure_w16 when the operand planes of a student are rebuilt.  rewritten: the buffer was
+        replaced or written through torch (load_state_dict, copy_) rather than by an optimiser step."""
+        if rewritten or self.safe[student] is None:
+            self._launch(range(self.store.n_students))
+            self._harvest(wait=True)
+            self._steps = [0] * self.store.n_students
+            return
+        self._steps[student] += 1
+        if student == 0 and self._steps[0] % self.period == 0 and not self._pending:
+            self._launch(range(self.store.n_students))
+
+    def sites(self, student: int) -> dict:
+        self._harvest(wait=False)
+        if self.safe[student] is None:
+            self._launch(range(self.store.n_students))
+            self._harvest(wait=True)
+        return self.safe[student]
+
+    def summary(self) -> dict:
+        """For logs / bench.py: how many sites run on the f32 kernels because their operands could leave fp16's range."""
+        self._harvest(wait=False)
+        n = 0
+        for s in self.safe:
+            if s is None:
+                continue
+            n += sum(not s[k] for k in ("patch", "conv6", "conv7")) + sum(not b[k] for b in s["blocks"] for k in self.SITES)
+        return {"sites_on_f32": n, "checks": self.checks, "margin": self.margin,
+                "headroom": (None if self.headroom == float("inf") else round(self.headroom, 1))}
+
 
 
 class StudentParams:
@@ -361,15 +534,19 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
     W = P.w
     assert not (save and len(xs) > 1)
     P.store.ensure_w16(P.student)
+    guard = P.store.guard.sites(P.student)      # which sites may run on fp16 planes (RangeGuard); the others run on f32
     toks, groups = [], []
     r0 = 0
     for x in xs:
         B, _, Himg, Wimg = x.shape
         h, w = Himg // cfg.patch, Wimg // cfg.patch
         n = h * w
-        rows16 = ops.split16(ops.patch_im2row(x, cfg.patch))
-        patch, _ = ops.linear16(rows16, P.w16("encoder.patch_embed.proj.weight", D), W["encoder.patch_embed.proj.bias"])
-        del rows16
+        if guard["patch"]:
+            rows16 = ops.split16(ops.patch_im2row(x, cfg.patch))
+            patch, _ = ops.linear16(rows16, P.w16("encoder.patch_embed.proj.weight", D), W["encoder.patch_embed.proj.bias"])
+            del rows16
+        else:
+            patch = ops.linear(ops.patch_im2row(x, cfg.patch), W["encoder.patch_embed.proj.weight"], W["encoder.patch_embed.proj.bias"])
         toks.append(ops.assemble_tokens(patch, W["encoder.cls_token"], P.pos_embed_for(h, w), B, n, D))
         groups.append((r0, B, n + 1, h, w))
         r0 += B * (n + 1)
@@ -385,37 +562,54 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
     scale = hd ** -0.5
     for i in range(cfg.depth):
         p = f"encoder.blocks.{i}."
-        ln1, ln1_16, m1, r1 = ops.layernorm_fwd16(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, save, want_f32=save)
+        g = guard["blocks"][i]
+        attn16 = hd == 64 and g["attn"]          # q, k, v as planes into the split attention kernel
+        ln1, ln1_16, m1, r1 = ops.layernorm_fwd16(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, save,
+                                                  want_f32=save or not g["qkv"])
         lse = None
-        if hd == 64:
-            # q, k, v stay fp16 planes end to end: the qkv GEMM writes them, the split attention kernel reads them and
-            # writes the planes the projection GEMM consumes; fp32 copies only where the backward needs them (save)
-            qkv, qkv16 = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"], want_f32=save,
-                                      want16=True)
-            del ln1_16
-            att = torch.empty((R, D), device=t.device, dtype=torch.float32) if save else None
-            att16 = ops.split16_empty(R, D, t.device)
-            for (g0, B, N, _, _) in groups:
+        # q, k, v stay fp16 planes end to end where their range allows: the qkv GEMM writes them, the split attention kernel
+        # reads them and writes the planes the projection GEMM consumes; fp32 copies only where the backward (save) or an
+        # f32-routed consumer needs them
+        if g["qkv"]:
+            qkv, qkv16 = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"],
+                                      want_f32=save or not attn16, want16=attn16)
+        else:
+            qkv = ops.linear(ln1, W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"])
+            qkv16 = ops.split16(qkv) if attn16 else None
+        del ln1_16
+        need_att32 = save or not g["proj"]
+        att = torch.empty((R, D), device=t.device, dtype=torch.float32) if (need_att32 or not attn16) else None
+        att16 = ops.split16_empty(R, D, t.device) if (attn16 and g["proj"]) else None
+        for (g0, B, N, _, _) in groups:
+            if attn16:
                 lse = ops.attention_fwd16(qkv16.rows_slice(g0, g0 + B * N), B, N, H, hd, scale, need_lse=save,
-                                          out=att[g0:g0 + B * N] if save else None, out16=att16.rows_slice(g0, g0 + B * N))
-            qkv16_keep = qkv16 if save else None
-            del qkv16
-        else:   # other head dims (the 96-dim test backbone): exact-f32 attention kernel between split GEMMs
-            qkv, _ = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"])
-            del ln1_16
-            att = torch.empty((R, D), device=t.device, dtype=torch.float32)
-            for (g0, B, N, _, _) in groups:
+                                          out=att[g0:g0 + B * N] if att is not None else None,
+                                          out16=att16.rows_slice(g0, g0 + B * N) if att16 is not None else None)
+            else:   # other head dims (the 96-dim test backbone) or q / k / v beyond fp16's range: exact-f32 attention kernel
                 _, lse = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
+        if not attn16 and g["proj"]:
             att16 = ops.split16(att)
-            qkv16_keep = None
-        x_mid, _ = ops.linear16(att16, P.w16(p + "attn.proj.weight", D), W[p + "attn.proj.bias"], res=t)
+        qkv16_keep = qkv16 if (save and attn16) else None
+        del qkv16
+        if g["proj"]:
+            x_mid, _ = ops.linear16(att16, P.w16(p + "attn.proj.weight", D), W[p + "attn.proj.bias"], res=t)
+        else:
+            x_mid = ops.linear(att, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], res=t)
         del att16
-        ln2, ln2_16, m2, r2 = ops.layernorm_fwd16(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save, want_f32=save)
+        ln2, ln2_16, m2, r2 = ops.layernorm_fwd16(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save,
+                                                  want_f32=save or not g["fc1"])
         pre1 = torch.empty((R, D * cfg.mlp_ratio), device=t.device, dtype=torch.float32) if save else None
-        h1, h1_16 = ops.linear16(ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio), W[p + "mlp.fc1.bias"], gelu=True,
-                                 store_pre=pre1, want_f32=save, want16=True)
+        if g["fc1"]:
+            h1, h1_16 = ops.linear16(ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio), W[p + "mlp.fc1.bias"], gelu=True,
+                                     store_pre=pre1, want_f32=save or not g["fc2"], want16=g["fc2"])
+        else:
+            h1 = ops.linear(ln2, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], gelu=True, store_pre=pre1)
+            h1_16 = ops.split16(h1) if g["fc2"] else None
         del ln2_16
-        x_out, _ = ops.linear16(h1_16, P.w16(p + "mlp.fc2.weight", D), W[p + "mlp.fc2.bias"], res=x_mid)
+        if g["fc2"]:
+            x_out, _ = ops.linear16(h1_16, P.w16(p + "mlp.fc2.weight", D), W[p + "mlp.fc2.bias"], res=x_mid)
+        else:
+            x_out = ops.linear(h1, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"], res=x_mid)
         del h1_16
         if save:
             sv.blocks.append(BlockSaved(x_in=t, mean1=m1, rstd1=r1, ln1=ln1, qkv=qkv, lse=lse, att=att, x_mid=x_mid,
@@ -571,14 +765,17 @@ def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
     col6 = torch.empty((B * n, 9 * D), device=x.device, dtype=torch.float32)
     ops.L().dupl_im2col_dil3(tf.data_ptr() + 4 * D, col6.data_ptr(), B, h, w, D, dil, D, (n + 1) * D, ops._stream())
     f16 = GEMM_MODE == "f16x3"        # the two 3x3 convs (K = 9 * 768 / 9 * 512) as split GEMMs; conv8 (N = classes) stays f32
+    guard = None
     if f16:
         P.store.ensure_w16(P.student)
+        guard = P.store.guard.sites(P.student)
+    if f16 and guard["conv6"]:
         h6, _ = ops.linear16(ops.split16(col6), P.w16("decoder.conv6.weight", dd), relu=True)
     else:
         h6 = ops.linear(col6, P.w["decoder.conv6.weight"].view(dd, -1), relu=True)
     col7 = torch.empty((B * n, 9 * dd), device=x.device, dtype=torch.float32)
     ops.L().dupl_im2col_dil3(h6.data_ptr(), col7.data_ptr(), B, h, w, dd, dil, dd, n * dd, ops._stream())
-    if f16:
+    if f16 and guard["conv7"]:
         h7, _ = ops.linear16(ops.split16(col7), P.w16("decoder.conv7.weight", dd), relu=True)
     else:
         h7 = ops.linear(col7, P.w["decoder.conv7.weight"].view(dd, -1), relu=True)
@@ -662,11 +859,14 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         ops.nchw_to_tokens_add(dseg.contiguous(), dseg_tok, B, n, NC, skip_cls=False)
         ops.linear_wgrad(dseg_tok, sv.h7, G["decoder.conv8.weight"], accumulate=True)
         dh7 = ops.linear_dgrad(dseg_tok, W["decoder.conv8.weight"].view(NC, dd), relumask_of=sv.h7)
-        conv_bwd = _linear_backward16 if GEMM_MODE == "f16x3" else _linear_backward32
+        f16 = GEMM_MODE == "f16x3"
+        guard = P.store.guard.sites(P.student) if f16 else None
+        conv_bwd = _linear_backward16 if (f16 and guard["conv7"]) else _linear_backward32
         dcol7 = conv_bwd(P, dh7, sv.col7, "decoder.conv7", has_bias=False)
         dh6 = torch.empty((B * n, dd), device=dev, dtype=torch.float32)
         ops.L().dupl_col2im_dil3(dcol7.data_ptr(), dh6.data_ptr(), B, h, w, dd, dil, dd, n * dd, 0, sv.h6.data_ptr(), ops._stream())
         del dcol7
+        conv_bwd = _linear_backward16 if (f16 and guard["conv6"]) else _linear_backward32
         dcol6 = conv_bwd(P, dh6, sv.col6, "decoder.conv6", has_bias=False)
         ops.L().dupl_col2im_dil3(dcol6.data_ptr(), dtf.data_ptr() + 4 * D, B, h, w, D, dil, D, N * D, 1, None, ops._stream())
         del dcol6
@@ -684,20 +884,24 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         s = enc.blocks[i]
         if dta is not None and i == aux_idx:
             ops.axpy_(dx, dta, 1.0)
-        lin_bwd = _linear_backward16 if GEMM_MODE == "f16x3" else _linear_backward32
+        f16 = GEMM_MODE == "f16x3"
+        g = P.store.guard.sites(P.student)["blocks"][i] if f16 else None
+
+        def lin_bwd(site):      # the site's backward runs where its forward ran: same operands, same range verdict
+            return _linear_backward16 if (f16 and g[site]) else _linear_backward32
         # MLP
-        dpre1 = lin_bwd(P, dx, s.h1, p + "mlp.fc2", dgelu_of=s.pre1)
-        dln2 = lin_bwd(P, dpre1, s.ln2, p + "mlp.fc1")
+        dpre1 = lin_bwd("fc2")(P, dx, s.h1, p + "mlp.fc2", dgelu_of=s.pre1)
+        dln2 = lin_bwd("fc1")(P, dpre1, s.ln2, p + "mlp.fc1")
         del dpre1
         dx_mid = ops.layernorm_bwd(dln2, s.x_mid, W[p + "norm2.weight"], s.mean2, s.rstd2,
                                    G[p + "norm2.weight"], G[p + "norm2.bias"], dres=dx)
         # attention
-        datt = lin_bwd(P, dx_mid, s.att, p + "attn.proj")
-        if GEMM_MODE == "f16x3" and s.qkv16 is not None and N <= 2048:
+        datt = lin_bwd("proj")(P, dx_mid, s.att, p + "attn.proj")
+        if f16 and s.qkv16 is not None and N <= 2048:
             dqkv = ops.attention_bwd16(s.qkv16, s.att, datt, s.lse, B, N, Hh, hd, scale)
         else:
             dqkv = ops.attention_bwd(s.qkv, s.att, datt, s.lse, B, N, Hh, hd, scale)
-        dln1 = lin_bwd(P, dqkv, s.ln1, p + "attn.qkv")
+        dln1 = lin_bwd("qkv")(P, dqkv, s.ln1, p + "attn.qkv")
         del dqkv, datt
         dx = ops.layernorm_bwd(dln1, s.x_in, W[p + "norm1.weight"], s.mean1, s.rstd1,
                                G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid)

