@@ -26,6 +26,15 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __re
     }
 }
 
+// One bilinear tap group, with every rounding pinned (no compiler-chosen FMA contraction): both fusion kernels below must
+// produce the same bits.   v = hy * ((1 - lx) a + lx b) + ly * ((1 - lx) c + lx d)
+__device__ __forceinline__ float bil_blend(float hy, float ly, float lx, float a, float b, float c, float d) {
+    const float hx = __fsub_rn(1.f, lx);
+    const float top = __fmaf_rn(lx, b, __fmul_rn(hx, a));
+    const float bot = __fmaf_rn(lx, d, __fmul_rn(hx, c));
+    return __fmaf_rn(ly, bot, __fmul_rn(hy, top));
+}
+
 struct CamFuseDesc {
     const float* low[4];   // token-major CAM logits [2B][rows][ldc]  (rows = row_off + hs*ws)
     int hs[4], ws[4];
@@ -57,15 +66,129 @@ __global__ __launch_bounds__(256) void cam_fuse_kernel(CamFuseDesc d, float* __r
             const float* p = d.low[s] + ((long)b * rows + d.row_off) * d.ldc + c;
             const float* q = d.low[s] + ((long)(B + b) * rows + d.row_off) * d.ldc + c;
             const float hy = 1.f - ly;
-            const float v1 = hy * ((1.f - lx) * p[(long)(y0 * ws + x0) * d.ldc] + lx * p[(long)(y0 * ws + x1) * d.ldc]) +
-                             ly * ((1.f - lx) * p[(long)(y1 * ws + x0) * d.ldc] + lx * p[(long)(y1 * ws + x1) * d.ldc]);
-            const float v2 = hy * ((1.f - lf) * q[(long)(y0 * ws + f0) * d.ldc] + lf * q[(long)(y0 * ws + f1) * d.ldc]) +
-                             ly * ((1.f - lf) * q[(long)(y1 * ws + f0) * d.ldc] + lf * q[(long)(y1 * ws + f1) * d.ldc]);
+            const float v1 = bil_blend(hy, ly, lx, p[(long)(y0 * ws + x0) * d.ldc], p[(long)(y0 * ws + x1) * d.ldc],
+                                       p[(long)(y1 * ws + x0) * d.ldc], p[(long)(y1 * ws + x1) * d.ldc]);
+            const float v2 = bil_blend(hy, ly, lf, q[(long)(y0 * ws + f0) * d.ldc], q[(long)(y0 * ws + f1) * d.ldc],
+                                       q[(long)(y1 * ws + f0) * d.ldc], q[(long)(y1 * ws + f1) * d.ldc]);
             acc += fmaxf(fmaxf(v1, v2), 0.f);
         }
         cam[(long)plane * HW + i] = acc;
         vmin = fminf(vmin, acc);
         vmax = fmaxf(vmax, acc);
+    }
+    vmin = -block_max(-vmin, red);
+    vmax = block_max(vmax, red);
+    if (threadIdx.x == 0) {
+        atomic_min_f(&mm[2 * plane + 0], vmin);
+        atomic_max_f(&mm[2 * plane + 1], vmax);
+    }
+}
+
+// The same fusion, restructured for HBM (round 3): the strided token-major reads (8 taps x nscale per pixel at stride ldc,
+// 0.46 TB/s of output in the per-pixel kernel above) go through LDS.  One block = one (b, c) plane x one band of output rows:
+// it stages, per scale, the few low-resolution rows of (b, c) and of the flipped image (B + b, c) that the band touches
+// (<= band * hs / H + 2 rows of ws floats), then every thread produces 4 consecutive pixels per item from LDS taps and
+// writes one float4 per row.  The arithmetic per pixel is the expression of cam_fuse_kernel, token for token (bit-identical output:
+// tests/test_kernels_gpu.py::test_cam_fuse_band_kernel_is_bit_identical).  Needs W % 4 == 0.
+constexpr int CAM_BAND_MAX_LDS = 60 * 1024;
+template <int NS>
+__global__ __launch_bounds__(256) void cam_fuse_band_kernel(CamFuseDesc d, float* __restrict__ cam, float* __restrict__ mm, int B,
+                                                            int C, int H, int W, int band) {
+    extern __shared__ float lds[];
+    __shared__ float red[16];
+    const int plane = blockIdx.y;
+    const int b = plane / C, c = plane - b * C;
+    const int ya = blockIdx.x * band, yb = min(H, ya + band);      // output rows [ya, yb)
+    // ---- stage: per scale the low-res rows [r0_s, r1_s] of both images
+    int base[NS + 1], r0s[NS];             // statically indexed (unrolled loops): registers, not scratch
+    int off = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int hs = d.hs[s], ws = d.ws[s];
+        const float sy = (float)hs / (float)H;
+        int y0, y1, t0, t1;
+        float ly;
+        bil_src(ya, sy, hs, false, y0, t1, ly);
+        bil_src(yb - 1, sy, hs, false, t0, y1, ly);
+        const int nr = y1 - y0 + 1;
+        base[s] = off;
+        r0s[s] = y0;
+        const long rows = d.row_off + hs * ws;
+        const float* p = d.low[s] + ((long)b * rows + d.row_off) * d.ldc + c;
+        const float* q = d.low[s] + ((long)(B + b) * rows + d.row_off) * d.ldc + c;
+        for (int i = threadIdx.x; i < nr * ws; i += 256) {
+            lds[off + i] = p[(long)(y0 * ws + i) * d.ldc];
+            lds[off + nr * ws + i] = q[(long)(y0 * ws + i) * d.ldc];
+        }
+        off += 2 * nr * ws;
+    }
+    base[NS] = off;
+    __syncthreads();
+    // Every thread owns ONE quad of 4 consecutive columns (its horizontal weights per scale are computed once) and walks down
+    // the rows of the band; the 16 low-resolution values a quad needs per scale (2 rows x (x0, x1) x 4 pixels x {image,
+    // flipped image}) live in registers and are re-read from LDS only when the row pair (y0, y1) of that scale changes --
+    // every H / hs output rows, a block-uniform event.  What remains per pixel and row is the arithmetic.
+    const int W4 = W >> 2;
+    const int nrp = 256 / W4;                          // row phases per block (host guarantees W4 <= 256)
+    const int xq = threadIdx.x % W4, rp = threadIdx.x / W4;
+    const int x4 = xq << 2;
+    float wlx[NS][4], wlf[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float sx = (float)d.ws[s] / (float)W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int i0, i1;
+            bil_src(x4 + j, sx, d.ws[s], false, i0, i1, wlx[s][j]);
+            bil_src(W - 1 - (x4 + j), sx, d.ws[s], false, i0, i1, wlf[s][j]);
+        }
+    }
+    float pa[NS][4][4], qa[NS][4][4];                  // [scale][pixel][y0x0, y0x1, y1x0, y1x1] of the image / the flipped image
+    int cy0[NS], cy1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { cy0[s] = -1; cy1[s] = -1; }
+    float vmin = INFINITY, vmax = -INFINITY;
+    if (rp < nrp) {
+        for (int y = ya + rp; y < yb; y += nrp) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int hs = d.hs[s], ws = d.ws[s];
+                const float sy = (float)hs / (float)H;
+                int y0, y1;
+                float ly;
+                bil_src(y, sy, hs, false, y0, y1, ly);
+                if (y0 != cy0[s] || y1 != cy1[s]) {
+                    cy0[s] = y0;
+                    cy1[s] = y1;
+                    const int nrws = (base[s + 1] - base[s]) >> 1;
+                    const float* p = lds + base[s] + (y0 - r0s[s]) * ws;
+                    const float* p1 = lds + base[s] + (y1 - r0s[s]) * ws;
+                    const float sx = (float)ws / (float)W;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int x0, x1, f0, f1;
+                        float t;
+                        bil_src(x4 + j, sx, ws, false, x0, x1, t);
+                        bil_src(W - 1 - (x4 + j), sx, ws, false, f0, f1, t);
+                        pa[s][j][0] = p[x0]; pa[s][j][1] = p[x1];
+                        pa[s][j][2] = p1[x0]; pa[s][j][3] = p1[x1];
+                        qa[s][j][0] = p[nrws + f0]; qa[s][j][1] = p[nrws + f1];
+                        qa[s][j][2] = p1[nrws + f0]; qa[s][j][3] = p1[nrws + f1];
+                    }
+                }
+                const float hy = 1.f - ly;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v1 = bil_blend(hy, ly, wlx[s][j], pa[s][j][0], pa[s][j][1], pa[s][j][2], pa[s][j][3]);
+                    const float v2 = bil_blend(hy, ly, wlf[s][j], qa[s][j][0], qa[s][j][1], qa[s][j][2], qa[s][j][3]);
+                    acc[j] += fmaxf(fmaxf(v1, v2), 0.f);
+                }
+            }
+            *reinterpret_cast<float4*>(cam + (long)plane * H * W + (long)y * W + x4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            vmin = fminf(fminf(vmin, acc[0]), fminf(acc[1], fminf(acc[2], acc[3])));
+            vmax = fmaxf(fmaxf(vmax, acc[0]), fmaxf(acc[1], fmaxf(acc[2], acc[3])));
+        }
     }
     vmin = -block_max(-vmin, red);
     vmax = block_max(vmax, red);
@@ -178,6 +301,13 @@ extern "C" int dupl_resize_bilinear(const float* in, float* out, int32_t B, int3
     return dupl_launch_status();
 }
 
+static int g_cam_fuse_impl = 1;     // 1: LDS-staged band kernel (W % 4 == 0), 0: per-pixel kernel (A/B tests, odd widths)
+extern "C" int dupl_set_cam_fuse_impl(int32_t impl) {
+    if (impl != 0 && impl != 1) return DUPL_ERR_ARG;
+    g_cam_fuse_impl = impl;
+    return DUPL_OK;
+}
+
 extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const int32_t* ws, int32_t nscale, int32_t row_off,
                              int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
@@ -192,6 +322,27 @@ extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const 
     d.nscale = nscale; d.row_off = row_off; d.ldc = ldc;
     const int planes = B * C;
     hipLaunchKernelGGL(minmax_init_kernel, dim3((planes + 255) / 256), dim3(256), 0, (hipStream_t)s, mm, planes);
+    if (g_cam_fuse_impl == 1 && !(W & 3) && W <= 1024 && !(reinterpret_cast<uintptr_t>(cam) & 15)) {
+        // bands: enough blocks to fill the chip a few times over, at least 8 rows each
+        int nb = (2048 + planes - 1) / planes;
+        int band = (H + nb - 1) / nb;
+        if (band < 8) band = 8;
+        for (;; band = (band + 1) / 2) {       // LDS need of a band (upper bound): per scale 2 images x (band * hs / H + 3) rows x ws
+            size_t need = 0;
+            for (int i = 0; i < nscale; ++i) need += 2 * ((size_t)band * hs[i] / H + 3) * ws[i] * sizeof(float);
+            if (need <= (size_t)CAM_BAND_MAX_LDS || band <= 1) {
+                if (need > (size_t)CAM_BAND_MAX_LDS) break;      // does not fit even at one row: per-pixel kernel below
+                const dim3 grid((H + band - 1) / band, planes);
+                switch (nscale) {
+                    case 1: hipLaunchKernelGGL(cam_fuse_band_kernel<1>, grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); break;
+                    case 2: hipLaunchKernelGGL(cam_fuse_band_kernel<2>, grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); break;
+                    case 3: hipLaunchKernelGGL(cam_fuse_band_kernel<3>, grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); break;
+                    default: hipLaunchKernelGGL(cam_fuse_band_kernel<4>, grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); break;
+                }
+                return dupl_launch_status();
+            }
+        }
+    }
     int gx = (H * W + 255) / 256;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(cam_fuse_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)s, d, cam, mm, B, C, H, W);

@@ -252,6 +252,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
 
 int g_dupl_deterministic = 0;
 
+extern "C" int dupl_get_deterministic(void) { return g_dupl_deterministic; }
+
 extern "C" int dupl_set_deterministic(int32_t on) {
     g_dupl_deterministic = on ? 1 : 0;
     return DUPL_OK;

@@ -52,8 +52,9 @@ __device__ __forceinline__ void scale_from_amax(unsigned int bits, int target, f
 __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__ x, int ld, int R, int C, float* __restrict__ slot,
                                                        unsigned int* __restrict__ next_bits, __half* __restrict__ hi,
                                                        __half* __restrict__ lo, __half* __restrict__ hiT, __half* __restrict__ loT,
-                                                       int Rp, int target) {
+                                                       int Rp, int target, float* __restrict__ colsum) {
     __shared__ unsigned int tile[64][65];            // (hi | lo << 16) per element; odd stride: conflict-free both ways
+    __shared__ float csum[4][64];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     float s = 1.f;
     if (slot) {
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
         }
     }
     const int tid = threadIdx.x;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);     // column sums of the UNSCALED values over this thread's 4 rows
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = tid + 256 * i;            // 1024 float4 chunks: row c / 16, cols (c % 16) * 4
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool in = r0 + r < R && c0 + cc < C;          // C % 4 == 0
         if (in) v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + r) * ld + c0 + cc);
+        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
         __half h[4], l[4];
         split_f32(v.x * s, h[0], l[0]);
         split_f32(v.y * s, h[1], l[1]);
@@ -87,6 +90,23 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
             for (int j = 0; j < 4; ++j)
                 tile[r][cc + j] = (unsigned int)__half_as_ushort(h[j]) | ((unsigned int)__half_as_ushort(l[j]) << 16);
         }
+    }
+    if (colsum) {
+        // bias gradient (column sums of dy) from the pass that reads dy anyway: lanes l, l + 16, l + 32, l + 48 of a wave hold
+        // the same 4 columns -> two shuffles, the 4 waves through LDS, one atomic per column and 64-row tile
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+            cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane < 16) {
+            csum[wave][4 * lane + 0] = cs.x; csum[wave][4 * lane + 1] = cs.y;
+            csum[wave][4 * lane + 2] = cs.z; csum[wave][4 * lane + 3] = cs.w;
+        }
+        __syncthreads();
+        if (tid < 64 && c0 + tid < C && r0 < R)
+            atomicAdd(&colsum[c0 + tid], (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]));
     }
     if (!hiT) return;
     __syncthreads();
@@ -110,9 +130,20 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
 
 }  // namespace
 
+extern "C" int dupl_split_prepare2(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
+                                   void* lo, void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum,
+                                   dupl_stream_t stream);
+
 extern "C" int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
                                   void* hiT, void* loT, int32_t Rp, int32_t target_exp, dupl_stream_t stream) {
+    return dupl_split_prepare2(x, ld, R, C, slot, next_bits, hi, lo, hiT, loT, Rp, target_exp, nullptr, stream);
+}
+
+extern "C" int dupl_split_prepare2(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
+                                   void* lo, void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum,
+                                   dupl_stream_t stream) {
     (void)hipGetLastError();
+    if (colsum_accum && g_dupl_deterministic) return DUPL_ERR_ARG;     // atomics: the caller uses dupl_colsum in that mode
     if (!x || R <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C || (!hi && !hiT) || ((hi == nullptr) != (lo == nullptr)) ||
         ((hiT == nullptr) != (loT == nullptr)) || (hiT && (Rp < R || (Rp & 7))) || target_exp < 1 || target_exp > 15)
         return DUPL_ERR_ARG;
@@ -128,6 +159,6 @@ extern "C" int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t
     }
     const int Rt = hiT ? Rp : R;
     hipLaunchKernelGGL(split_rt_kernel, dim3((C + 63) / 64, (Rt + 63) / 64), dim3(256), 0, s, x, ld, R, C, slot,
-                       (unsigned int*)next_bits, (__half*)hi, (__half*)lo, (__half*)hiT, (__half*)loT, Rp, target_exp);
+                       (unsigned int*)next_bits, (__half*)hi, (__half*)lo, (__half*)hiT, (__half*)loT, Rp, target_exp, colsum_accum);
     return dupl_launch_status();
 }

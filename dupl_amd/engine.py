@@ -808,11 +808,13 @@ def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
     through transposed operand planes:  dW += dy^T16 . (x^T16)^T,  dx = dy16 . (W^T16)^T  (csrc/split_prep.hip)."""
     M, N = dy.shape
     Mp = (M + 31) // 32 * 32
-    dy16, dyT16, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=True, rows_pad=Mp)
+    fuse_bias = has_bias and not ops.deterministic()         # the bias gradient rides in the split pass (fp32 atomics)
+    dy16, dyT16, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=True, rows_pad=Mp,
+                                           colsum_into=P.g[name + ".bias"] if fuse_bias else None)
     _, xT16, _ = ops.split_prepare(x, scaled=False, want_rm=False, want_T=True, rows_pad=Mp)
     gw = P.g[name + ".weight"]
     ops.linear16(dyT16, xT16, out=gw.view(N, -1), accumulate=True, alpha=alpha)
-    if has_bias:
+    if has_bias and not fuse_bias:
         ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
     dx, _ = ops.linear16(dy16, P.w16T(name + ".weight", N), alpha=alpha, dgelu_of=dgelu_of)
     return dx

@@ -21,6 +21,11 @@ def L():
     return _lib.lib()
 
 
+def deterministic() -> bool:
+    """dupl_amd.set_deterministic state (held by the library): fused atomics paths check it."""
+    return bool(L().dupl_get_deterministic())
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -130,7 +135,8 @@ def _scale_slot(device):
     return base + 16 * i, base + 16 * ((i + 1) % _RING) + 8, buf[i]
 
 
-def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad: int = 0, target_exp: int = 15):
+def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad: int = 0, target_exp: int = 15,
+                  colsum_into: Optional[Tensor] = None):
     """Backward-path operand preparation (csrc/split_prep.hip): fp32 [R, C] -> row-major planes [R, C] and / or transposed
     planes [C, Rp] (Rp = rows_pad >= R, zero-filled), optionally scaled by the power of two that brings max|x| into
     [2^14, 2^15) (gradients).  Returns (rm Split16 | None, T Split16 | None, alpha: int device pointer of 1 / scale | None;
@@ -143,8 +149,10 @@ def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad
     slot = nxt = rec = None
     if scaled:
         slot, nxt, rec = _scale_slot(x.device)
-    L().dupl_split_prepare(x.data_ptr(), x.stride(0), R, C, slot, nxt, rm.hi if rm else None, rm.lo if rm else None,
-                           T.hi if T else None, T.lo if T else None, Rp, target_exp, _stream())
+    # colsum_into: [C] fp32 accumulator that receives the column sums of x (a Linear's bias gradient) from the same pass
+    rc = L().dupl_split_prepare2(x.data_ptr(), x.stride(0), R, C, slot, nxt, rm.hi if rm else None, rm.lo if rm else None,
+                                 T.hi if T else None, T.lo if T else None, Rp, target_exp, _p(colsum_into), _stream())
+    assert rc == 0, f"dupl_split_prepare2 failed ({rc})"
     if scaled:
         for o in (rm, T):
             if o is not None:

@@ -28,6 +28,8 @@ int dupl_abi_version(void);
  * column sums, seg-loss backward scatter) runs in a fixed order, so that two identical steps give bit-identical gradients
  * (torch.use_deterministic_algorithms / cudnn.deterministic of train_final_voc.py:95-102).  Slower; default 0. */
 int dupl_set_deterministic(int32_t on);
+/* the current setting (1 / 0) */
+int dupl_get_deterministic(void);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 in / fp32 accumulate / fp32 out.
@@ -101,6 +103,11 @@ int dupl_set_gemm16_group(int32_t gm);
  * No reference counterpart (the reference's autograd calls ATen GEMMs on fp32 operands). */
 int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
                        void* hiT, void* loT, int32_t Rp, int32_t target_exp, dupl_stream_t stream);
+/* the same, and colsum_accum[c] += sum_r x[r][c] (fp32 atomics, unscaled values) when colsum_accum != NULL: the bias gradient of a
+ * Linear (autograd of vit.py:92-136's `+ bias`) from the pass that reads dy anyway.  Refused in deterministic mode (use
+ * dupl_colsum there). */
+int dupl_split_prepare2(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
+                        void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum, dupl_stream_t stream);
 /* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 3: 128x64 on 4 waves, 5: 128x128 on 8 waves, 6 / 7: 256x128 ring
  * kernel on 8 / 4 waves; 8 / 9: single-accumulator 256x256 timing probes, results only valid for unscaled lo planes) */
 int dupl_set_gemm16_tile(int32_t t);
@@ -211,6 +218,8 @@ int dupl_resize_bilinear(const float* in, float* out, int32_t B, int32_t C, int3
  * and mm[b*C+c] = {min, max} over the plane.  `lows`, `hs`, `ws` are HOST arrays of nscale (<= 4) entries. */
 int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const int32_t* ws, int32_t nscale, int32_t row_off,
                   int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, dupl_stream_t s);
+/* test / tuning knob (no reference counterpart): 1 = LDS-staged band kernel (default), 0 = per-pixel kernel; same bits */
+int dupl_set_cam_fuse_impl(int32_t impl);
 /* per plane, in place: cam = (cam - min) / ((max - min) + 1e-5)  == `cam + maxpool(-cam); cam /= maxpool(cam) + 1e-5`
  * (cam_helper.py:197-199).  mm [planes][2]; have_minmax = 0 recomputes it first. */
 int dupl_cam_minmax_normalise(float* cam, float* mm, int32_t planes, int32_t HW, int32_t have_minmax, dupl_stream_t s);

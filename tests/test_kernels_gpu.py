@@ -922,3 +922,21 @@ def test_param_bounds_kernel(dev):
     buf[offs[2] + 5] = float("nan")
     ops.L().dupl_param_bounds(buf.data_ptr(), tabd.data_ptr(), len(shapes), out.data_ptr(), ops._stream())
     assert torch.isinf(out[2]).all() and torch.isfinite(out[[0, 1, 3, 4, 5]]).all()
+
+
+@pytest.mark.parametrize("B,C,H,W,sizes", [(4, 20, 448, 448, [(28, 28), (14, 14), (42, 42)]), (2, 80, 448, 448, [(28, 28), (14, 14), (42, 42)]),
+                                           (1, 20, 96, 160, [(6, 10), (3, 5), (9, 15)]), (3, 5, 64, 64, [(4, 4), (2, 2), (6, 6)])])
+def test_cam_fuse_band_kernel_is_bit_identical(dev, B, C, H, W, sizes):
+    """The LDS-staged multi-scale CAM fusion (cam_helper.py:173-202: upsample, flip, max, ReLU, sum over scales; csrc/cam.hip
+    cam_fuse_band_kernel) against the per-pixel kernel it replaces: same bits in the fused map and in the per-plane min / max."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + C)
+    lows = [torch.randn(2 * B * (1 + h * w), C, generator=g).to(dev) for (h, w) in sizes]
+    L = ops.L()
+    assert L.dupl_set_cam_fuse_impl(0) == 0
+    cam0, mm0 = ops.cam_fuse(lows, sizes, B, C, H, W, 1, C)
+    assert L.dupl_set_cam_fuse_impl(1) == 0
+    cam1, mm1 = ops.cam_fuse(lows, sizes, B, C, H, W, 1, C)
+    torch.cuda.synchronize()
+    assert torch.equal(cam0, cam1) and torch.equal(mm0, mm1)
+    assert float(cam1.max()) > 0 and float(mm1[:, 0].min()) == 0.0
