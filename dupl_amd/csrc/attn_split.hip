@@ -15,9 +15,17 @@
 #include "common.h"
 #include "../../include/dupl_hip.h"
 
+#ifndef ATT_PRIO
+#define ATT_PRIO 0   // s_setprio around the MFMA clusters: measured null (316.3 vs 316.7 us at 8 x 1765), kept as a build knob
+#endif
+#ifndef ATT_ABL
+#define ATT_ABL 0   // ablation builds only (tools/attn16_bench): 16 = per-phase s_memtime sums of wave 0 into the lse buffer
+#endif
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float LO_INV = 1.f / DUPL_LO_SCALE;
 constexpr int HD = 64, KT = 64;
 constexpr int PLANE = KT * 128;          // one [64][128 B] image
@@ -149,6 +157,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nkt = (N + KT - 1) / KT;
+    long long tph[4] = {0, 0, 0, 0}, tlast = 0;      // ATT_ABL & 16: wait + barrier, QK, softmax, PV
+    if (ATT_ABL & 16) tlast = clock64();
+#define ATT_STAMP(i)                                  \
+    if (ATT_ABL & 16) {                               \
+        const long long now_ = clock64();             \
+        tph[i] += now_ - tlast;                       \
+        tlast = now_;                                 \
+    }
     issue(0, 0);
     for (int t = 0; t < nkt; ++t) {
         // EVERY wave must have its own DMA pieces of tile t landed before it arrives at the barrier -- including waves
@@ -160,71 +176,131 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
         if (t + 1 < nkt) issue(t + 1, (t + 1) & 1);
         if (!wave_active) continue;
         const char* st = smem + (t & 1) * STAGE;
+        ATT_STAMP(0)
 
-        // ---- S^T = K Q^T, two 32-key sub-tiles
-        f32x16 sM[2], sX[2];
+        // ---- S^T = K Q^T, two 32-key sub-tiles.  Fragment reads run ONE k-step ahead of the MFMAs that consume them (two
+        // register sets), and the six MFMAs of a step are ordered so that no accumulator is touched twice in a row:
+        // main 0, main 1, cross 0, cross 1 (hi x lo), cross 0, cross 1 (lo x hi).
+        f32x16 sM[2], sX[2];                 // no zero fill: the first MFMA of each chain takes the inline constant 0 as C
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        h8 kh[2][2], kl[2][2];               // [set][sub-tile]
+        auto k_read = [&](const int sstep, h8(&fh)[2], h8(&fl)[2]) __attribute__((always_inline)) {
+            const int ch = ((2 * sstep + hf) ^ k_sw) * 16;
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { sM[kt2][e] = 0.f; sX[kt2][e] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int ch = ((2 * s + hf) ^ k_sw) * 16;
-                const h8 kh = *reinterpret_cast<const h8*>(st + kt2 * 4096 + k_off + ch);
-                const h8 kl = *reinterpret_cast<const h8*>(st + PLANE + kt2 * 4096 + k_off + ch);
-                sM[kt2] = MFMA16(kh, qh[s], sM[kt2]);
-                sX[kt2] = MFMA16(kh, ql[s], sX[kt2]);
-                sX[kt2] = MFMA16(kl, qh[s], sX[kt2]);
+            for (int kt2 = 0; kt2 < 2; ++kt2) {
+                fh[kt2] = *reinterpret_cast<const h8*>(st + kt2 * 4096 + k_off + ch);
+                fl[kt2] = *reinterpret_cast<const h8*>(st + PLANE + kt2 * 4096 + k_off + ch);
             }
+        };
+        k_read(0, kh[0], kl[0]);
+        __builtin_amdgcn_s_setprio(ATT_PRIO);   // MFMA clusters outrank the co-resident wave's softmax arithmetic at the issue port
+#pragma unroll
+        for (int sstep = 0; sstep < 4; ++sstep) {
+            const int cur = sstep & 1;
+            if (sstep + 1 < 4) k_read(sstep + 1, kh[cur ^ 1], kl[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);       // the reads of step s+1 are ISSUED before the MFMAs of step s (hipcc would
+                                                     // otherwise sink each read to just before its use and wait for it there)
+            sM[0] = MFMA16(kh[cur][0], qh[sstep], sstep == 0 ? zero16 : sM[0]);
+            sM[1] = MFMA16(kh[cur][1], qh[sstep], sstep == 0 ? zero16 : sM[1]);
+            sX[0] = MFMA16(kh[cur][0], ql[sstep], sstep == 0 ? zero16 : sX[0]);
+            sX[1] = MFMA16(kh[cur][1], ql[sstep], sstep == 0 ? zero16 : sX[1]);
+            sX[0] = MFMA16(kl[cur][0], qh[sstep], sX[0]);
+            sX[1] = MFMA16(kl[cur][1], qh[sstep], sX[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- online softmax (fp32).  Register e of sub-tile kt2 is key  t*64 + 32 kt2 + 16 (e >> 3) + 8 hf + (e & 7)
-        const int kbase_t = t * KT + 8 * hf;
+        __builtin_amdgcn_s_setprio(0);
+        if (ATT_ABL & 16) { asm volatile("" ::"v"(sM[0]), "v"(sM[1]), "v"(sX[0]), "v"(sX[1])); }
+        ATT_STAMP(1)
+        // the first V^T fragments are fetched now: their LDS latency hides under the softmax arithmetic
+        h8 vh[2][2], vl[2][2];               // [set][d half]
+        auto v_read = [&](const int sg, h8(&fh)[2], h8(&fl)[2]) __attribute__((always_inline)) {
+            const int ch = ((2 * sg + hf) ^ v_sw) * 16;
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+                fh[dd] = *reinterpret_cast<const h8*>(st + 2 * PLANE + dd * 4096 + v_off + ch);
+                fl[dd] = *reinterpret_cast<const h8*>(st + 3 * PLANE + dd * 4096 + v_off + ch);
+            }
+        };
+        v_read(0, vh[0], vl[0]);
+        // ---- online softmax (fp32, base-2 exponent domain: c1 = scale log2(e) folded into the score).  Register e of
+        // sub-tile kt2 is key  t*64 + 32 kt2 + 16 (e >> 3) + 8 hf + (e & 7); keys >= N exist in the last tile only
+        const float c1 = scale * 1.4426950408889634f, c2 = c1 * LO_INV;
         float mx = -INFINITY;
+        // explicit register PAIRS (v_pk_mul_f32 + v_pk_fma_f32 on aligned accumulator pairs): left to itself hipcc pairs
+        // elements (1,2), (3,4), ... and pays two v_mov per packed op to re-align them
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = (sM[kt2][e] + sX[kt2][e] * LO_INV) * scale;
-                if (kbase_t + 32 * kt2 + 16 * (e >> 3) + (e & 7) >= N) v = -INFINITY;
-                sM[kt2][e] = v;
-                mx = fmaxf(mx, v);
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 m2 = {sM[kt2][e], sM[kt2][e + 1]}, x2 = {sX[kt2][e], sX[kt2][e + 1]};
+                const f32x2 v2 = __builtin_elementwise_fma(x2, f32x2{c2, c2}, m2 * f32x2{c1, c1});
+                sM[kt2][e] = v2[0];
+                sM[kt2][e + 1] = v2[1];
             }
+        if (t == nkt - 1) {            // block-uniform
+            const int kbase_t = t * KT + 8 * hf;
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kbase_t + 32 * kt2 + 16 * (e >> 3) + (e & 7) >= N) sM[kt2][e] = -INFINITY;
+        }
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sM[kt2][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
         h8 ph[4], pl[4];
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pv = fast_exp(sM[kt2][e] - m_new);
-                psum += pv;
-                float px = pv;
-                asm volatile("" : "+v"(px));         // one materialised fp32 value for both uses (see split_f32, common.h)
+                float px = __builtin_amdgcn_exp2f(sM[kt2][e] - m_new);
+                asm volatile("" : "+v"(px));         // one materialised fp32 value for every use (see split_f32, common.h)
+                psum += px;
                 const _Float16 hh = (_Float16)px;
                 ph[2 * kt2 + (e >> 3)][e & 7] = hh;
                 pl[2 * kt2 + (e >> 3)][e & 7] = (_Float16)((px - (float)hh) * DUPL_LO_SCALE);
             }
         l_run = l_run * alpha + psum;
+        // the accumulators are rescaled only when some lane's running maximum moved (wave-uniform test; alpha == 1 exactly
+        // otherwise, so skipping the 64 multiplications does not change a bit)
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { oM[d][e] *= alpha; oX[d][e] *= alpha; }
+        }
         m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { oM[d][e] *= alpha; oX[d][e] *= alpha; }
-        // ---- O^T += V^T P^T
+        if (ATT_ABL & 16) { asm volatile("" ::"v"(ph[0]), "v"(ph[3]), "v"(pl[0]), "v"(pl[3]), "v"(oM[0]), "v"(oX[1])); }
+        ATT_STAMP(2)
+        // ---- O^T += V^T P^T, same read-ahead and accumulator rotation
+        __builtin_amdgcn_s_setprio(ATT_PRIO);
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {
-            const int ch = ((2 * sg + hf) ^ v_sw) * 16;
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                const h8 vh = *reinterpret_cast<const h8*>(st + 2 * PLANE + d * 4096 + v_off + ch);
-                const h8 vl = *reinterpret_cast<const h8*>(st + 3 * PLANE + d * 4096 + v_off + ch);
-                oM[d] = MFMA16(vh, ph[sg], oM[d]);
-                oX[d] = MFMA16(vh, pl[sg], oX[d]);
-                oX[d] = MFMA16(vl, ph[sg], oX[d]);
-            }
+            const int cur = sg & 1;
+            if (sg + 1 < 4) v_read(sg + 1, vh[cur ^ 1], vl[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            oM[0] = MFMA16(vh[cur][0], ph[sg], oM[0]);
+            oM[1] = MFMA16(vh[cur][1], ph[sg], oM[1]);
+            oX[0] = MFMA16(vh[cur][0], pl[sg], oX[0]);
+            oX[1] = MFMA16(vh[cur][1], pl[sg], oX[1]);
+            oX[0] = MFMA16(vl[cur][0], ph[sg], oX[0]);
+            oX[1] = MFMA16(vl[cur][1], ph[sg], oX[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_s_setprio(0);
+        if (ATT_ABL & 16) { asm volatile("" ::"v"(oM[0]), "v"(oM[1]), "v"(oX[0]), "v"(oX[1])); }
+        ATT_STAMP(3)
+    }
+    if ((ATT_ABL & 16) && lse && tid == 0) {
+        // behind the real lse data ([B][H][N] floats, rounded up to 8 bytes)
+        long long* q = reinterpret_cast<long long*>(lse + (((size_t)gridDim.z * H * N + 1) & ~(size_t)1)) +
+                       (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4;
+        q[0] = tph[0]; q[1] = tph[1]; q[2] = tph[2]; q[3] = tph[3];
     }
     if (!wave_active) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -248,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
                     *reinterpret_cast<uint2*>(out_lo + ro + col) = *reinterpret_cast<const uint2*>(ll);
                 }
             }
-        if (lse && hf == 0) lse[((size_t)b * H + h) * N + qrow] = m_run + logf(l_tot);
+        if (lse && hf == 0) lse[((size_t)b * H + h) * N + qrow] = m_run * 0.6931471805599453f + logf(l_tot);   // m_run is in base-2 units
     }
 }
 
