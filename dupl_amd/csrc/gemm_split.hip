@@ -246,6 +246,139 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c)
     }   // passes
 }
 
+
+// One float4 of the epilogue: v = 4 consecutive columns of output row `row` starting at `col` (alpha already applied), nv of
+// them inside N.  Bias, activation, aux / res traffic and the stores exactly as gemm16_epilogue_lds does them (ACCUM excluded).
+struct Epi16 {
+    bool f_pre, f_gelu, f_relu, f_dgelu, f_rmask, vec;
+    __half *Ch, *Cl;
+};
+__device__ __forceinline__ Epi16 epi16_setup(const dupl_gemm16_desc& p) {
+    Epi16 e;
+    const int fl = p.flags;
+    e.f_pre = fl & DUPL_GEMM_STORE_PRE; e.f_gelu = fl & DUPL_GEMM_GELU; e.f_relu = fl & DUPL_GEMM_RELU;
+    e.f_dgelu = fl & DUPL_GEMM_MUL_DGELU; e.f_rmask = fl & DUPL_GEMM_MUL_RELUMASK;
+    e.Ch = static_cast<__half*>(p.C_hi);
+    e.Cl = static_cast<__half*>(p.C_lo);
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    e.vec = !(p.N & 3) && !(p.ldc & 3) && !(p.ldo & 3) && !(p.ldr & 3) && !(p.ldaux & 3) && a16(p.C) && a16(p.res) && a16(p.aux) &&
+            a16(p.bias) && !(reinterpret_cast<uintptr_t>(e.Ch) & 7) && !(reinterpret_cast<uintptr_t>(e.Cl) & 7);
+    return e;
+}
+__device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi16& E, const int row, const int col, const int nv,
+                                           const f32x4 t, const float (&bv)[4]) {
+    const bool fast = E.vec && nv == 4;
+    float v[4] = {t[0] + bv[0], t[1] + bv[1], t[2] + bv[2], t[3] + bv[3]};
+    float* auxp = p.aux + (size_t)row * p.ldaux + col;
+    if (E.f_pre) {
+        if (fast) *reinterpret_cast<f32x4*>(auxp) = f32x4{v[0], v[1], v[2], v[3]};
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < nv) auxp[c] = v[c];
+        }
+    }
+    if (E.f_gelu) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
+    }
+    if (E.f_relu) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+    }
+    if (E.f_dgelu | E.f_rmask) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (fast) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(auxp);
+            a[0] = q[0]; a[1] = q[1]; a[2] = q[2]; a[3] = q[3];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < nv) a[c] = auxp[c];
+        }
+        if (E.f_dgelu) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= gelu_grad_f(a[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = a[c] > 0.f ? v[c] : 0.f;
+        }
+    }
+    if (p.res) {
+        const float* rp = p.res + (size_t)row * p.ldr + col;
+        if (fast) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(rp);
+            v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < nv) v[c] += rp[c];
+        }
+    }
+    if (p.C) {
+        float* cp = p.C + (size_t)row * p.ldc + col;
+        if (fast) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < nv) cp[c] = v[c];
+        }
+    }
+    if (E.Ch) {
+        __half h[4], l[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_f32(v[c], h[c], l[c]);
+        __half* hp = E.Ch + (size_t)row * p.ldo + col;
+        __half* lp = E.Cl + (size_t)row * p.ldo + col;
+        if (fast) {
+            *reinterpret_cast<uint2*>(hp) = *reinterpret_cast<const uint2*>(h);
+            *reinterpret_cast<uint2*>(lp) = *reinterpret_cast<const uint2*>(l);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nv) {
+                    hp[c] = h[c];
+                    lp[c] = l[c];
+                }
+        }
+    }
+}
+
+// Epilogue of the persistent kernel: the stages already receive the next tile, so the tile leaves through a 2 KB per wave
+// side buffer, 8 rows x 64 columns at a time (4 WM passes: MFMA tile i, register group g = rows 8 g .. 8 g + 7 of it).
+// Same access pattern as gemm16_epilogue_lds (b32 writes of 32 consecutive floats, b128 reads of whole 256-byte rows ->
+// float4 global accesses); in-order LDS execution within the wave orders the passes.
+template <int WM, int WN>
+__device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN], f32x16 (&accX)[WM][WN],
+                                                     float* __restrict__ side, const int mw, const int nw, const int lane) {
+    static_assert(WN == 2, "side buffer rows are 64 floats");
+    const int l31 = lane & 31, hf = lane >> 5;
+    const float alpha = p.alpha_dev ? *p.alpha_dev : 1.f;
+    const Epi16 E = epi16_setup(p);
+    const int cl = (lane & 15) * 4, rl = lane >> 4;
+    const int col = nw + cl;
+    const int nv = min(4, p.N - col);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && nv > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < nv) bv[c] = p.bias[col + c];
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    side[(q + 4 * hf) * 64 + j * 32 + l31] = (accM[i][j][4 * g + q] + accX[i][j][4 * g + q] * LO_INV) * alpha;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = rl + 4 * k;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(side + r * 64 + cl);
+                const int row = mw + i * 32 + 8 * g + r;
+                if (nv > 0 && row < p.M) epi16_quad(p, E, row, col, nv, t, bv);
+            }
+        }
+}
+
 // WM x WN: 32x32 MFMA tiles per wave; NWM x NWN: waves per block.  Block tile (32 WM NWM) x (32 WN NWN) x 32.
 template <int WM, int WN, int NWM, int NWN, int MINB>
 __global__ __launch_bounds__(64 * NWM * NWN, MINB) void gemm_f16x3_kernel(const dupl_gemm16_desc p, const int g_gm) {
@@ -646,11 +779,203 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_ring_kernel(co
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Persistent form of the ring kernel (round 3): one block per CU walks over the output tiles (tile = blockIdx.x + k gridDim.x,
+// gridDim.x a multiple of 8 so that a block keeps its XCD and the XCD-aware tile order holds).  What it buys over one block per
+// tile: the three-stage prologue DMA of the NEXT tile is issued before the epilogue of the current one (the stages are free
+// once every wave has left the k-loop; the tile leaves through the side buffer, gemm16_epilogue_side), so a block pays its
+// ~5 k-cycle pipeline fill once per launch instead of once per tile, and blocks drift apart, which spreads the HBM write
+// bursts of the epilogues that otherwise come from all 256 CUs at once.  No split-K (the weight gradients stay on tile 5).
+template <int WM, int WN, int NWM, int NWN, int WPS>
+__global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(const dupl_gemm16_desc p, const int g_gm) {
+    constexpr int STAGES = 3;
+    constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, NW = NWM * NWN;
+    constexpr int PA = BM / 16, PB = BN / 16;
+    constexpr int NP = 2 * PA + 2 * PB;
+    constexpr int STAGE = NP * 1024;
+    constexpr int PPW = NP / NW;
+    constexpr int NMF = 3 * WM * WN, NR = 2 * (WM + WN);
+    constexpr int SIDE = NW * 2048;
+    static_assert(NP % NW == 0, "pieces must divide over the waves");
+    static_assert(STAGES * STAGE + SIDE <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE + SIDE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nblk = nbm * nbn;
+    const int nt = p.K / TBK;                     // >= STAGES (host)
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int gspan = g_gm * nbn;
+    auto tile_origin = [&](const int bid, int& m0, int& n0) __attribute__((always_inline)) {
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        const int gid = lid / gspan, gin = lid - gid * gspan;
+        const int gfirst = gid * g_gm;
+        const int gsz = min(nbm - gfirst, g_gm);
+        m0 = (gfirst + gin % gsz) * BM;
+        n0 = (gin / gsz) * BN;
+    };
+    // a block whose first index is past the last tile of its XCD's share has nothing to do (idx >= q8 + (xcd < r8))
+    auto has_tile = [&](const int bid) { return (bid >> 3) < q8 + ((bid & 7) < r8 ? 1 : 0); };
+
+    const int prow = lane >> 2;
+    const int jsrc = (lane & 3) ^ ((prow >> 2) & 3);
+    const char* gp[PPW];
+    auto plan = [&](const int m0, const int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int g = wave + NW * i;
+            const __half* plane;
+            int ld, r0, R, q;
+            if (g < PA) { plane = static_cast<const __half*>(p.A_hi); ld = p.lda; r0 = m0; R = p.M; q = g; }
+            else if (g < 2 * PA) { plane = static_cast<const __half*>(p.A_lo); ld = p.lda; r0 = m0; R = p.M; q = g - PA; }
+            else if (g < 2 * PA + PB) { plane = static_cast<const __half*>(p.B_hi); ld = p.ldb; r0 = n0; R = p.N; q = g - 2 * PA; }
+            else { plane = static_cast<const __half*>(p.B_lo); ld = p.ldb; r0 = n0; R = p.N; q = g - 2 * PA - PB; }
+            const int row = min(r0 + q * 16 + prow, R - 1);
+            gp[i] = reinterpret_cast<const char*>(plane + (size_t)row * ld) + jsrc * 16;
+        }
+    };
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        char* dst = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[i],
+                                             (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
+            gp[i] += TBK * 2;
+        }
+    };
+    const int sw = (l31 >> 2) & 3;
+    const int a_row = (wm * (32 * WM) + l31) * 64, b_row = 2 * PA * 1024 + (wn * (32 * WN) + l31) * 64;
+    const int c0 = ((0 | hf) ^ sw) * 16, c1 = ((2 | hf) ^ sw) * 16;
+    f32x16 accM[WM][WN], accX[WM][WN];
+    h8 f0a[2 * WM], f0b[2 * WN], f1a[2 * WM], f1b[2 * WN];
+    auto read_frags = [&](const char* st, const int cs, h8(&fa)[2 * WM], h8(&fb)[2 * WN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            fa[i] = *reinterpret_cast<const h8*>(st + a_row + i * 2048 + cs);
+            fa[WM + i] = *reinterpret_cast<const h8*>(st + PA * 1024 + a_row + i * 2048 + cs);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            fb[j] = *reinterpret_cast<const h8*>(st + b_row + j * 2048 + cs);
+            fb[WN + j] = *reinterpret_cast<const h8*>(st + PB * 1024 + b_row + j * 2048 + cs);
+        }
+    };
+    constexpr int XMFMA = 0x7ff & ~0x8;
+    auto mfmas = [&](const h8(&fa)[2 * WM], const h8(&fb)[2 * WN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], accM[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(XMFMA);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) accX[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[WN + j], accX[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(XMFMA);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) accX[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WM + i], fb[j], accX[i][j], 0, 0, 0);
+    };
+    auto read_item = [&](auto rc, const char* st, const int cs, h8(&fa)[2 * WM], h8(&fb)[2 * WN]) __attribute__((always_inline)) {
+        constexpr int R = decltype(rc)::value;
+        if constexpr (R < WM) fa[R] = *reinterpret_cast<const h8*>(st + a_row + R * 2048 + cs);
+        else if constexpr (R < 2 * WM) fa[R] = *reinterpret_cast<const h8*>(st + PA * 1024 + a_row + (R - WM) * 2048 + cs);
+        else if constexpr (R < 2 * WM + WN) fb[R - 2 * WM] = *reinterpret_cast<const h8*>(st + b_row + (R - 2 * WM) * 2048 + cs);
+        else fb[R - 2 * WM] = *reinterpret_cast<const h8*>(st + PB * 1024 + b_row + (R - 2 * WM - WN) * 2048 + cs);
+    };
+    auto dma_item = [&](auto dc, char* dst) __attribute__((always_inline)) {
+        constexpr int I = decltype(dc)::value;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[I],
+                                         (__attribute__((address_space(3))) void*)(dst + I * (NW * 1024)), 16, 0, 0);
+        gp[I] += TBK * 2;
+    };
+
+    int bid = blockIdx.x;
+    if (!has_tile(bid)) return;
+    int m0, n0;
+    tile_origin(bid, m0, n0);
+    plan(m0, n0);
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s) issue(s);
+    bool first = true;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    accM[i][j][e] = 0.f;
+                    accX[i][j][e] = 0.f;
+                }
+        // tile 0 of this k-loop has landed.  First tile of the block: the two younger stages may still fly; later tiles: the
+        // prologue was issued before the previous epilogue, whose stores are younger in the same counter -> drain everything
+        if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(smem, c0, f0a, f0b);
+        int rb = 0;
+        int t = 0;
+        for (; t + STAGES < nt; ++t) {
+            const char* st = smem + rb * STAGE;
+            const int nb = rb + 1 == STAGES ? 0 : rb + 1;
+            read_frags(st, c1, f1a, f1b);
+            mfmas(f0a, f0b);
+            sched_mfma_ds<NMF, NR>();
+            __builtin_amdgcn_s_waitcnt(WAIT_LGKM0_VM((STAGES - 2) * PPW));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            loads_b<NR, PPW>(read_item, dma_item, smem + nb * STAGE, c0, f0a, f0b, smem + rb * STAGE + wave * 1024);
+            mfmas(f1a, f1b);
+            sched_mfma_ds_dma<NMF, NR, PPW>();
+            rb = nb;
+        }
+        for (; t < nt; ++t) {
+            const char* st = smem + rb * STAGE;
+            const int nb = rb + 1 == STAGES ? 0 : rb + 1;
+            read_frags(st, c1, f1a, f1b);
+            mfmas(f0a, f0b);
+            sched_mfma_ds<NMF, NR>();
+            if (t + 1 < nt) {
+                __builtin_amdgcn_s_waitcnt(WAIT_LGKM0_VM(0));
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                read_frags(smem + nb * STAGE, c0, f0a, f0b);
+            }
+            mfmas(f1a, f1b);
+            rb = nb;
+        }
+        // every wave has left the k-loop -> the stages are free: start the next tile's pipeline, then write this tile out
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int mw = m0 + wm * (32 * WM), nw = n0 + wn * (32 * WN);
+        bid += gridDim.x;
+        const bool more = has_tile(bid);
+        if (more) {
+            tile_origin(bid, m0, n0);
+            plan(m0, n0);
+#pragma unroll
+            for (int s = 0; s < STAGES; ++s) issue(s);
+        }
+        gemm16_epilogue_side<WM, WN>(p, accM, accX, reinterpret_cast<float*>(smem + STAGES * STAGE) + wave * 512, mw, nw, lane);
+        if (!more) break;
+    }
+}
+
 }  // namespace
 
 static int g16_group_m = 8;
 static int g16_group_ring = 2;   // row tiles (256 rows) per group of the ring kernel's block order: 512-row A bands stay in an
                                   // XCD's L2 while it sweeps the columns (2 / 3: 320, 4: 312, 8: 304, 16: 285 TF/s-eq on 15696 x 3072 x 768)
+static int g16_persist_blocks = 256;   // blocks of the persistent kernel: one per CU (a multiple of 8: a block keeps its XCD)
 static int g16_concurrency = 1;  // how many streams feed split GEMMs at a time (dupl_set_gemm16_concurrency)
 static int g16_tile = 0;     // 0 = heuristic; 3: 128x64 on 4 waves; 5: 128x128 on 8 waves (wave tile 64x32 in both).  Measured
                              // and dropped: 64x64 wave tiles on 4 / 8 waves (2 waves / SIMD: -10..25 %), 256x128 on 16 waves
@@ -681,7 +1006,7 @@ extern "C" int dupl_set_gemm16_concurrency(int32_t n) {
 }
 
 extern "C" int dupl_set_gemm16_tile(int32_t t) {
-    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9) return DUPL_ERR_ARG;
+    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9 && t != 10) return DUPL_ERR_ARG;
     g16_tile = t;
     return DUPL_OK;
 }
@@ -715,20 +1040,26 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
     int tile = g16_tile;
     if (tile == 0) {
         // Measured on the shapes of the step (tools/gemm16_bench -w 200 with and without -2, profiles/r03_gemm16_tiles.txt),
-        // sustained clocks.  The 256 x 128 ring kernel (tile 6) is one block per CU: it wins where its grid fills the chip
-        // or where a long K amortises the un-overlapped prologue / epilogue of a block.  With a second stream feeding the
-        // chip (the two students: dupl_set_gemm16_concurrency(2)) that is >= ~100 blocks (>= 64 when K >= 2048); alone,
-        // >= ~900 blocks (>= 128 when K >= 1536).  The weight gradients (split-K partials: short blocks, atomics) and
-        // the mid-size grids stay on 128 x 128 (tile 5, two blocks per CU), grids that would leave most of its 512 block
-        // slots empty on 128 x 64 (tile 3).
+        // sustained clocks.  The persistent 256 x 128 ring kernel (tile 10; 6 = the same, one block per tile) is one block
+        // per CU: it wins wherever its grid covers a good part of the chip -- >= 64 tiles when a second stream feeds the chip
+        // as well (the two students: dupl_set_gemm16_concurrency(2)), >= 128 tiles alone.  The weight gradients (split-K
+        // partials: short blocks, atomics) stay on 128 x 128 (tile 5, two blocks per CU), grids that would leave most of
+        // its 512 block slots empty on 128 x 64 (tile 3).
         const long b256 = (long)((d->M + 255) / 256) * ((d->N + 127) / 128);
         const long b128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * ksplit;
-        const bool ring = g16_concurrency >= 2 ? (b256 >= 100 || (b256 >= 64 && d->K >= 2048))
-                                               : (b256 >= 900 || (b256 >= 128 && d->K >= 1536));
-        if (!accum && ring) tile = 6;
+        const bool ring = b256 >= (g16_concurrency >= 2 ? 64 : 128);
+        if (!accum && ring) tile = 10;
         else tile = b128 < 200 ? 3 : 5;
     }
     auto blocks = [&](int bm, int bn) { return dim3((unsigned)(((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn)), (unsigned)ksplit); };
+    if (tile == 10 && (accum || d->K / TBK < 3)) tile = 6;      // the persistent kernel has no split-K and a 3-stage prologue
+    if (tile == 10) {
+        const int nblk = ((d->M + 255) / 256) * ((d->N + 127) / 128);
+        int grid = (nblk + 7) / 8 * 8;
+        if (grid > g16_persist_blocks) grid = g16_persist_blocks;
+        hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2>), dim3((unsigned)grid), dim3(512), 0, s, *d, g16_group_ring);
+        return dupl_launch_status();
+    }
     // 8 / 9: experimental single-accumulator 256 x 256 forms (need UNSCALED lo planes: timing probes only, tools/gemm16_bench)
     if (tile == 8) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), blocks(256, 256), dim3(512), 0, s, *d, g16_group_ring);
     else if (tile == 9) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 4, 2, 2, 1, 2, true>), blocks(256, 256), dim3(256), 0, s, *d, g16_group_ring);
