@@ -102,7 +102,8 @@ class _Lib:
             fn = getattr(self.cdll, name)  # AttributeError if the .so does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
-            setattr(self, name, fn if name == "dupl_abi_version" else self._checked(name, fn))
+            # getters return a value, everything else a status (0 = ok) that is checked on every call
+            setattr(self, name, fn if name in ("dupl_abi_version", "dupl_get_deterministic") else self._checked(name, fn))
 
     @staticmethod
     def _checked(name, fn):

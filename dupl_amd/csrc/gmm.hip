@@ -20,12 +20,12 @@
 // Per-sample arithmetic is float32 in the same operation order as sklearn's; reductions are float64 in a fixed
 // order (sklearn's are float32 pairwise / BLAS sums, so fitted parameters agree to ~1e-6 relative, not bit-wise).
 //
-// Version note: the reference pins scikit-learn 1.0.2, whose k-means++ draws its FIRST centre with
-// random_state.randint(n_samples); sklearn >= 1.2 (1.7.2 is what this image has and what the goldens were generated
-// with) draws it through random_state.choice -> random_sample, i.e. a different first draw from RandomState(0).  The
-// seeding here follows 1.7 (step 1 above); on the 1-D two-mode data of this filter both seedings converge to the same
-// two components (the fit is re-initialised from the k-means labels and runs EM to tol = 1e-2), but exact parity is pinned
-// to the sklearn of this image, not to 1.0.2.
+// Version note: the reference pins scikit-learn 1.0.2 (requirements.txt:4), whose k-means++ draws its FIRST centre with
+// random_state.randint(n_samples); sklearn >= 1.2 (1.7.2 is what this image has and what the goldens were generated with) draws
+// it through random_state.choice -> random_sample, i.e. a different first draw from RandomState(0).  Both are implemented
+// (gmm_args.seeding): 0 follows >= 1.2 (step 1 above), 1 follows 1.0.2 -- numpy's masked rejection sampling of randint on the raw
+// MT19937 words, then the two trial uniforms from the words that follow -- and is the default of the training loop (the
+// reference's pinned environment); the arithmetic after the draws is the same in both versions.
 #include "common.h"
 #include "../../include/dupl_hip.h"
 
@@ -37,11 +37,19 @@ constexpr int GT = 1024, GW = GT / 64;
 constexpr float LOG_2PI = 1.8378770664093453f;
 constexpr float EPS10 = 10.f * 1.1920928955078125e-07f;   // 10 * np.finfo(float32).eps
 
+constexpr int GMM_RAW = 48;
 struct gmm_args {
     float ignore, min_ce, valid_thre, gamma, reg_covar, em_tol;
     int min_count, em_iters, kmeans_iters;
     double u0, u1, u2;
+    int seeding;                 // 0: sklearn >= 1.2 (u0, u1, u2); 1: sklearn 1.0.2 (raw MT19937 words, see below)
+    unsigned int raw[GMM_RAW];   // the first 32-bit outputs of numpy's RandomState(seed)
 };
+
+// legacy numpy double from two 32-bit words (mt19937_next_double)
+__device__ __forceinline__ double mt_double(unsigned int a, unsigned int b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -161,8 +169,26 @@ __global__ __launch_bounds__(GT) void gmm_filter_kernel(const float* __restrict_
     const double mc = a2[0] / n;
     const float km_tol = (float)((a2[1] / n - mc * mc) * 1e-4);
 
-    // k-means++ seeding
-    const int i0 = min((int)floor(p.u0 * (double)n), n - 1);
+    // k-means++ seeding.  sklearn >= 1.2: first centre = RandomState.choice(n) -> floor(u0 n), then two trial uniforms.
+    // sklearn 1.0.2 (the reference's pin, requirements.txt:4): first centre = RandomState.randint(n), i.e. numpy's masked
+    // rejection on 32-bit words -- val = next_uint32() & mask (mask = smallest 2^k - 1 >= n - 1) until val <= n - 1 -- so the
+    // NUMBER of words consumed depends on n and the two trial uniforms are the next two doubles after it.
+    int i0;
+    double u1 = p.u1, u2 = p.u2;
+    if (p.seeding == 1) {
+        unsigned int mask = (unsigned int)(n - 1);
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        int k = 0;
+        unsigned int val = 0;
+        if (n > 1) {
+            while (k < GMM_RAW - 4 && (val = (p.raw[k++] & mask)) > (unsigned int)(n - 1)) {}
+        }
+        i0 = (int)min(val, (unsigned int)(n - 1));
+        u1 = mt_double(p.raw[k], p.raw[k + 1]);
+        u2 = mt_double(p.raw[k + 2], p.raw[k + 3]);
+    } else {
+        i0 = min((int)floor(p.u0 * (double)n), n - 1);
+    }
     const float c0 = xs[i0] - mean32;
     const int L = (n + GT - 1) / GT, s0 = min(n, tid * L), s1 = min(n, s0 + L);
     double seg = 0.0;
@@ -186,7 +212,7 @@ __global__ __launch_bounds__(GT) void gmm_filter_kernel(const float* __restrict_
     const double exc = tid ? scan[tid - 1] : 0.0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const double r = (t ? p.u2 : p.u1) * (double)pot32;
+        const double r = (t ? u2 : u1) * (double)pot32;
         // np.searchsorted(cumsum, r) (side='left'): the first index whose cumulative sum is >= r
         if ((tid == 0 || exc < r) && r <= inc && s1 > s0) {
             double run = exc;
@@ -340,15 +366,33 @@ __global__ __launch_bounds__(GT) void gmm_filter_kernel(const float* __restrict_
 
 }  // namespace
 
+extern "C" int dupl_gmm_noise_filter2(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch,
+                                      float* stats, int32_t B, int32_t HW, int32_t ignore_index, float min_ce,
+                                      int32_t min_count, float valid_thre, float gamma, float reg_covar, float em_tol,
+                                      int32_t em_iters, double u0, double u1, double u2, int32_t seeding,
+                                      const uint32_t* mt_raw_host, dupl_stream_t s);
+
 extern "C" int dupl_gmm_noise_filter(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch,
                                      float* stats, int32_t B, int32_t HW, int32_t ignore_index, float min_ce,
                                      int32_t min_count, float valid_thre, float gamma, float reg_covar, float em_tol,
                                      int32_t em_iters, double u0, double u1, double u2, dupl_stream_t s) {
+    return dupl_gmm_noise_filter2(ce_map, label, xs_scratch, lab_scratch, stats, B, HW, ignore_index, min_ce, min_count, valid_thre,
+                                  gamma, reg_covar, em_tol, em_iters, u0, u1, u2, 0, nullptr, s);
+}
+
+extern "C" int dupl_gmm_noise_filter2(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch,
+                                      float* stats, int32_t B, int32_t HW, int32_t ignore_index, float min_ce,
+                                      int32_t min_count, float valid_thre, float gamma, float reg_covar, float em_tol,
+                                      int32_t em_iters, double u0, double u1, double u2, int32_t seeding,
+                                      const uint32_t* mt_raw_host, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!ce_map || !label || !xs_scratch || !lab_scratch || !stats || B <= 0 || HW <= 0 || em_iters < 0 ||
-        !(u0 >= 0.0 && u0 < 1.0) || !(u1 >= 0.0 && u1 < 1.0) || !(u2 >= 0.0 && u2 < 1.0))
+        !(u0 >= 0.0 && u0 < 1.0) || !(u1 >= 0.0 && u1 < 1.0) || !(u2 >= 0.0 && u2 < 1.0) || (seeding != 0 && seeding != 1) ||
+        (seeding == 1 && !mt_raw_host))
         return DUPL_ERR_ARG;
     gmm_args p;
+    p.seeding = seeding;
+    for (int i = 0; i < GMM_RAW; ++i) p.raw[i] = seeding == 1 ? mt_raw_host[i] : 0u;
     p.ignore = (float)ignore_index;
     p.min_ce = min_ce;
     p.valid_thre = valid_thre;

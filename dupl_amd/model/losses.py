@@ -164,8 +164,29 @@ def _gmm_uniforms(seed: int):
     return _GMM_UNIFORMS[seed]
 
 
+_GMM_RAW = {}
+
+
+def _gmm_raw_words(seed: int):
+    """The first 48 raw 32-bit outputs of numpy's RandomState(seed) (a full-range uint32 randint returns them unmasked):
+    what sklearn 1.0.2's k-means++ consumes through randint(n) and random_sample(2)."""
+    if seed not in _GMM_RAW:
+        import ctypes
+        import numpy as np
+        w = np.random.RandomState(seed).randint(0, 2 ** 32, size=48, dtype=np.uint32)
+        _GMM_RAW[seed] = (ctypes.c_uint32 * 48)(*[int(v) for v in w])
+    return _GMM_RAW[seed]
+
+
+# which scikit-learn the k-means++ seeding of the GMM filter follows: "1.0.2" = the reference's pin (requirements.txt:4,
+# first centre by RandomState.randint), "1.2+" = RandomState.choice (what this image's 1.7.2 does; the goldens of the 1.2+
+# path were generated with it).  DUPL_GMM_SKLEARN overrides.
+import os as _os
+GMM_SEEDING = _os.environ.get("DUPL_GMM_SKLEARN", "1.0.2")
+
+
 def gmm_noise_filter_(ce_map, label, ignore_index=255, gmm_valid_thre=1.0, gamma=0.95, min_ce=0.1, min_count=1000,
-                      reg_covar=5e-4, tol=1e-2, max_iter=10, random_state=0):
+                      reg_covar=5e-4, tol=1e-2, max_iter=10, random_state=0, sklearn_version=None):
     """The GMM label-noise filter of one student (train_final_voc.py:363-394) entirely on the device, in place on
     `label` (b,H,W) float32: the reference's per-image sklearn GaussianMixture(2, max_iter, tol, reg_covar,
     random_state) fit on the CE values of the foreground pseudo-labels and the relabelling of the high-loss mode.
@@ -178,9 +199,15 @@ def gmm_noise_filter_(ce_map, label, ignore_index=255, gmm_valid_thre=1.0, gamma
     lab = torch.empty((b, HW), device=label.device, dtype=torch.uint8)
     stats = torch.empty((b, GMM_STATS), device=label.device, dtype=torch.float32)
     u0, u1, u2 = _gmm_uniforms(int(random_state))
-    L().dupl_gmm_noise_filter(ce.data_ptr(), label.data_ptr(), xs.data_ptr(), lab.data_ptr(), stats.data_ptr(), b, HW,
-                              int(ignore_index), float(min_ce), int(min_count), float(gmm_valid_thre), float(gamma),
-                              float(reg_covar), float(tol), int(max_iter), u0, u1, u2, _stream())
+    ver = sklearn_version or GMM_SEEDING
+    assert ver in ("1.0.2", "1.2+"), ver
+    import ctypes
+    raw = _gmm_raw_words(int(random_state))
+    rc = L().dupl_gmm_noise_filter2(ce.data_ptr(), label.data_ptr(), xs.data_ptr(), lab.data_ptr(), stats.data_ptr(), b, HW,
+                                    int(ignore_index), float(min_ce), int(min_count), float(gmm_valid_thre), float(gamma),
+                                    float(reg_covar), float(tol), int(max_iter), u0, u1, u2, 1 if ver == "1.0.2" else 0,
+                                    ctypes.cast(raw, ctypes.c_void_p), _stream())
+    assert rc == 0, rc
     return stats
 
 

@@ -172,6 +172,9 @@ int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int3
 int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
                          void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
                          dupl_stream_t s);
+/* test / tuning knob (no reference counterpart): 0 = phase-sequential kernel, 1 = software-pipelined kernel (same results to
+ * fp32 round-off: the online softmax then advances per 32 keys instead of per 64) */
+int dupl_set_attention_fwd16_impl(int32_t impl);
 /* backward (what autograd derives for vit.py:123-135): dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N]. */
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,
@@ -310,6 +313,14 @@ int dupl_gmm_noise_filter(const float* ce_map, float* label, float* xs_scratch, 
                           int32_t B, int32_t HW, int32_t ignore_index, float min_ce, int32_t min_count,
                           float valid_thre, float gamma, float reg_covar, float em_tol, int32_t em_iters, double u0,
                           double u1, double u2, dupl_stream_t s);
+/* the same with the k-means++ seeding selectable: seeding 0 = sklearn >= 1.2 (the three uniforms above), 1 = sklearn 1.0.2, the
+ * version the reference pins (requirements.txt:4): first centre = RandomState.randint(n), numpy's masked rejection on 32-bit
+ * MT19937 words, the trial uniforms from the words after it; mt_raw_host = the first 48 32-bit outputs of RandomState(seed)
+ * (a HOST array, copied into the launch). */
+int dupl_gmm_noise_filter2(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch, float* stats,
+                           int32_t B, int32_t HW, int32_t ignore_index, float min_ce, int32_t min_count,
+                           float valid_thre, float gamma, float reg_covar, float em_tol, int32_t em_iters, double u0,
+                           double u1, double u2, int32_t seeding, const uint32_t* mt_raw_host, dupl_stream_t s);
 /* label[i] = value where mask[i] != 0 (noise-mask write-back, train_final_voc.py:381,393) */
 int dupl_mask_fill(float* label, const uint8_t* mask, float value, int64_t n, dupl_stream_t s);
 /* dlogits (token-major, zero first) += gscale[0] * d loss / d logits (wave-reduced atomics when H/h, W/w are multiples

@@ -549,18 +549,40 @@ def coco_step_args(**kw) -> "StepArgs":
     return StepArgs(**d)
 
 
-def gmm_noise_filter_(ce_map: Tensor, refined: Tensor, gmm_valid_thre: float, gamma: float) -> int:
+def sklearn_102_random_state(seed: int = 0):
+    """numpy RandomState that makes the installed scikit-learn (>= 1.2) draw k-means++ seeds the way the reference's pinned
+    1.0.2 does (requirements.txt:4): 1.0.2's _kmeans_plusplus takes its first centre with random_state.randint(n_samples),
+    later versions with random_state.choice(n_samples, p=uniform) -- the only difference on this path (the trial draws
+    random_sample(2) and all arithmetic are the same; sample_weight is all ones).  Restated from the published sources of
+    both versions (sklearn/cluster/_kmeans.py); 1.0.2 itself is not installed in this image."""
+    import numpy as np
+
+    class _RS(np.random.RandomState):
+        def choice(self, a, size=None, replace=True, p=None):
+            assert size is None and isinstance(a, (int, np.integer))
+            return self.randint(a)
+
+    return _RS(seed)
+
+
+GMM_SKLEARN = "1.0.2"       # which scikit-learn's seeding the oracle follows ("1.0.2" = the reference's pin, "1.2+" = installed)
+
+
+def gmm_noise_filter_(ce_map: Tensor, refined: Tensor, gmm_valid_thre: float, gamma: float, sklearn_version: Optional[str] = None) -> int:
     """GMM label-noise filter of one student, in place on `refined` (train_final_voc.py:363-394).
-    Third-party dependency: sklearn.mixture.GaussianMixture (reference pins scikit-learn 1.0.2; 1.7.2 here),
-    called exactly as the reference calls it.  Returns the number of images whose labels were filtered."""
+    Third-party dependency: sklearn.mixture.GaussianMixture (reference pins scikit-learn 1.0.2; 1.7.2 here), called exactly as
+    the reference calls it -- with the k-means++ first-centre draw of 1.0.2 unless sklearn_version == "1.2+"
+    (sklearn_102_random_state).  Returns the number of images whose labels were filtered."""
     from sklearn.mixture import GaussianMixture
+    ver = sklearn_version or GMM_SKLEARN
     b, h, w = refined.shape
     roi = (refined != 0) & (refined != 255)
     hit = 0
     for i in range(b):
         m = ce_map[i][roi[i]]
         if (m > 0.1).sum().item() > 1000:
-            gmm = GaussianMixture(n_components=2, max_iter=10, tol=1e-2, reg_covar=5e-4, random_state=0)
+            gmm = GaussianMixture(n_components=2, max_iter=10, tol=1e-2, reg_covar=5e-4,
+                                  random_state=sklearn_102_random_state(0) if ver == "1.0.2" else 0)
             gmm.fit(m[m > 0.1].unsqueeze(-1).cpu().detach().numpy())
             means = gmm.means_
             if abs(means[0, 0] - means[1, 0]) > gmm_valid_thre:

@@ -525,9 +525,13 @@ def _gmm_case(kind, H, W, seed):
 
 
 @pytest.mark.parametrize("H,W", [(128, 128), (448, 448), (97, 131)])
-def test_gmm_noise_filter_vs_sklearn(dev, H, W):
-    """dupl_gmm_noise_filter vs the reference's sklearn call (oracle.gmm_noise_filter_ restates train_final_voc.py:
-    363-394): same k-means++ seeds, fitted parameters to 1e-3, relabelled pixels identical up to threshold ties."""
+@pytest.mark.parametrize("skver", ["1.2+", "1.0.2"])
+def test_gmm_noise_filter_vs_sklearn(dev, H, W, skver):
+    """dupl_gmm_noise_filter2 vs the reference's sklearn call (oracle.gmm_noise_filter_ restates train_final_voc.py:
+    363-394): same k-means++ seeds, fitted parameters to 1e-3, relabelled pixels identical up to threshold ties -- for the
+    seeding of the installed scikit-learn ("1.2+": first centre by RandomState.choice) and for that of the reference's pin
+    ("1.0.2", requirements.txt:4: RandomState.randint, i.e. masked rejection on the raw MT19937 words; the sklearn side is
+    the installed library driven by oracle.sklearn_102_random_state, which restates that one draw)."""
     pytest.importorskip("sklearn")
     from sklearn.mixture import GaussianMixture
     from sklearn.cluster import kmeans_plusplus
@@ -538,9 +542,10 @@ def test_gmm_noise_filter_vs_sklearn(dev, H, W):
     ce = torch.from_numpy(np.stack([c[0] for c in cases]))
     lab = torch.from_numpy(np.stack([c[1] for c in cases]))
     ref = lab.clone()
-    hits = O.gmm_noise_filter_(ce, ref, 1.0, 0.95)
+    hits = O.gmm_noise_filter_(ce, ref, 1.0, 0.95, sklearn_version=skver)
     got = lab.clone().to(dev)
-    stats = LS.gmm_noise_filter_(ce.to(dev), got, 255, 1.0, 0.95)
+    stats = LS.gmm_noise_filter_(ce.to(dev), got, 255, 1.0, 0.95, sklearn_version=skver)
+    rs_of = (lambda: O.sklearn_102_random_state(0)) if skver == "1.0.2" else (lambda: np.random.RandomState(0))
     torch.cuda.synchronize()
     stats = stats.cpu().numpy()
     got = got.cpu()
@@ -553,8 +558,10 @@ def test_gmm_noise_filter_vs_sklearn(dev, H, W):
         if x.shape[0] <= 1000:
             assert stats[i, 1] == 0 and torch.equal(got[i], lab[i])
             continue
-        gm = GaussianMixture(n_components=2, max_iter=10, tol=1e-2, reg_covar=5e-4, random_state=0).fit(x)
-        _, idx = kmeans_plusplus(x - x.mean(axis=0), 2, random_state=np.random.RandomState(0))
+        gm = GaussianMixture(n_components=2, max_iter=10, tol=1e-2, reg_covar=5e-4, random_state=rs_of()).fit(x)
+        _, idx = kmeans_plusplus(x - x.mean(axis=0), 2, random_state=rs_of())
+        if skver == "1.0.2":     # the first seed IS numpy's randint(n): checked against numpy itself, not only the emulation
+            assert int(stats[i, 14]) == int(np.random.RandomState(0).randint(x.shape[0]))
         assert [int(stats[i, 14]), int(stats[i, 15])] == [int(idx[0]), int(idx[1])], "k-means++ seeds"
         assert int(stats[i, 8]) == gm.n_iter_, "EM iteration count"
         np.testing.assert_allclose(stats[i, 2:4], gm.means_[:, 0], rtol=1e-3, atol=1e-4)
