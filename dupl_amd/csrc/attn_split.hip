@@ -14,11 +14,7 @@
 // Block = 4 waves x 32 queries, 64 keys per iteration, two LDS stages (64 KB, 2 blocks / CU), one barrier per key tile.
 #include "common.h"
 #include "../../include/dupl_hip.h"
-#include <type_traits>
 
-#ifndef ATT_SCHED
-#define ATT_SCHED 6
-#endif
 #ifndef ATT_PRIO
 #define ATT_PRIO 0   // s_setprio around the MFMA clusters: measured null (316.3 vs 316.7 us at 8 x 1765), kept as a build knob
 #endif
@@ -333,279 +329,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Software-pipelined form (round 3).  Same operands, tiles, LDS images and epilogue as attn_fwd16_kernel; what changes is the
-// order of work inside a wave.  The 64-key tile is processed as two 32-key halves g = 2 t + kt2 and three things run in the
-// same instruction window ("stage g"):
-//        matrix pipe:  S(g+1) = K(g+1) Q^T   (12 MFMAs)   and   O += V(g-1)^T P(g-1)^T   (12 MFMAs), alternating
-//        vector pipe:  softmax of S(g) -> P(g)              (max, exp2, row sum, hi / lo split)
-// i.e. the softmax arithmetic of one half sits in the issue shadow of the MFMAs of its neighbours instead of between
-// them: in attn_fwd16_kernel a wave spends 2 600 cycles per key tile in softmax code with an idle matrix pipe (per-phase
-// s_memtime stamps, tools/attn16_bench -d) and only the co-resident wave of the other block can use it.
-// Consequences for the data flow: K runs one tile ahead of V (iteration t needs K(t+1) and V(t)), both through 2-deep rings
-// (the same 64 KB); S and P are double-buffered by the parity of g; the accumulator rescale of half g is applied after the
-// MFMAs of stage g (it must follow PV(g-1) and precede PV(g)), and only when some lane's running maximum moved.
-__global__ __launch_bounds__(256, 2) void attn_fwd16p_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
-                                                             const __half* __restrict__ vT_hi, const __half* __restrict__ vT_lo,
-                                                             float* __restrict__ out, __half* __restrict__ out_hi,
-                                                             __half* __restrict__ out_lo, float* __restrict__ lse, int N, int H,
-                                                             int Npad, float scale, int remap) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];      // K ring: 2 x (hi | lo), then V^T ring: 2 x (hi | lo)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    int bx, h, b;
-    xcd_remap3(remap, bx, h, b);
-    const int q0 = bx * 128 + wave * 32;
-    const int D = H * HD, ld = 3 * D;
-    const int qrow = q0 + l31;
-    const bool wave_active = q0 < N;
-    h8 qh[4], ql[4];
-    {
-        const size_t off = ((size_t)b * N + min(qrow, N - 1)) * ld + h * HD + 8 * hf;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            qh[s] = *reinterpret_cast<const h8*>(qkv_hi + off + 16 * s);
-            ql[s] = *reinterpret_cast<const h8*>(qkv_lo + off + 16 * s);
-        }
-    }
-    // ---- DMA plan (as attn_fwd16_kernel), K and V^T of a tile issued separately
-    const int prow = lane >> 3, pch = lane & 7;
-    const char* kbase[2];
-    kbase[0] = reinterpret_cast<const char*>(qkv_hi + (size_t)b * N * ld + D + h * HD);
-    kbase[1] = reinterpret_cast<const char*>(qkv_lo + (size_t)b * N * ld + D + h * HD);
-    const char* vp[4];
-    int krow[2], kch[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 8 * (wave + 4 * j) + prow;
-        const int c = pch ^ ((r >> 1) & 7);
-        krow[j] = r;
-        kch[j] = c * 16;
-        vp[j] = reinterpret_cast<const char*>(vT_hi + ((size_t)(b * H + h) * HD + r) * Npad) + c * 16;
-        vp[2 + j] = reinterpret_cast<const char*>(vT_lo + ((size_t)(b * H + h) * HD + r) * Npad) + c * 16;
-    }
-    constexpr int KSLOT = 2 * PLANE;          // bytes of one K (or V^T) slot: hi | lo
-    auto issue_k = [&](int t) __attribute__((always_inline)) {
-        char* dst = smem + (t & 1) * KSLOT + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = i & 1;
-            const char* src = kbase[i >> 1] + (size_t)min(t * KT + krow[j], N - 1) * (ld * 2) + kch[j];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
-        }
-    };
-    auto issue_v = [&](int t) __attribute__((always_inline)) {
-        char* dst = smem + 2 * KSLOT + (t & 1) * KSLOT + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = i & 1;
-            const char* src = vp[(i >= 2 ? 2 : 0) + j] + (size_t)t * (KT * 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
-        }
-    };
-    const int g4 = (l31 >> 2) & 3;
-    const int krow_a = (l31 & ~12) | ((g4 == 1 ? 2 : (g4 == 2 ? 1 : g4)) << 2);
-    const int k_off = krow_a * 128, k_sw = (krow_a >> 1) & 7;
-    const int v_off = l31 * 128, v_sw = (l31 >> 1) & 7;
-
-    f32x16 oM[2], oX[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { oM[d][e] = 0.f; oX[d][e] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-    const float c1 = scale * 1.4426950408889634f, c2 = c1 * LO_INV;
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int nkt = (N + KT - 1) / KT;
-    const int ng = 2 * nkt;                    // halves
-
-    f32x16 sM[2], sX[2];                       // S(g) in slot g & 1
-    h8 ph[2][2], pl[2][2];                     // P(g) in slot g & 1: [slot][16-key group]
-
-    // QK step: 3 MFMAs of k-step `ss` of half g into slot `sl`;  PV step: 3 MFMAs (16-key group j >> 1, d half j & 1) of half g
-    auto qk3 = [&](const char* kst, const int kt2, const int ss, f32x16& m, f32x16& x) __attribute__((always_inline)) {
-        const int ch = ((2 * ss + hf) ^ k_sw) * 16;
-        const h8 kh = *reinterpret_cast<const h8*>(kst + kt2 * 4096 + k_off + ch);
-        const h8 kl = *reinterpret_cast<const h8*>(kst + PLANE + kt2 * 4096 + k_off + ch);
-        m = MFMA16(kh, qh[ss], ss == 0 ? zero16 : m);
-        x = MFMA16(kh, ql[ss], ss == 0 ? zero16 : x);
-        x = MFMA16(kl, qh[ss], x);
-    };
-    auto pv3 = [&](const char* vst, const int kt2, const int j, const h8 (&p_h)[2], const h8 (&p_l)[2]) __attribute__((always_inline)) {
-        const int grp = j >> 1, dd = j & 1;
-        const int ch = ((2 * (2 * kt2 + grp) + hf) ^ v_sw) * 16;
-        const h8 vh = *reinterpret_cast<const h8*>(vst + dd * 4096 + v_off + ch);
-        const h8 vl = *reinterpret_cast<const h8*>(vst + PLANE + dd * 4096 + v_off + ch);
-        oM[dd] = MFMA16(vh, p_h[grp], oM[dd]);
-        oX[dd] = MFMA16(vh, p_l[grp], oX[dd]);
-        oX[dd] = MFMA16(vl, p_h[grp], oX[dd]);
-    };
-    // softmax of half g (slot sl): S -> P, running max / sum; returns the factor the accumulators still have to take
-    auto softmax_half = [&](auto mask_c, const int g, f32x16& m, f32x16& x, h8 (&p_h)[2], h8 (&p_l)[2], float& alpha_out, bool& moved)
-                            __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const f32x2 m2 = {m[e], m[e + 1]}, x2 = {x[e], x[e + 1]};
-            const f32x2 v2 = __builtin_elementwise_fma(x2, f32x2{c2, c2}, m2 * f32x2{c1, c1});
-            m[e] = v2[0];
-            m[e + 1] = v2[1];
-        }
-        if constexpr (decltype(mask_c)::value) {     // keys >= N exist in the last tile only: straight-line selects there, no
-            const int kb = g * 32 + 8 * hf;          // branch anywhere (a branch would end the scheduling region of the stage)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) m[e] = (kb + 16 * (e >> 3) + (e & 7) >= N) ? -INFINITY : m[e];
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, m[e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        alpha_out = __builtin_amdgcn_exp2f(m_run - m_new);
-        moved = __builtin_amdgcn_ballot_w64(m_new != m_run) != 0;
-        float psum = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float px = __builtin_amdgcn_exp2f(m[e] - m_new);
-            asm volatile("" : "+v"(px));
-            psum += px;
-            const _Float16 hh = (_Float16)px;
-            p_h[e >> 3][e & 7] = hh;
-            p_l[e >> 3][e & 7] = (_Float16)((px - (float)hh) * DUPL_LO_SCALE);
-        }
-        l_run = l_run * alpha_out + psum;
-        m_run = m_new;
-    };
-    auto rescale = [&](const float alpha, const bool moved) __attribute__((always_inline)) {
-        if (moved) {
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { oM[d][e] *= alpha; oX[d][e] *= alpha; }
-        }
-    };
-    // one pipeline stage: QK(g + 1) -> slot (g + 1) & 1, PV(g - 1) from slot (g - 1) & 1 = the same slot index, softmax(g).
-    // has_qk / has_pv are block-uniform.
-    auto stage = [&](auto has_qk_c, auto has_pv_c, auto mask_c, const int g, const char* kst_next, const int kt2_next, const char* vst_prev,
-                     const int kt2_prev, f32x16& sMc, f32x16& sXc, h8 (&phc)[2], h8 (&plc)[2], f32x16& sMn, f32x16& sXn,
-                     const h8 (&php)[2], const h8 (&plp)[2]) __attribute__((always_inline)) {
-        constexpr bool has_qk = decltype(has_qk_c)::value, has_pv = decltype(has_pv_c)::value;
-        float alpha;
-        bool moved;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (has_qk) qk3(kst_next, kt2_next, j, sMn, sXn);
-            if constexpr (has_pv) pv3(vst_prev, kt2_prev, j, php, plp);
-        }
-        softmax_half(mask_c, g, sMc, sXc, phc, plc, alpha, moved);
-        // issue order: one MFMA, then a slice of the softmax arithmetic, fragment reads in between
-#if ATT_SCHED
-        if constexpr (has_qk && has_pv) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, ATT_SCHED, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, ATT_SCHED, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, ATT_SCHED, 0);
-            }
-        }
-#endif
-        rescale(alpha, moved);
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-
-    // ---- prologue: K(0); then K(1) and V(0) in flight while S(0) and the first stage run
-    issue_k(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (nkt > 1) issue_k(1);
-    issue_v(0);
-    if (wave_active) {
-        const char* k0 = smem;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) qk3(k0, 0, j, sM[0], sX[0]);
-        // stage 0: QK(1) (second half of K(0)), no PV yet, softmax(0)
-        if (nkt > 1) stage(T_{}, F_{}, F_{}, 0, k0, 1, nullptr, 0, sM[0], sX[0], ph[0], pl[0], sM[1], sX[1], ph[1], pl[1]);
-        else stage(T_{}, F_{}, T_{}, 0, k0, 1, nullptr, 0, sM[0], sX[0], ph[0], pl[0], sM[1], sX[1], ph[1], pl[1]);
-    }
-    // iteration t: K(t+1) and V(t) have landed (issued one iteration ago); every wave waits for its own pieces before the barrier
-    //   stage 2t+1: QK(2t+2) = first half of K(t+1) -> slot 0, PV(2t) = first half of V(t) with P slot 0, softmax(2t+1) slot 1
-    //   stage 2t+2: QK(2t+3) = second half of K(t+1) -> slot 1, PV(2t+1) = second half of V(t) with P slot 1, softmax(2t+2) slot 0
-    // keys >= N live in tile nkt-1 = halves 2 nkt - 2 (softmaxed in the second stage of iteration nkt-2) and 2 nkt - 1 (tail)
-    int t = 0;
-    for (; t + 2 < nkt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        issue_k(t + 2);
-        issue_v(t + 1);
-        if (!wave_active) continue;
-        const char* kn = smem + ((t + 1) & 1) * KSLOT;          // K(t+1)
-        const char* vc = smem + 2 * KSLOT + (t & 1) * KSLOT;    // V(t)
-        stage(T_{}, T_{}, F_{}, 2 * t + 1, kn, 0, vc, 0, sM[1], sX[1], ph[1], pl[1], sM[0], sX[0], ph[0], pl[0]);
-        stage(T_{}, T_{}, F_{}, 2 * t + 2, kn, 1, vc, 1, sM[0], sX[0], ph[0], pl[0], sM[1], sX[1], ph[1], pl[1]);
-    }
-    if (t + 1 < nkt) {      // t = nkt - 2: the second stage softmaxes the first half of the last tile
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        issue_v(t + 1);
-        if (wave_active) {
-            const char* kn = smem + ((t + 1) & 1) * KSLOT;
-            const char* vc = smem + 2 * KSLOT + (t & 1) * KSLOT;
-            stage(T_{}, T_{}, F_{}, 2 * t + 1, kn, 0, vc, 0, sM[1], sX[1], ph[1], pl[1], sM[0], sX[0], ph[0], pl[0]);
-            stage(T_{}, T_{}, T_{}, 2 * t + 2, kn, 1, vc, 1, sM[0], sX[0], ph[0], pl[0], sM[1], sX[1], ph[1], pl[1]);
-        }
-        ++t;
-    }
-    {   // last tile (t = nkt - 1): no K left to multiply; PV(2t), softmax(2t+1), then PV(2t+1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (wave_active) {
-            const char* vc = smem + 2 * KSLOT + (t & 1) * KSLOT;
-            stage(F_{}, T_{}, T_{}, 2 * t + 1, nullptr, 0, vc, 0, sM[1], sX[1], ph[1], pl[1], sM[0], sX[0], ph[0], pl[0]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pv3(vc, 1, j, ph[1], pl[1]);
-        }
-    }
-    (void)ng;
-    if (!wave_active) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
-    if (qrow < N) {
-        const size_t ro = ((size_t)b * N + qrow) * D + h * HD;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (oM[d][4 * g + j] + oX[d][4 * g + j] * LO_INV) * inv;
-                const int col = d * 32 + 8 * g + 4 * hf;
-                if (out) *reinterpret_cast<float4*>(out + ro + col) = make_float4(v[0], v[1], v[2], v[3]);
-                if (out_hi) {
-                    __half hh[4], ll[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) split_f32(v[j], hh[j], ll[j]);
-                    *reinterpret_cast<uint2*>(out_hi + ro + col) = *reinterpret_cast<const uint2*>(hh);
-                    *reinterpret_cast<uint2*>(out_lo + ro + col) = *reinterpret_cast<const uint2*>(ll);
-                }
-            }
-        if (lse && hf == 0) lse[((size_t)b * H + h) * N + qrow] = m_run * 0.6931471805599453f + logf(l_tot);
-    }
-}
-
 }  // namespace
 
 static int g_attn16_remap = 1;
-static int g_attn16_impl = 0;     // 1: software-pipelined kernel (attn_fwd16p_kernel)
-extern "C" int dupl_set_attention_fwd16_impl(int32_t impl) {
-    if (impl != 0 && impl != 1) return DUPL_ERR_ARG;
-    g_attn16_impl = impl;
-    return DUPL_OK;
-}
+
 
 extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
                                     void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
@@ -618,13 +345,8 @@ extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void
     if (!al16(qkv_hi) || !al16(qkv_lo) || !al16(vT_hi) || !al16(vT_lo)) return DUPL_ERR_ARG;
     hipLaunchKernelGGL(vt_planes_kernel, dim3(Npad / KT, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
                        (const __half*)qkv_lo, (__half*)vT_hi, (__half*)vT_lo, N, H, Npad);
-    if (g_attn16_impl == 1)
-        hipLaunchKernelGGL(attn_fwd16p_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
-                           (const __half*)qkv_lo, (const __half*)vT_hi, (const __half*)vT_lo, out, (__half*)out_hi, (__half*)out_lo, lse,
-                           N, H, Npad, scale, g_attn16_remap);
-    else
-        hipLaunchKernelGGL(attn_fwd16_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
-                           (const __half*)qkv_lo, (const __half*)vT_hi, (const __half*)vT_lo, out, (__half*)out_hi, (__half*)out_lo, lse,
-                           N, H, Npad, scale, g_attn16_remap);
+    hipLaunchKernelGGL(attn_fwd16_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
+                       (const __half*)qkv_lo, (const __half*)vT_hi, (const __half*)vT_lo, out, (__half*)out_hi, (__half*)out_lo, lse,
+                       N, H, Npad, scale, g_attn16_remap);
     return dupl_launch_status();
 }

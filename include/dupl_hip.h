@@ -172,9 +172,6 @@ int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int3
 int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
                          void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
                          dupl_stream_t s);
-/* test / tuning knob (no reference counterpart): 0 = phase-sequential kernel, 1 = software-pipelined kernel (same results to
- * fp32 round-off: the online softmax then advances per 32 keys instead of per 64) */
-int dupl_set_attention_fwd16_impl(int32_t impl);
 /* backward (what autograd derives for vit.py:123-135): dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N]. */
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,

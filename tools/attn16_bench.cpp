@@ -21,7 +21,7 @@ __global__ void fill_kernel(float* x, long n, uint32_t seed, float sigma) {
 int main(int argc, char** argv) {
     bool dbg = false;
     int window_ms = 200;
-    for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "-d")) dbg = true; else if (!strcmp(argv[i], "-i") && i + 1 < argc) dupl_set_attention_fwd16_impl(atoi(argv[++i])); else if (!strcmp(argv[i], "-w") && i + 1 < argc) window_ms = atoi(argv[++i]); }
+    for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "-d")) dbg = true; else if (!strcmp(argv[i], "-w") && i + 1 < argc) window_ms = atoi(argv[++i]); }
     const int H = 12, hd = 64, D = H * hd;
     const int cases[][2] = {{8, 1765}, {8, 785}, {8, 197}, {4, 785}};
     hipStream_t st; CK(hipStreamCreate(&st));
