@@ -126,4 +126,6 @@ def lib() -> _Lib:
         _LIB = _Lib()
         if os.environ.get("DUPL_DETERMINISTIC", "0") == "1":
             _LIB.dupl_set_deterministic(1)
+        if os.environ.get("DUPL_GEMM16_TILE"):          # tuning / A-B runs: force one tile of the split GEMM (0 = heuristic)
+            _LIB.dupl_set_gemm16_tile(int(os.environ["DUPL_GEMM16_TILE"]))
     return _LIB

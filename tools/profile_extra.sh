@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round-3 side measurements (run through gpurun from the repo root; everything lands in gpurun_out/<tag>/ and is then copied to
+# profiles/ by hand):   gpurun --timeout 1500 -- 'bash tools/profile_extra.sh r03'
+#   <tag>_gemm16_tiles.txt    sustained TF/s-eq of every tile variant of dupl_gemm_f16x3 on the step's shapes, one and two streams
+#   <tag>_gemm16_phases.txt   per-block s_memtime breakdown (prologue / k-loop / epilogue) and in-block clock of the ring kernel
+#   <tag>_power.txt           socket power + sclk (rocm-smi) under: pure f16 MFMA probe, the GEMM tiles, GEMM minus MFMA, LDS only
+#   <tag>_attn16.txt          dupl_attention_fwd16 stand-alone + per-phase cycles of wave 0
+#   <tag>_configs.txt         bench.py on the secondary configurations
+TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+B=tools/gemm16_bench
+{ echo "# tools/gemm16_bench -s all -t 3,5,6,10 -w 200 (one stream)"; $B -s all -t 3,5,6,10 -w 200;
+  echo "# the same with -2 (every launch on two streams at a time: the two students)"; $B -s all -t 3,5,6,10 -w 200 -2;
+  echo "# epilogue 1 (bias -> planes), 2 (bias + GELU + stored pre-activation -> planes), 3 (bias + residual -> fp32), two streams";
+  for e in 1 2 3; do $B -s fwd -t 5,10 -w 150 -2 -e $e; done;
+  echo "# epilogue 4 (ACCUM, split-K atomics: the weight gradients), two streams"; $B -s bwd -t 3,5,6 -w 150 -2 -e 4;
+  echo "# single-accumulator 256 x 256 timing probes (tiles 8 / 9; results invalid by construction: lo planes are scaled), two streams";
+  $B -s 15696x3072x768,15696x768x3072,6280x3072x768,3140x3072x768 -t 10,8,9 -w 150 -2; } > $OUT/${TAG}_gemm16_tiles.txt 2>&1
+{ echo "# LD_LIBRARY_PATH=tools/abl/16 (G16_ABL=16: s_memtime stamps of wave 0 per block): prologue / k-loop / epilogue cycles";
+  LD_LIBRARY_PATH=tools/abl/16 $B -s 15696x3072x768,15696x768x3072,6280x3072x768,3140x3072x768 -t 6,7 -d -p; } > $OUT/${TAG}_gemm16_phases.txt 2>&1
+S=15696x3072x768
+{ echo "# rocm-smi samples (sclk, socket W) while the command runs; idle first"; rocm-smi --showpower --showclocks | grep -E "Power \(W\)|sclk";
+  tools/power_probe.sh "pure f16 MFMA probe (registers only, random operands, 2 waves / SIMD)" $B -P 4000000 -s 129x128x32 -t 5 -c;
+  for t in 5 6 10; do tools/power_probe.sh "dupl_gemm_f16x3 tile $t, $S" $B -s $S -t $t -n 8000; done;
+  LD_LIBRARY_PATH=tools/abl/18 tools/power_probe.sh "tile 6 without the MFMAs (DMA + LDS reads + epilogue)" $B -s $S -t 6 -n 12000;
+  LD_LIBRARY_PATH=tools/abl/19 tools/power_probe.sh "tile 6 without MFMAs and DMA (LDS reads + barriers + epilogue)" $B -s $S -t 6 -n 20000; } > $OUT/${TAG}_power.txt 2>&1
+{ tools/attn16_bench -w 200; echo "# ATT_ABL=16 build: cycles per key tile of wave 0"; LD_LIBRARY_PATH=tools/abl/att16 tools/attn16_bench -d -w 50; } > $OUT/${TAG}_attn16.txt 2>&1
+bash tools/bench_configs.sh > $OUT/${TAG}_configs.txt 2>&1
+ls -la $OUT
