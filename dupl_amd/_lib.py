@@ -41,7 +41,7 @@ class Gemm16Desc(ctypes.Structure):
         ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
         ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("ldo", ctypes.c_int32),
         ("ldr", ctypes.c_int32), ("ldaux", ctypes.c_int32),
-        ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("flags", ctypes.c_int32), ("c_rows", ctypes.c_int32),
         ("alpha_dev", ctypes.c_void_p),
     ]
 

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
                                                             const __half* __restrict__ vT_hi, const __half* __restrict__ vT_lo,
                                                             float* __restrict__ out, __half* __restrict__ out_hi,
                                                             __half* __restrict__ out_lo, float* __restrict__ lse, int N, int H,
-                                                            int Npad, float scale, int remap) {
+                                                            int Npad, float scale, int remap, int B_f32) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     int bx, h, b;
@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
     if (!wave_active) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
+    if (b >= B_f32) { out = nullptr; lse = nullptr; }     // fp32 copies only for the images that are back-propagated
     if (qrow < N) {
         const size_t ro = ((size_t)b * N + qrow) * D + h * HD;
 #pragma unroll
@@ -337,7 +338,14 @@ static int g_attn16_remap = 1;
 extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
                                     void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
                                     float scale, dupl_stream_t s) {
+    return dupl_attention_fwd16b(qkv_hi, qkv_lo, vT_hi, vT_lo, out, out_hi, out_lo, lse, B, N, H, hd, Npad, scale, B, s);
+}
+
+extern "C" int dupl_attention_fwd16b(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
+                                     void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
+                                     float scale, int32_t B_f32, dupl_stream_t s) {
     (void)hipGetLastError();
+    if (B_f32 < 0 || B_f32 > B || (B_f32 < B && !out_hi)) return DUPL_ERR_ARG;
     if (!qkv_hi || !qkv_lo || !vT_hi || !vT_lo || (!out && !out_hi) || ((out_hi == nullptr) != (out_lo == nullptr)) || B <= 0 ||
         N <= 0 || H <= 0 || hd != HD || Npad < N || (Npad % KT))
         return DUPL_ERR_ARG;
@@ -347,6 +355,6 @@ extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void
                        (const __half*)qkv_lo, (__half*)vT_hi, (__half*)vT_lo, N, H, Npad);
     hipLaunchKernelGGL(attn_fwd16_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
                        (const __half*)qkv_lo, (const __half*)vT_hi, (const __half*)vT_lo, out, (__half*)out_hi, (__half*)out_lo, lse,
-                       N, H, Npad, scale, g_attn16_remap);
+                       N, H, Npad, scale, g_attn16_remap, B_f32);
     return dupl_launch_status();
 }

@@ -75,7 +75,8 @@ __device__ __forceinline__ void gemm16_epilogue(const dupl_gemm16_desc& p, f32x1
                                                      // CSE'd across the 16 x WM x WN elements it spills (144 VGPRs at 2 x 2 tiles)
                 if (!interior && row >= p.M) continue;
                 float v = (accM[i][j][e] + accX[i][j][e] * LO_INV) * alpha + bv;
-                if (f_pre) p.aux[(size_t)row * p.ldaux + col] = v;
+                const bool w32 = p.c_rows <= 0 || row < p.c_rows;      // fp32 copies for the first c_rows rows only
+                if (f_pre && w32) p.aux[(size_t)row * p.ldaux + col] = v;
                 if (f_gelu) v = gelu_f(v);
                 if (f_relu) v = fmaxf(v, 0.f);
                 if (f_dgelu) v *= gelu_grad_f(p.aux[(size_t)row * p.ldaux + col]);
@@ -87,7 +88,7 @@ __device__ __forceinline__ void gemm16_epilogue(const dupl_gemm16_desc& p, f32x1
                     else *cp += v;
                     continue;
                 }
-                if (p.C) p.C[(size_t)row * p.ldc + col] = v;
+                if (p.C && w32) p.C[(size_t)row * p.ldc + col] = v;
                 if (Ch) {
                     __half h, l;
                     split_f32(v, h, l);
@@ -178,7 +179,8 @@ __device__ __forceinline__ void gemm16_epilogue_lds(const dupl_gemm16_desc& p, f
         }
         float v[4] = {t[0] + bv[0], t[1] + bv[1], t[2] + bv[2], t[3] + bv[3]};
         float* auxp = p.aux + (size_t)row * p.ldaux + col;
-        if (f_pre) {
+        const bool w32 = p.c_rows <= 0 || row < p.c_rows;
+        if (f_pre && w32) {
             if (fast) *reinterpret_cast<f32x4*>(auxp) = f32x4{v[0], v[1], v[2], v[3]};
             else
                 {
@@ -217,7 +219,7 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) a[c] = auxp[c]; }
                 {
 _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) v[c] += rp[c]; }
         }
-        if (p.C) {
+        if (p.C && w32) {
             float* cp = p.C + (size_t)row * p.ldc + col;
             if (fast) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
             else
@@ -270,7 +272,8 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
     const bool fast = E.vec && nv == 4;
     float v[4] = {t[0] + bv[0], t[1] + bv[1], t[2] + bv[2], t[3] + bv[3]};
     float* auxp = p.aux + (size_t)row * p.ldaux + col;
-    if (E.f_pre) {
+    const bool w32 = p.c_rows <= 0 || row < p.c_rows;          // fp32 copies for the first c_rows rows only
+    if (E.f_pre && w32) {
         if (fast) *reinterpret_cast<f32x4*>(auxp) = f32x4{v[0], v[1], v[2], v[3]};
         else {
 #pragma unroll
@@ -312,7 +315,7 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
             for (int c = 0; c < 4; ++c) if (c < nv) v[c] += rp[c];
         }
     }
-    if (p.C) {
+    if (p.C && w32) {
         float* cp = p.C + (size_t)row * p.ldc + col;
         if (fast) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
         else {
@@ -1024,7 +1027,8 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
                      DUPL_GEMM_MUL_RELUMASK))
         return DUPL_ERR_ARG;
     const bool accum = d->flags & DUPL_GEMM_ACCUM;
-    if (accum && (!d->C || d->C_hi || d->bias || d->res)) return DUPL_ERR_ARG;   // C += alpha * A B^T, nothing else
+    if (accum && (!d->C || d->C_hi || d->bias || d->res || d->c_rows)) return DUPL_ERR_ARG;   // C += alpha * A B^T, nothing else
+    if (d->c_rows < 0 || (d->c_rows && (d->flags & (DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK)))) return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     // split-K for accumulating GEMMs (weight gradients: few output tiles, K = all tokens): >= ~2 blocks per CU,
     // >= 8 k-tiles per split

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                             long rows, int D, float eps, __half* __restrict__ y_hi,
-                                                            __half* __restrict__ y_lo) {
+                                                            __half* __restrict__ y_lo, long f32_rows) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float rstd = 1.0f / sqrtf(var + eps);
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
-    float4* yr = y ? reinterpret_cast<float4*>(y + row * D) : nullptr;
+    float4* yr = (y && (f32_rows <= 0 || row < f32_rows)) ? reinterpret_cast<float4*>(y + row * D) : nullptr;
     uint2* hr = y_hi ? reinterpret_cast<uint2*>(y_hi + row * D) : nullptr;   // f16x3 operand planes of the output
     uint2* lr = y_hi ? reinterpret_cast<uint2*>(y_lo + row * D) : nullptr;
 #pragma unroll
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             }
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && (f32_rows <= 0 || row < f32_rows)) {
         if (mean_o) mean_o[row] = mean;
         if (rstd_o) rstd_o[row] = rstd;
     }
@@ -222,13 +222,19 @@ extern "C" int dupl_layernorm_fwd(const float* x, const float* gamma, const floa
 
 extern "C" int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
                                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s) {
+    return dupl_layernorm_fwd16b(x, gamma, beta, y, y_hi, y_lo, mean, rstd, rows, D, eps, 0, s);
+}
+
+extern "C" int dupl_layernorm_fwd16b(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
+                                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
+                                     dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !gamma || !beta || (!y && !y_hi) || ((y_hi == nullptr) != (y_lo == nullptr)) || rows <= 0 || D <= 0 || (D & 3) ||
-        D > LN_MAXC_LIMIT * 256)
+        D > LN_MAXC_LIMIT * 256 || f32_rows < 0 || f32_rows > rows || (f32_rows && !y_hi))
         return DUPL_ERR_ARG;
     const int grid = (int)((rows + 3) / 4);
 #define LN_FWD(MC) hipLaunchKernelGGL(layernorm_fwd_kernel<MC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, gamma, beta, y, \
-                                      mean, rstd, (long)rows, D, eps, (__half*)y_hi, (__half*)y_lo)
+                                      mean, rstd, (long)rows, D, eps, (__half*)y_hi, (__half*)y_lo, (long)f32_rows)
     if (D <= 256) LN_FWD(1);
     else if (D <= 768) LN_FWD(3);
     else if (D <= 1024) LN_FWD(4);

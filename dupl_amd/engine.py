@@ -476,11 +476,12 @@ class EncoderSaved:
     rstd_f: Tensor = None
 
 
-def encoder_forward(P: StudentParams, x: Tensor, save: bool):
+def encoder_forward(P: StudentParams, x: Tensor, save: bool, save_rows: int = 0):
     """forward_features (vit.py:308-326).  Returns (tokens_final [B*(1+n), D], tokens_aux [B*(1+n), D], saved).
-    tokens_aux = output of block `aux_layer` (un-normalised unless it is the last block)."""
+    tokens_aux = output of block `aux_layer` (un-normalised unless it is the last block).
+    save_rows: only the first save_rows token rows will be back-propagated (f16x3 mode: their fp32 copies only)."""
     if GEMM_MODE == "f16x3":
-        return _encoder_forward16(P, [x], save)[0]
+        return _encoder_forward16(P, [x], save, save_rows)[0]
     cfg = P.cfg
     B, _, Himg, Wimg = x.shape
     h, w = Himg // cfg.patch, Wimg // cfg.patch
@@ -520,7 +521,7 @@ def encoder_forward(P: StudentParams, x: Tensor, save: bool):
     return tf, aux, sv
 
 
-def _encoder_forward16(P: StudentParams, xs, save: bool):
+def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
     """forward_features of ONE or SEVERAL batches (different resolutions) with every Linear on the f16x3 split GEMM.
     Token rows of all batches are concatenated (every row-wise kernel runs once over all of them, attention per batch on
     its row slice -- the merged ms-CAM pass of cam_logits_multi); with save=True (single batch only) the fp32 copies
@@ -535,6 +536,11 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
     assert not (save and len(xs) > 1)
     P.store.ensure_w16(P.student)
     guard = P.store.guard.sites(P.student)      # which sites may run on fp16 planes (RangeGuard); the others run on f32
+    # save_rows > 0 (shared ms-CAM / training pass: rows of the un-flipped images come first and only they are back-propagated):
+    # the fp32 copies the backward needs are produced for those rows only -- planes, which the forward consumes, for all rows.
+    # Only while every site runs on planes (an f32-routed consumer needs its fp32 input for all rows).
+    if save_rows and not (hd == 64 and all(b[k] for b in guard["blocks"] for k in RangeGuard.SITES)):
+        save_rows = 0
     toks, groups = [], []
     r0 = 0
     for x in xs:
@@ -565,26 +571,30 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
         g = guard["blocks"][i]
         attn16 = hd == 64 and g["attn"]          # q, k, v as planes into the split attention kernel
         ln1, ln1_16, m1, r1 = ops.layernorm_fwd16(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, save,
-                                                  want_f32=save or not g["qkv"])
+                                                  want_f32=save or not g["qkv"], f32_rows=save_rows)
         lse = None
         # q, k, v stay fp16 planes end to end where their range allows: the qkv GEMM writes them, the split attention kernel
         # reads them and writes the planes the projection GEMM consumes; fp32 copies only where the backward (save) or an
         # f32-routed consumer needs them
+        # the fp32 q / k / v exist only for consumers that cannot take planes: the f32 attention kernels (other head dims, an
+        # out-of-range verdict) and the f32 attention backward of sequences beyond 2 048 tokens
+        need_qkv32 = (not attn16) or (save and max(gr[2] for gr in groups) > 2048)
         if g["qkv"]:
             qkv, qkv16 = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"],
-                                      want_f32=save or not attn16, want16=attn16)
+                                      want_f32=need_qkv32, want16=attn16)
         else:
             qkv = ops.linear(ln1, W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"])
             qkv16 = ops.split16(qkv) if attn16 else None
         del ln1_16
         need_att32 = save or not g["proj"]
-        att = torch.empty((R, D), device=t.device, dtype=torch.float32) if (need_att32 or not attn16) else None
+        att = torch.empty((save_rows or R, D), device=t.device, dtype=torch.float32) if (need_att32 or not attn16) else None
         att16 = ops.split16_empty(R, D, t.device) if (attn16 and g["proj"]) else None
         for (g0, B, N, _, _) in groups:
             if attn16:
+                bf = save_rows // N if save_rows else 0
                 lse = ops.attention_fwd16(qkv16.rows_slice(g0, g0 + B * N), B, N, H, hd, scale, need_lse=save,
-                                          out=att[g0:g0 + B * N] if att is not None else None,
-                                          out16=att16.rows_slice(g0, g0 + B * N) if att16 is not None else None)
+                                          out=att[g0:g0 + (bf or B) * N] if att is not None else None,
+                                          out16=att16.rows_slice(g0, g0 + B * N) if att16 is not None else None, b_f32=bf)
             else:   # other head dims (the 96-dim test backbone) or q / k / v beyond fp16's range: exact-f32 attention kernel
                 _, lse = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
         if not attn16 and g["proj"]:
@@ -597,11 +607,11 @@ def _encoder_forward16(P: StudentParams, xs, save: bool):
             x_mid = ops.linear(att, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], res=t)
         del att16
         ln2, ln2_16, m2, r2 = ops.layernorm_fwd16(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save,
-                                                  want_f32=save or not g["fc1"])
-        pre1 = torch.empty((R, D * cfg.mlp_ratio), device=t.device, dtype=torch.float32) if save else None
+                                                  want_f32=save or not g["fc1"], f32_rows=save_rows)
+        pre1 = torch.empty((save_rows or R, D * cfg.mlp_ratio), device=t.device, dtype=torch.float32) if save else None
         if g["fc1"]:
             h1, h1_16 = ops.linear16(ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio), W[p + "mlp.fc1.bias"], gelu=True,
-                                     store_pre=pre1, want_f32=save or not g["fc2"], want16=g["fc2"])
+                                     store_pre=pre1, want_f32=save or not g["fc2"], want16=g["fc2"], c_rows=save_rows)
         else:
             h1 = ops.linear(ln2, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], gelu=True, store_pre=pre1)
             h1_16 = ops.split16(h1) if g["fc2"] else None
@@ -718,7 +728,8 @@ def _prefix_saved(sv: EncoderSaved, b: int, rows: int) -> EncoderSaved:
     out = EncoderSaved(B=b, h=sv.h, w=sv.w, x_img=sv.x_img[:b])
     for s in sv.blocks:
         out.blocks.append(BlockSaved(x_in=s.x_in[:rows], mean1=s.mean1[:rows], rstd1=s.rstd1[:rows], ln1=s.ln1[:rows],
-                                     qkv=s.qkv[:rows], lse=s.lse[:b], att=s.att[:rows], x_mid=s.x_mid[:rows],
+                                     qkv=s.qkv[:rows] if s.qkv is not None else None, lse=s.lse[:b], att=s.att[:rows],
+                                     x_mid=s.x_mid[:rows],
                                      mean2=s.mean2[:rows], rstd2=s.rstd2[:rows], ln2=s.ln2[:rows], pre1=s.pre1[:rows],
                                      h1=s.h1[:rows], qkv16=s.qkv16.rows_slice(0, rows) if s.qkv16 is not None else None))
     out.x_last, out.mean_f, out.rstd_f = sv.x_last[:rows], sv.mean_f[:rows], sv.rstd_f[:rows]
@@ -734,10 +745,11 @@ def cam_logits_shared(P: StudentParams, x2: Tensor, b: int):
     C = P.num_classes - 1
     Wc = P.w["classifier.weight"].view(C, -1)
     Wa = P.w["aux_classifier.weight"].view(C, -1)
-    tf, aux, enc = encoder_forward(P, x2, save=True)
+    rows = (x2.shape[0] // 2) * ((x2.shape[2] // P.cfg.patch) * (x2.shape[3] // P.cfg.patch) + 1)
+    tf, aux, enc = encoder_forward(P, x2, save=True, save_rows=rows)
     cam = ops.linear(tf, Wc)
     cam_aux = ops.linear(aux, Wa)
-    rows = tf.shape[0] // 2
+    assert rows == tf.shape[0] // 2
     return cam_aux, cam, (tf[:rows], aux[:rows], _prefix_saved(enc, b, rows))
 
 

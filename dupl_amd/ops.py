@@ -165,7 +165,7 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
              res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None,
              want_f32: bool = True, out16: Optional[Split16] = None, want16: bool = False, device=None,
              alpha: Optional[int] = None, accumulate: bool = False, dgelu_of: Optional[Tensor] = None,
-             relumask_of: Optional[Tensor] = None):
+             relumask_of: Optional[Tensor] = None, c_rows: int = 0):
     """y = act(alpha * x W^T + bias) (+ res) on the f16x3 split GEMM.  x: Split16 / Split16View [M, K]; W: Split16 [N, K].
     alpha: device pointer of a float (inverse scale of scaled gradient planes).  accumulate: out += alpha * x W^T (weight
     gradients; split-K).  dgelu_of / relumask_of: multiply by gelu'(pre) / (post > 0) (data gradients through an activation).
@@ -177,8 +177,9 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
         store_pre = dgelu_of if dgelu_of is not None else relumask_of
     dev = device if device is not None else (x.planes.device if isinstance(x, Split16) else x.base.planes.device)
     y = None
+    # c_rows > 0: the fp32 outputs (y, store_pre) exist for the first c_rows rows only (the planes for all M)
     if want_f32 or out is not None:
-        y = out if out is not None else torch.empty((M, N), device=dev, dtype=torch.float32)
+        y = out if out is not None else torch.empty((c_rows or M, N), device=dev, dtype=torch.float32)
     y16 = out16 if out16 is not None else (split16_empty(M, N, dev) if want16 else None)
     d = _lib.Gemm16Desc()
     d.A_hi, d.A_lo, d.B_hi, d.B_lo = x.hi, x.lo, W.hi, W.lo
@@ -195,6 +196,9 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
                                                                   (_lib.GEMM_STORE_PRE if store_pre is not None else 0))
     d.flags = (_lib.GEMM_GELU if gelu else 0) | (_lib.GEMM_RELU if relu else 0) | aux_flag | (_lib.GEMM_ACCUM if accumulate else 0)
     d.alpha_dev = alpha
+    d.c_rows = int(c_rows)
+    if c_rows:
+        assert y16 is not None and (y is None or y.shape[0] >= c_rows) and (store_pre is None or store_pre.shape[0] >= c_rows)
     L().dupl_gemm_f16x3(ctypes.byref(d), _stream())
     return y, y16
 
@@ -262,18 +266,21 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bool
     return y, mean, rstd
 
 
-def layernorm_fwd16(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bool = False, want_f32: bool = False):
+def layernorm_fwd16(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bool = False, want_f32: bool = False,
+                    f32_rows: int = 0):
     """LayerNorm whose output goes out as f16x3 operand planes (and as fp32 too when want_f32, e.g. saved for backward).
+    f32_rows > 0: the fp32 copy and mean / rstd are produced for the first f32_rows rows only (and have that many rows).
     Returns (y fp32 or None, y16 Split16, mean, rstd)."""
     rows, D = x.shape
-    y = torch.empty_like(x) if want_f32 else None
+    keep = f32_rows or rows
+    y = torch.empty((keep, D), device=x.device, dtype=torch.float32) if want_f32 else None
     y16 = split16_empty(rows, D, x.device)
     mean = rstd = None
     if save:
-        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
-        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-    L().dupl_layernorm_fwd16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y), y16.hi, y16.lo, _p(mean), _p(rstd), rows, D,
-                             eps, _stream())
+        mean = torch.empty(keep, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(keep, device=x.device, dtype=torch.float32)
+    L().dupl_layernorm_fwd16b(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y), y16.hi, y16.lo, _p(mean), _p(rstd), rows, D,
+                              eps, int(f32_rows), _stream())
     return y, y16, mean, rstd
 
 
@@ -300,7 +307,7 @@ def attention_fwd(qkv: Tensor, B: int, N: int, H: int, hd: int, scale: float, ne
 
 
 def attention_fwd16(qkv16, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool = False,
-                    out: Optional[Tensor] = None, out16=None):
+                    out: Optional[Tensor] = None, out16=None, b_f32: int = 0):
     """Attention forward on the f16x3 split kernels (head dim 64).  qkv16: Split16 / Split16View [B*N, 3*H*hd] (planes of
     the qkv GEMM output); out: optional fp32 [B*N, H*hd] destination; out16: optional Split16 / Split16View [B*N, H*hd]
     receiving the planes of the output.  Returns lse (B, H, N) or None."""
@@ -308,12 +315,13 @@ def attention_fwd16(qkv16, B: int, N: int, H: int, hd: int, scale: float, need_l
     dev = out.device if out is not None else (out16.planes.device if isinstance(out16, Split16) else out16.base.planes.device)
     npad = (N + 63) // 64 * 64
     vt = torch.empty((2, B * H * hd * npad), device=dev, dtype=torch.float16)
-    lse = torch.empty((B, H, N), device=dev, dtype=torch.float32) if need_lse else None
+    bf = b_f32 or B          # fp32 out / lse for the first bf images only (the planes for all B)
+    lse = torch.empty((bf, H, N), device=dev, dtype=torch.float32) if need_lse else None
     if out is not None:
-        assert out.shape == (B * N, H * hd) and out.is_contiguous()
-    L().dupl_attention_fwd16(qkv16.hi, qkv16.lo, vt.data_ptr(), vt.data_ptr() + 2 * vt.shape[1], _p(out),
-                             out16.hi if out16 is not None else None, out16.lo if out16 is not None else None, _p(lse),
-                             B, N, H, hd, npad, float(scale), _stream())
+        assert out.shape == (bf * N, H * hd) and out.is_contiguous()
+    L().dupl_attention_fwd16b(qkv16.hi, qkv16.lo, vt.data_ptr(), vt.data_ptr() + 2 * vt.shape[1], _p(out),
+                              out16.hi if out16 is not None else None, out16.lo if out16 is not None else None, _p(lse),
+                              B, N, H, hd, npad, float(scale), bf, _stream())
     return lse
 
 

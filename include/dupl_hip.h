@@ -85,7 +85,9 @@ typedef struct dupl_gemm16_desc {
     int32_t M, N, K;
     int32_t lda, ldb, ldc, ldo, ldr, ldaux;
     int32_t flags;
-    int32_t reserved;
+    int32_t c_rows;                       /* > 0: the fp32 outputs (C, and aux under DUPL_GEMM_STORE_PRE) are written for rows < c_rows only --
+                                             the planes for all M rows (shared ms-CAM / training pass: only the training rows are
+                                             back-propagated); 0 = all rows */
     const float* alpha_dev;               /* device scalar multiplied into A.B^T before the epilogue (inverse operand scales of
                                              scaled gradient planes, dupl_split_prepare), or NULL (= 1) */
 } dupl_gemm16_desc;
@@ -145,6 +147,9 @@ int dupl_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
  * dupl_gemm_f16x3 (y may be NULL when only the planes are wanted; y_hi / y_lo both NULL = dupl_layernorm_fwd) */
 int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
                          float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s);
+/* the same with the fp32 copy y (and mean / rstd) written for the first f32_rows rows only (0 = all): y then has f32_rows rows */
+int dupl_layernorm_fwd16b(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
+                          float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows, dupl_stream_t s);
 /* LayerNorm backward (autograd of vit.py:157,159,323), optionally fused with the residual-stream gradient add */
 int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
@@ -172,6 +177,11 @@ int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int3
 int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
                          void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
                          dupl_stream_t s);
+/* the same with the fp32 output and lse written for the first B_f32 images only (out: [B_f32*N][H*hd], lse: [B_f32][H][N]); the
+ * planes for all B */
+int dupl_attention_fwd16b(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi, void* out_lo,
+                          float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, int32_t B_f32,
+                          dupl_stream_t s);
 /* backward (what autograd derives for vit.py:123-135): dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N]. */
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,
