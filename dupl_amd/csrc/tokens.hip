@@ -103,17 +103,29 @@ __global__ void assemble_tokens_bwd_kernel(const float* __restrict__ dtok, float
 }
 
 // global max pool over patch rows 1..n of tokens [B][1+n][D]; first index wins ties (torch semantics)
-__global__ __launch_bounds__(256) void gmp_fwd_kernel(const float* __restrict__ tok, float* __restrict__ out,
-                                                      int* __restrict__ idx, int n, int D) {
-    __shared__ float sv[4][64];
-    __shared__ int si[4][64];
+// 16 row groups x 64 columns per block, 4 independent loads in flight per thread: the 48-block launch is latency-bound (it was
+// 83-187 us with 4 row groups and one dependent load at a time)
+__global__ __launch_bounds__(1024) void gmp_fwd_kernel(const float* __restrict__ tok, float* __restrict__ out,
+                                                       int* __restrict__ idx, int n, int D) {
+    constexpr int RG = 16;
+    __shared__ float sv[RG][64];
+    __shared__ int si[RG][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl, b = blockIdx.y;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     if (col < D) {
         const float* base = tok + ((long)b * (n + 1) + 1) * D + col;
-        for (int i = rg; i < n; i += 4) {
+        int i = rg;
+        for (; i + 3 * RG < n; i += 4 * RG) {
+            const float v0 = base[(long)i * D], v1 = base[(long)(i + RG) * D], v2 = base[(long)(i + 2 * RG) * D],
+                        v3 = base[(long)(i + 3 * RG) * D];
+            if (v0 > best) { best = v0; bi = i; }
+            if (v1 > best) { best = v1; bi = i + RG; }
+            if (v2 > best) { best = v2; bi = i + 2 * RG; }
+            if (v3 > best) { best = v3; bi = i + 3 * RG; }
+        }
+        for (; i < n; i += RG) {
             const float v = base[(long)i * D];
             if (v > best) { best = v; bi = i; }
         }
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(256) void gmp_fwd_kernel(const float* __restrict__ 
     __syncthreads();
     if (rg == 0 && col < D) {
 #pragma unroll
-        for (int g = 1; g < 4; ++g) {
+        for (int g = 1; g < RG; ++g) {
             const float v = sv[g][cl];
             const int i = si[g][cl];
             if (v > best || (v == best && i < bi)) { best = v; bi = i; }
@@ -225,7 +237,7 @@ extern "C" int dupl_assemble_tokens_bwd(const float* dtok, float* dpatch, float*
 extern "C" int dupl_gmp_fwd(const float* tokens, float* out, int32_t* idx, int32_t B, int32_t n, int32_t D, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!tokens || !out || !idx || B <= 0 || n <= 0 || D <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(gmp_fwd_kernel, dim3((D + 63) / 64, B), dim3(256), 0, (hipStream_t)s, tokens, out, idx, n, D);
+    hipLaunchKernelGGL(gmp_fwd_kernel, dim3((D + 63) / 64, B), dim3(1024), 0, (hipStream_t)s, tokens, out, idx, n, D);
     return dupl_launch_status();
 }
 
