@@ -48,12 +48,28 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
 }
 
 
+// dupl_gemm16_desc.amax_out: block max of the per-lane max |C| values -> ONE atomic per block (non-negative floats order like
+// their bits; same-address atomics cost ~12 ns each, a per-wave flush would add ~25 us to the tail of a 2048-wave launch).
+// scratch: LDS that no wave reads any more once the first barrier is passed.
+__device__ __forceinline__ void gemm16_amax_flush(unsigned int* out, float amx, float* scratch, const int wave, const int lane,
+                                                  const int nwaves) {
+    amx = wave_max(amx);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = amx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = scratch[0];
+        for (int w = 1; w < nwaves; ++w) m = fmaxf(m, scratch[w]);
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
+}
+
 // Epilogue shared by the split GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) +
 // 4 * (lane >> 5).  (mw, nw): first row / column of this wave's tile; interior: block-uniform, no per-element edge tests.
 template <int WM, int WN>
 __device__ __forceinline__ void gemm16_epilogue(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN], f32x16 (&accX)[WM][WN],
                                                 const int mw, const int nw, const bool interior, const int l31, const int hf,
-                                                const int ksplit) {
+                                                const int ksplit, float& amx) {
     const int fl = p.flags;
     const bool f_pre = fl & DUPL_GEMM_STORE_PRE, f_gelu = fl & DUPL_GEMM_GELU, f_relu = fl & DUPL_GEMM_RELU;
     const bool f_acc = fl & DUPL_GEMM_ACCUM, f_dgelu = fl & DUPL_GEMM_MUL_DGELU, f_rmask = fl & DUPL_GEMM_MUL_RELUMASK;
@@ -88,6 +104,7 @@ __device__ __forceinline__ void gemm16_epilogue(const dupl_gemm16_desc& p, f32x1
                     else *cp += v;
                     continue;
                 }
+                amx = fmaxf(amx, fabsf(v));
                 if (p.C && w32) p.C[(size_t)row * p.ldc + col] = v;
                 if (Ch) {
                     __half h, l;
@@ -115,7 +132,7 @@ __device__ __forceinline__ void gemm16_epilogue(const dupl_gemm16_desc& p, f32x1
 template <int WM, int WN, int WMP, bool SINGLE>
 __device__ __forceinline__ void gemm16_epilogue_lds(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN], f32x16 (&accX)[SINGLE ? 1 : WM][SINGLE ? 1 : WN],
                                                     float* __restrict__ tile, const int mw0, const int nw, const int lane,
-                                                    const int ksplit) {
+                                                    const int ksplit, float& amx) {
     constexpr int TW = 32 * WN, TH = 32 * WMP, LPR = TW / 4, RPI = 64 / LPR;
     static_assert(WM % WMP == 0, "passes");
     const int l31 = lane & 31, hf = lane >> 5;
@@ -219,6 +236,9 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) a[c] = auxp[c]; }
                 {
 _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) v[c] += rp[c]; }
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < nv) amx = fmaxf(amx, fabsf(v[c]));
         if (p.C && w32) {
             float* cp = p.C + (size_t)row * p.ldc + col;
             if (fast) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
@@ -268,7 +288,7 @@ __device__ __forceinline__ Epi16 epi16_setup(const dupl_gemm16_desc& p) {
     return e;
 }
 __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi16& E, const int row, const int col, const int nv,
-                                           const f32x4 t, const float (&bv)[4]) {
+                                           const f32x4 t, const float (&bv)[4], float& amx) {
     const bool fast = E.vec && nv == 4;
     float v[4] = {t[0] + bv[0], t[1] + bv[1], t[2] + bv[2], t[3] + bv[3]};
     float* auxp = p.aux + (size_t)row * p.ldaux + col;
@@ -315,6 +335,9 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
             for (int c = 0; c < 4; ++c) if (c < nv) v[c] += rp[c];
         }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < nv) amx = fmaxf(amx, fabsf(v[c]));
     if (p.C && w32) {
         float* cp = p.C + (size_t)row * p.ldc + col;
         if (fast) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
@@ -349,7 +372,8 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
 // float4 global accesses); in-order LDS execution within the wave orders the passes.
 template <int WM, int WN>
 __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN], f32x16 (&accX)[WM][WN],
-                                                     float* __restrict__ side, const int mw, const int nw, const int lane) {
+                                                     float* __restrict__ side, const int mw, const int nw, const int lane,
+                                                     float& amx) {
     static_assert(WN == 2, "side buffer rows are 64 floats");
     const int l31 = lane & 31, hf = lane >> 5;
     const float alpha = p.alpha_dev ? *p.alpha_dev : 1.f;
@@ -377,7 +401,7 @@ __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, 
                 const int r = rl + 4 * k;
                 const f32x4 t = *reinterpret_cast<const f32x4*>(side + r * 64 + cl);
                 const int row = mw + i * 32 + 8 * g + r;
-                if (nv > 0 && row < p.M) epi16_quad(p, E, row, col, nv, t, bv);
+                if (nv > 0 && row < p.M) epi16_quad(p, E, row, col, nv, t, bv, amx);
             }
         }
 }
@@ -492,8 +516,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINB) void gemm_f16x3_kernel(const 
         }
     }
 
+    float amx = 0.f;
     gemm16_epilogue<WM, WN>(p, accM, accX, m0 + wm * (32 * WM), n0 + wn * (32 * WN), m0 + BM <= p.M && n0 + BN <= p.N, l31, hf,
-                            ksplit);
+                            ksplit, amx);
+    if (p.amax_out)
+        gemm16_amax_flush(static_cast<unsigned int*>(p.amax_out), amx, reinterpret_cast<float*>(smem), threadIdx.x >> 6,
+                          threadIdx.x & 63, NWM * NWN);
 }
 
 
@@ -770,8 +798,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_ring_kernel(co
         if (sum == 123.456f) p.C[0] = 1.f;
         return;
     }
+    float amx = 0.f;
     gemm16_epilogue_lds<WM, WN, WMP, SINGLE>(p, accM, accX, reinterpret_cast<float*>(smem) + wave * ((32 * WMP) * (32 * WN)),
-                                             m0 + wm * (32 * WM), n0 + wn * (32 * WN), lane, ksplit);
+                                             m0 + wm * (32 * WM), n0 + wn * (32 * WN), lane, ksplit, amx);
+    if (p.amax_out) gemm16_amax_flush(static_cast<unsigned int*>(p.amax_out), amx, reinterpret_cast<float*>(smem), wave, lane, NWM * NWN);
     if (G16_ABL & 16) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0 && p.aux) {
@@ -906,6 +936,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
 #pragma unroll
     for (int s = 0; s < STAGES; ++s) issue(s);
     bool first = true;
+    float amx = 0.f;                 // max |C| over this block's tiles (dupl_gemm16_desc.amax_out)
     for (;;) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -968,9 +999,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
 #pragma unroll
             for (int s = 0; s < STAGES; ++s) issue(s);
         }
-        gemm16_epilogue_side<WM, WN>(p, accM, accX, reinterpret_cast<float*>(smem + STAGES * STAGE) + wave * 512, mw, nw, lane);
+        gemm16_epilogue_side<WM, WN>(p, accM, accX, reinterpret_cast<float*>(smem + STAGES * STAGE) + wave * 512, mw, nw, lane, amx);
         if (!more) break;
     }
+    if (p.amax_out)
+        gemm16_amax_flush(static_cast<unsigned int*>(p.amax_out), amx, reinterpret_cast<float*>(smem + STAGES * STAGE), wave, lane,
+                          NWM * NWN);
 }
 
 }  // namespace
@@ -1029,6 +1063,7 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
     const bool accum = d->flags & DUPL_GEMM_ACCUM;
     if (accum && (!d->C || d->C_hi || d->bias || d->res || d->c_rows)) return DUPL_ERR_ARG;   // C += alpha * A B^T, nothing else
     if (d->c_rows < 0 || (d->c_rows && (d->flags & (DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK)))) return DUPL_ERR_ARG;
+    if (d->amax_out && (accum || d->c_rows || (reinterpret_cast<uintptr_t>(d->amax_out) & 3))) return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     // split-K for accumulating GEMMs (weight gradients: few output tiles, K = all tokens): >= ~2 blocks per CU,
     // >= 8 k-tiles per split

@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, long rows, int D) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][D]
+                                                            float* __restrict__ dbeta, long rows, int D,
+                                                            unsigned int* __restrict__ amax_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][D] + the block's max |dx| (bits)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
@@ -93,8 +94,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int t = threadIdx.x; t < 2 * D; t += blockDim.x) lds[t] = 0.f;
+    for (int t = threadIdx.x; t < 2 * D + 1; t += blockDim.x) lds[t] = 0.f;
     __syncthreads();
+    float amx = 0.f;
     const long row0 = ((long)blockIdx.x * 4 + wave) * LNB_ROWS;
     for (int rr = 0; rr < LNB_ROWS; ++rr) {
         const long row = row0 + rr;
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 o.z = rs * (g[i].z - m1 - xh[i].z * m2);
                 o.w = rs * (g[i].w - m1 - xh[i].w * m2);
                 if (drr) { const float4 d = drr[c]; o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
+                amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                 dxr[c] = o;
             }
         }
@@ -145,7 +148,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             atomicAdd(&lds[D + 4 * c + 2], db[i].z); atomicAdd(&lds[D + 4 * c + 3], db[i].w);
         }
     }
+    if (amax_out) {      // non-negative floats order like their bits (NaN is dropped by fmaxf, as in the stand-alone amax pass)
+        amx = wave_max(amx);
+        if (lane == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(lds + 2 * D), __float_as_uint(amx));
+    }
     __syncthreads();
+    if (amax_out && threadIdx.x == 0) {
+        const unsigned int b = *reinterpret_cast<const unsigned int*>(lds + 2 * D);
+        if (b) atomicMax(amax_out, b);
+    }
     for (int t = threadIdx.x; t < D; t += blockDim.x) {
         if (dgamma) atomicAdd(&dgamma[t], lds[t]);
         if (dbeta) atomicAdd(&dbeta[t], lds[D + t]);
@@ -243,9 +254,17 @@ extern "C" int dupl_layernorm_fwd16b(const float* x, const float* gamma, const f
     return dupl_launch_status();
 }
 
+extern "C" int dupl_layernorm_bwd2(const float* dy, const float* x, const float* gamma, const float* mean,
+                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                                   int64_t rows, int32_t D, void* amax_out, dupl_stream_t s);
 extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                                   int64_t rows, int32_t D, dupl_stream_t s) {
+    return dupl_layernorm_bwd2(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, nullptr, s);
+}
+extern "C" int dupl_layernorm_bwd2(const float* dy, const float* x, const float* gamma, const float* mean,
+                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                                   int64_t rows, int32_t D, void* amax_out, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256)
         return DUPL_ERR_ARG;
@@ -253,8 +272,8 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
     const bool det = g_dupl_deterministic && (dgamma || dbeta);
     float* dg_k = det ? nullptr : dgamma;
     float* db_k = det ? nullptr : dbeta;
-#define LN_BWD(MC) hipLaunchKernelGGL(layernorm_bwd_kernel<MC>, dim3(grid), dim3(256), 2 * D * sizeof(float), (hipStream_t)s, \
-                                      dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D)
+#define LN_BWD(MC) hipLaunchKernelGGL(layernorm_bwd_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
+                                      dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D, (unsigned int*)amax_out)
     if (D <= 256) LN_BWD(1);
     else if (D <= 768) LN_BWD(3);
     else if (D <= 1024) LN_BWD(4);

@@ -130,27 +130,35 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int dupl_split_prepare2(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
+extern "C" int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
                                    void* lo, void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum,
-                                   dupl_stream_t stream);
+                                   int32_t amax_mode, dupl_stream_t stream);
 
 extern "C" int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
                                   void* hiT, void* loT, int32_t Rp, int32_t target_exp, dupl_stream_t stream) {
-    return dupl_split_prepare2(x, ld, R, C, slot, next_bits, hi, lo, hiT, loT, Rp, target_exp, nullptr, stream);
+    return dupl_split_prepare3(x, ld, R, C, slot, next_bits, hi, lo, hiT, loT, Rp, target_exp, nullptr, 0, stream);
 }
 
 extern "C" int dupl_split_prepare2(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
                                    void* lo, void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum,
                                    dupl_stream_t stream) {
+    return dupl_split_prepare3(x, ld, R, C, slot, next_bits, hi, lo, hiT, loT, Rp, target_exp, colsum_accum, 0, stream);
+}
+
+extern "C" int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
+                                   void* lo, void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum,
+                                   int32_t amax_mode, dupl_stream_t stream) {
     (void)hipGetLastError();
+    if (amax_mode < 0 || amax_mode > 2 || (amax_mode && !slot)) return DUPL_ERR_ARG;
     if (colsum_accum && g_dupl_deterministic) return DUPL_ERR_ARG;     // atomics: the caller uses dupl_colsum in that mode
     if (!x || R <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C || (!hi && !hiT) || ((hi == nullptr) != (lo == nullptr)) ||
         ((hiT == nullptr) != (loT == nullptr)) || (hiT && (Rp < R || (Rp & 7))) || target_exp < 1 || target_exp > 15)
         return DUPL_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15)) return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (slot) {
+    if (slot && amax_mode != 1) {
         if (ld != C) return DUPL_ERR_ARG;      // the amax pass reads the matrix as one contiguous run
+        if (amax_mode == 2 && hipMemsetAsync(reinterpret_cast<unsigned int*>(slot) + 2, 0, 4, s) != hipSuccess) return DUPL_ERR_LAUNCH;
         const long n4 = (long)R * C / 4;
         long g = (n4 + 2047) / 2048;           // >= 8 float4 per thread, at most one block per CU
         if (g > 256) g = 256;

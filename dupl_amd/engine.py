@@ -814,7 +814,7 @@ def _linear_backward32(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
 
 
 def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu_of: Optional[Tensor] = None,
-                       has_bias: bool = True) -> Tensor:
+                       has_bias: bool = True, dx_feeds_split: bool = False) -> Tensor:
     """The same on the f16x3 split GEMM (fp32-equivalent).  The gradient dy is scaled by a power of two from its own
     max-abs before it is split (its values are far below fp16's normal range); both GEMMs run as k-contiguous products
     through transposed operand planes:  dW += dy^T16 . (x^T16)^T,  dx = dy16 . (W^T16)^T  (csrc/split_prep.hip)."""
@@ -828,7 +828,8 @@ def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
     ops.linear16(dyT16, xT16, out=gw.view(N, -1), accumulate=True, alpha=alpha)
     if has_bias and not fuse_bias:
         ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
-    dx, _ = ops.linear16(dy16, P.w16T(name + ".weight", N), alpha=alpha, dgelu_of=dgelu_of)
+    # dx_feeds_split: dx is the next Linear's dy -> its max-abs comes out of this epilogue (ops.reserve_amax)
+    dx, _ = ops.linear16(dy16, P.w16T(name + ".weight", N), alpha=alpha, dgelu_of=dgelu_of, amax_for_next=dx_feeds_split)
     return dx
 
 
@@ -888,8 +889,12 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
     if on_ready is not None:
         on_ready("heads")
     # ---- final LayerNorm
+    f16 = GEMM_MODE == "f16x3"
+    gb = P.store.guard.sites(P.student)["blocks"] if f16 else None
+    # a gradient whose next use is the scaled operand split of an f16x3 Linear backward gets its max-abs from the kernel that
+    # writes it (LayerNorm backward, dgrad epilogue) instead of a pass of its own (ops.reserve_amax)
     dx = ops.layernorm_bwd(dtf, enc.x_last, W["encoder.norm.weight"], enc.mean_f, enc.rstd_f,
-                           G["encoder.norm.weight"], G["encoder.norm.bias"])
+                           G["encoder.norm.weight"], G["encoder.norm.bias"], amax_for_next=f16 and gb[cfg.depth - 1]["fc2"])
     aux_idx = cfg.aux_layer % cfg.depth
     Hh, hd = cfg.num_heads, cfg.head_dim
     scale = hd ** -0.5
@@ -898,27 +903,33 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         s = enc.blocks[i]
         if dta is not None and i == aux_idx:
             ops.axpy_(dx, dta, 1.0)
-        f16 = GEMM_MODE == "f16x3"
-        g = P.store.guard.sites(P.student)["blocks"][i] if f16 else None
+            dx._dupl_amax = None         # modified after its producer took the max
+        g = gb[i] if f16 else None
 
         def lin_bwd(site):      # the site's backward runs where its forward ran: same operands, same range verdict
             return _linear_backward16 if (f16 and g[site]) else _linear_backward32
+
+        def feeds(site):        # does the tensor go into a scaled split next (= is `site`'s backward an f16x3 one)?
+            return {"dx_feeds_split": bool(g[site])} if f16 else {}
+        att16 = f16 and s.qkv16 is not None and N <= 2048
         # MLP
-        dpre1 = lin_bwd("fc2")(P, dx, s.h1, p + "mlp.fc2", dgelu_of=s.pre1)
+        dpre1 = lin_bwd("fc2")(P, dx, s.h1, p + "mlp.fc2", dgelu_of=s.pre1, **(feeds("fc1") if g and g["fc2"] else {}))
         dln2 = lin_bwd("fc1")(P, dpre1, s.ln2, p + "mlp.fc1")
         del dpre1
         dx_mid = ops.layernorm_bwd(dln2, s.x_mid, W[p + "norm2.weight"], s.mean2, s.rstd2,
-                                   G[p + "norm2.weight"], G[p + "norm2.bias"], dres=dx)
+                                   G[p + "norm2.weight"], G[p + "norm2.bias"], dres=dx, amax_for_next=f16 and g["proj"])
         # attention
-        datt = lin_bwd("proj")(P, dx_mid, s.att, p + "attn.proj")
-        if f16 and s.qkv16 is not None and N <= 2048:
+        datt = lin_bwd("proj")(P, dx_mid, s.att, p + "attn.proj",
+                               **({"dx_feeds_split": bool(att16)} if g and g["proj"] else {}))
+        if att16:
             dqkv = ops.attention_bwd16(s.qkv16, s.att, datt, s.lse, B, N, Hh, hd, scale)
         else:
             dqkv = ops.attention_bwd(s.qkv, s.att, datt, s.lse, B, N, Hh, hd, scale)
         dln1 = lin_bwd("qkv")(P, dqkv, s.ln1, p + "attn.qkv")
         del dqkv, datt
         dx = ops.layernorm_bwd(dln1, s.x_in, W[p + "norm1.weight"], s.mean1, s.rstd1,
-                               G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid)
+                               G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid,
+                               amax_for_next=f16 and i > 0 and gb[i - 1]["fc2"])
         enc.blocks[i] = None  # release activations as we go
         if on_ready is not None:
             on_ready(i)

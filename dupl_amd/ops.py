@@ -121,18 +121,44 @@ _SCALE_RINGS = {}
 _RING = 128
 
 
-def _scale_slot(device):
-    """Next slot of this stream's ring of {scale, 1/scale, amax word, -} records (zero-initialised once; every scaled
-    split_prepare zeroes the amax word of its successor, so the ring is self-cleaning in stream order)."""
+def _scale_ring(device):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ring = _SCALE_RINGS.get(key)
     if ring is None:
-        ring = [torch.zeros((_RING, 4), device=device, dtype=torch.float32), 0]
+        # [records, next index, pending producer token]
+        ring = [torch.zeros((_RING, 4), device=device, dtype=torch.float32), 0, None]
         _SCALE_RINGS[key] = ring
-    buf, i = ring
+    return ring
+
+
+def _scale_slot(device):
+    """Next slot of this stream's ring of {scale, 1/scale, amax word, -} records (zero-initialised once; every scaled
+    split_prepare zeroes the amax word of its successor, so the ring is self-cleaning in stream order)."""
+    ring = _scale_ring(device)
+    buf, i = ring[0], ring[1]
     ring[1] = (i + 1) % _RING
     base = buf.data_ptr()
     return base + 16 * i, base + 16 * ((i + 1) % _RING) + 8, buf[i]
+
+
+class _AmaxToken:
+    __slots__ = ("word",)
+
+
+def reserve_amax(device):
+    """For a kernel that is about to PRODUCE a tensor whose next use on this stream is a scaled split_prepare: the amax word
+    of the slot that split will take, and a token.  The producer raises the word to max |tensor| (dupl_gemm16_desc.amax_out,
+    dupl_layernorm_bwd2); tag the tensor with `t._dupl_amax = token` and split_prepare skips its own amax pass.  Returns
+    (None, None) while an earlier reservation is still open (one producer per slot).  A tagged tensor that is modified
+    in place afterwards must drop the tag (`t._dupl_amax = None`); an unclaimed or stale word is cleared by the next
+    scaled split on the stream (amax_mode 2)."""
+    ring = _scale_ring(device)
+    if ring[2] is not None:
+        return None, None
+    tok = _AmaxToken()
+    tok.word = ring[0].data_ptr() + 16 * ring[1] + 8
+    ring[2] = tok
+    return tok.word, tok
 
 
 def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad: int = 0, target_exp: int = 15,
@@ -147,12 +173,19 @@ def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad
     rm = split16_empty(R, C, x.device) if want_rm else None
     T = split16_empty(C, Rp, x.device) if want_T else None
     slot = nxt = rec = None
+    amax_mode = 0
     if scaled:
+        ring = _scale_ring(x.device)
+        pending, ring[2] = ring[2], None
+        if pending is not None:      # a producer wrote into this slot's amax word: x's own (1: no amax pass) or not (2: clear)
+            amax_mode = 1 if getattr(x, "_dupl_amax", None) is pending else 2
         slot, nxt, rec = _scale_slot(x.device)
+        assert pending is None or pending.word == slot + 8
     # colsum_into: [C] fp32 accumulator that receives the column sums of x (a Linear's bias gradient) from the same pass
-    rc = L().dupl_split_prepare2(x.data_ptr(), x.stride(0), R, C, slot, nxt, rm.hi if rm else None, rm.lo if rm else None,
-                                 T.hi if T else None, T.lo if T else None, Rp, target_exp, _p(colsum_into), _stream())
-    assert rc == 0, f"dupl_split_prepare2 failed ({rc})"
+    rc = L().dupl_split_prepare3(x.data_ptr(), x.stride(0), R, C, slot, nxt, rm.hi if rm else None, rm.lo if rm else None,
+                                 T.hi if T else None, T.lo if T else None, Rp, target_exp, _p(colsum_into), amax_mode,
+                                 _stream())
+    assert rc == 0, f"dupl_split_prepare3 failed ({rc})"
     if scaled:
         for o in (rm, T):
             if o is not None:
@@ -165,10 +198,12 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
              res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None,
              want_f32: bool = True, out16: Optional[Split16] = None, want16: bool = False, device=None,
              alpha: Optional[int] = None, accumulate: bool = False, dgelu_of: Optional[Tensor] = None,
-             relumask_of: Optional[Tensor] = None, c_rows: int = 0):
+             relumask_of: Optional[Tensor] = None, c_rows: int = 0, amax_for_next: bool = False):
     """y = act(alpha * x W^T + bias) (+ res) on the f16x3 split GEMM.  x: Split16 / Split16View [M, K]; W: Split16 [N, K].
     alpha: device pointer of a float (inverse scale of scaled gradient planes).  accumulate: out += alpha * x W^T (weight
     gradients; split-K).  dgelu_of / relumask_of: multiply by gelu'(pre) / (post > 0) (data gradients through an activation).
+    amax_for_next: y's next use on this stream is a scaled split_prepare -- the epilogue leaves max |y| in that split's
+    slot (reserve_amax) and y is tagged, so the split needs no amax pass.
     Returns (y fp32 [M, N] or None, y as Split16 or None)."""
     M, K, N = x.rows, x.cols, W.rows
     assert W.cols == K and K % 32 == 0
@@ -197,9 +232,14 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     d.flags = (_lib.GEMM_GELU if gelu else 0) | (_lib.GEMM_RELU if relu else 0) | aux_flag | (_lib.GEMM_ACCUM if accumulate else 0)
     d.alpha_dev = alpha
     d.c_rows = int(c_rows)
+    tok = None
+    if amax_for_next and y is not None and not accumulate and not c_rows:
+        d.amax_out, tok = reserve_amax(dev)
     if c_rows:
         assert y16 is not None and (y is None or y.shape[0] >= c_rows) and (store_pre is None or store_pre.shape[0] >= c_rows)
     L().dupl_gemm_f16x3(ctypes.byref(d), _stream())
+    if tok is not None:
+        y._dupl_amax = tok
     return y, y16
 
 
@@ -285,12 +325,15 @@ def layernorm_fwd16(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bo
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor,
-                  dres: Optional[Tensor] = None) -> Tensor:
-    """Returns dx = dres + LN'(dy); accumulates into dgamma / dbeta (atomics)."""
+                  dres: Optional[Tensor] = None, amax_for_next: bool = False) -> Tensor:
+    """Returns dx = dres + LN'(dy); accumulates into dgamma / dbeta (atomics).  amax_for_next: as in linear16."""
     rows, D = x.shape
     dx = torch.empty_like(x)
-    L().dupl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
-                           dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, _stream())
+    word, tok = reserve_amax(x.device) if amax_for_next else (None, None)
+    L().dupl_layernorm_bwd2(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
+                            dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, word, _stream())
+    if tok is not None:
+        dx._dupl_amax = tok
     return dx
 
 

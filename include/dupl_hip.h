@@ -90,6 +90,9 @@ typedef struct dupl_gemm16_desc {
                                              back-propagated); 0 = all rows */
     const float* alpha_dev;               /* device scalar multiplied into A.B^T before the epilogue (inverse operand scales of
                                              scaled gradient planes, dupl_split_prepare), or NULL (= 1) */
+    void* amax_out;                       /* NULL, or the amax word of a scale slot (dupl_split_prepare3, amax_mode 1): the kernel
+                                             raises it (atomic max on the bits) to max |C| over the M x N result, so that the
+                                             split of C needs no pass of its own.  Not with DUPL_GEMM_ACCUM or c_rows. */
 } dupl_gemm16_desc;
 int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream);
 /* the operand split of the GEMM above: n fp32 values (n % 4 == 0) -> hi / lo fp16 planes (no reference counterpart) */
@@ -110,6 +113,12 @@ int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* 
  * dupl_colsum there). */
 int dupl_split_prepare2(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
                         void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum, dupl_stream_t stream);
+/* the same with the source of the amax word of `slot` chosen by amax_mode: 0 = this call computes it (the word must be zero on
+ * entry, as above); 1 = the kernel that produced x has left max |x| there already (dupl_gemm16_desc.amax_out,
+ * dupl_layernorm_bwd2): no amax pass; 2 = the word may hold a stale value: it is cleared (memset node), then computed. */
+int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
+                        void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum, int32_t amax_mode,
+                        dupl_stream_t stream);
 /* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 3: 128x64 on 4 waves, 5: 128x128 on 8 waves, 6 / 7: 256x128 ring
  * kernel on 8 / 4 waves; 8 / 9: single-accumulator 256x256 timing probes, results only valid for unscaled lo planes) */
 int dupl_set_gemm16_tile(int32_t t);
@@ -154,6 +163,10 @@ int dupl_layernorm_fwd16b(const float* x, const float* gamma, const float* beta,
 int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                        int64_t rows, int32_t D, dupl_stream_t s);
+/* the same, and max |dx| raised into *amax_out (the amax word of a scale slot, see dupl_split_prepare3) when amax_out != NULL */
+int dupl_layernorm_bwd2(const float* dy, const float* x, const float* gamma, const float* mean,
+                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                        int64_t rows, int32_t D, void* amax_out, dupl_stream_t s);
 
 /* column sums: out[n] (+)= sum_m x[m][n]: the bias gradients autograd derives for nn.Linear (vit.py:92-102,115-122)
  * and the patch-embed conv (vit.py:176-183).  accumulate!=0 adds to out (atomic). */

@@ -947,3 +947,74 @@ def test_cam_fuse_band_kernel_is_bit_identical(dev, B, C, H, W, sizes):
     torch.cuda.synchronize()
     assert torch.equal(cam0, cam1) and torch.equal(mm0, mm1)
     assert float(cam1.max()) > 0 and float(mm1[:, 0].min()) == 0.0
+
+
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 10])
+@pytest.mark.parametrize("M,N,K", [(3140, 768, 3072), (3140, 3072, 768), (130, 96, 288)])
+def test_producer_amax_replaces_the_amax_pass(dev, M, N, K, tile):
+    """dupl_gemm16_desc.amax_out / dupl_layernorm_bwd2: the kernel that WRITES a gradient leaves max |gradient| in the scale
+    slot of the split that reads it next (ops.reserve_amax), so dupl_split_prepare3 runs without its own amax pass
+    (amax_mode 1).  Bars: the word equals the tensor's max-abs bit for bit; the planes and the scale are identical to those of
+    the stand-alone pass; an unclaimed reservation (tensor modified / not split next) is cleared (amax_mode 2)."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + tile)
+    dy = (torch.randn(M, N, generator=g) * 3e-6).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    pre = torch.randn(M, K, generator=g).to(dev)
+    dy16, _, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False)
+    _, WT16, _ = ops.split_prepare(W, scaled=False, want_rm=False, want_T=True, rows_pad=N)
+    ops.L().dupl_set_gemm16_tile(tile)
+    try:
+        ref, _ = ops.linear16(dy16, WT16, alpha=alpha, dgelu_of=pre)
+        ring = ops._scale_ring(dev)
+        assert ring[2] is None
+        dx, _ = ops.linear16(dy16, WT16, alpha=alpha, dgelu_of=pre, amax_for_next=True)
+    finally:
+        ops.L().dupl_set_gemm16_tile(0)
+    assert torch.equal(dx, ref)
+    tok = dx._dupl_amax
+    assert tok is ring[2] and tok.word == ring[0].data_ptr() + 16 * ring[1] + 8
+    word = ring[0][ring[1], 2].clone()
+    assert float(word) == float(dx.abs().max()) > 0
+    # a second reservation while one is open is refused (one producer per slot)
+    assert ops.reserve_amax(dev) == (None, None)
+    a16, aT16, _ = ops.split_prepare(dx, scaled=True, want_rm=True, want_T=True)
+    assert ring[2] is None
+    b16, bT16, _ = ops.split_prepare(ref, scaled=True, want_rm=True, want_T=True)          # stand-alone amax pass
+    assert torch.equal(a16.planes, b16.planes) and torch.equal(aT16.planes, bT16.planes)
+    assert torch.equal(a16.planes._dupl_scale[:2], b16.planes._dupl_scale[:2])
+    # unclaimed reservation: the producer's max must not leak into the scale of another (much smaller) tensor
+    dx2, _ = ops.linear16(dy16, WT16, alpha=alpha, dgelu_of=pre, amax_for_next=True)
+    small = ref * 2.0 ** -20
+    c16, _, _ = ops.split_prepare(small, scaled=True, want_rm=True, want_T=False)
+    assert ring[2] is None
+    assert float(c16.planes._dupl_scale[0]) == float(b16.planes._dupl_scale[0]) * 2.0 ** 20
+    # ... and a tag dropped after an in-place update falls back to the amax pass of the updated values
+    dx3, _ = ops.linear16(dy16, WT16, alpha=alpha, dgelu_of=pre, amax_for_next=True)
+    dx3.mul_(8.0)
+    dx3._dupl_amax = None
+    d16, _, _ = ops.split_prepare(dx3, scaled=True, want_rm=True, want_T=False)
+    assert float(d16.planes._dupl_scale[0]) == float(b16.planes._dupl_scale[0]) / 8.0
+    assert torch.equal(d16.planes, b16.planes)
+
+
+@pytest.mark.parametrize("rows,D", [(3140, 768), (37, 192), (785, 1024)])
+def test_layernorm_bwd_leaves_amax_for_the_next_split(dev, rows, D):
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g).to(dev)
+    dy = (torch.randn(rows, D, generator=g) * 1e-5).to(dev)
+    dres = (torch.randn(rows, D, generator=g) * 1e-5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    mean = x.mean(1)
+    rstd = (x.var(1, unbiased=False) + 1e-6).rsqrt()
+    dg0, db0 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    dg1, db1 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    ref = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg0, db0, dres=dres)
+    ring = ops._scale_ring(dev)
+    dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg1, db1, dres=dres, amax_for_next=True)
+    assert torch.equal(dx, ref)
+    assert float(ring[0][ring[1], 2]) == float(dx.abs().max()) > 0
+    a16, _, _ = ops.split_prepare(dx, scaled=True, want_rm=True, want_T=False)
+    b16, _, _ = ops.split_prepare(ref, scaled=True, want_rm=True, want_T=False)
+    assert torch.equal(a16.planes, b16.planes) and torch.equal(a16.planes._dupl_scale[:2], b16.planes._dupl_scale[:2])
