@@ -67,6 +67,14 @@ __device__ __forceinline__ void split_regs(const f32x16& v, h8 (&hi)[2], h8 (&lo
 }
 
 // delta[b][h][q] = sum_d dO[q][d] * O[q][d]   (fp32 operands)
+// max |dq| / |dk| / |dv| of a wave -> the amax word of the scale slot the split of dqkv will use (dupl_split_prepare3, amax_mode 1):
+// one atomic per wave (non-negative floats order like their bits); the waves of the ~340 blocks retire spread over the launch
+__device__ __forceinline__ void attn_bwd_amax_flush(unsigned int* amax_out, float amx) {
+    if (!amax_out) return;
+    amx = wave_max(amx);
+    if ((threadIdx.x & 63) == 0 && amx > 0.f) atomicMax(amax_out, __float_as_uint(amx));
+}
+
 __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ out, const float* __restrict__ dout,
                                                     float* __restrict__ delta, int B, int N, int H) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dq_kernel(const __half* __r
                                                                const __half* __restrict__ do_hi, const __half* __restrict__ do_lo,
                                                                const __half* __restrict__ kT_hi, const __half* __restrict__ kT_lo,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               const float* __restrict__ slot, float* __restrict__ dqkv, int N, int H,
+                                                               const float* __restrict__ slot, float* __restrict__ dqkv, unsigned int* __restrict__ amax_out, int N, int H,
                                                                int Npad, float scale, int remap) {
     constexpr int STAGE = 6 * PL;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
@@ -240,20 +248,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dq_kernel(const __half* __r
             }
         }
     }
-    if (!wave_active || !qv) return;
-    const float f = scale * inv_s;
-    float* op = dqkv + ((size_t)b * N + qrow) * ld + h * HD;
+    float amx = 0.f;
+    if (wave_active && qv) {
+        const float f = scale * inv_s;
+        float* op = dqkv + ((size_t)b * N + qrow) * ld + h * HD;
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 v;
-            v.x = (dqM[d][4 * g + 0] + dqX[d][4 * g + 0] * LO_INV) * f;
-            v.y = (dqM[d][4 * g + 1] + dqX[d][4 * g + 1] * LO_INV) * f;
-            v.z = (dqM[d][4 * g + 2] + dqX[d][4 * g + 2] * LO_INV) * f;
-            v.w = (dqM[d][4 * g + 3] + dqX[d][4 * g + 3] * LO_INV) * f;
-            *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hf) = v;
-        }
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = (dqM[d][4 * g + 0] + dqX[d][4 * g + 0] * LO_INV) * f;
+                v.y = (dqM[d][4 * g + 1] + dqX[d][4 * g + 1] * LO_INV) * f;
+                v.z = (dqM[d][4 * g + 2] + dqX[d][4 * g + 2] * LO_INV) * f;
+                v.w = (dqM[d][4 * g + 3] + dqX[d][4 * g + 3] * LO_INV) * f;
+                amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hf) = v;
+            }
+    }
+    attn_bwd_amax_flush(amax_out, amx);
 }
 
 // ---------------------------------------------------------------------------------------------------- dk / dv
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dkv_kernel(const __half* __
                                                                 const __half* __restrict__ do_hi, const __half* __restrict__ do_lo,
                                                                 const __half* __restrict__ xT_hi, const __half* __restrict__ xT_lo,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                const float* __restrict__ slot, float* __restrict__ dqkv, int N, int H,
+                                                                const float* __restrict__ slot, float* __restrict__ dqkv, unsigned int* __restrict__ amax_out, int N, int H,
                                                                 int Npad, float scale, int remap) {
     constexpr int NPL = MODE == 0 ? 4 : 6;
     constexpr int STAGE = NPL * PL;
@@ -386,31 +398,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dkv_kernel(const __half* __
             }
         }
     }
-    if (!wave_active || !kv) return;
-    const float f = MODE == 0 ? inv_s : scale * inv_s;
-    float* op = dqkv + ((size_t)b * N + krow) * ld + (MODE == 0 ? 2 * D : D) + h * HD;
+    float amx = 0.f;
+    if (wave_active && kv) {
+        const float f = MODE == 0 ? inv_s : scale * inv_s;
+        float* op = dqkv + ((size_t)b * N + krow) * ld + (MODE == 0 ? 2 * D : D) + h * HD;
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 v;
-            v.x = (gM[d][4 * g + 0] + gX[d][4 * g + 0] * LO_INV) * f;
-            v.y = (gM[d][4 * g + 1] + gX[d][4 * g + 1] * LO_INV) * f;
-            v.z = (gM[d][4 * g + 2] + gX[d][4 * g + 2] * LO_INV) * f;
-            v.w = (gM[d][4 * g + 3] + gX[d][4 * g + 3] * LO_INV) * f;
-            *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hf) = v;
-        }
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = (gM[d][4 * g + 0] + gX[d][4 * g + 0] * LO_INV) * f;
+                v.y = (gM[d][4 * g + 1] + gX[d][4 * g + 1] * LO_INV) * f;
+                v.z = (gM[d][4 * g + 2] + gX[d][4 * g + 2] * LO_INV) * f;
+                v.w = (gM[d][4 * g + 3] + gX[d][4 * g + 3] * LO_INV) * f;
+                amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hf) = v;
+            }
+    }
+    attn_bwd_amax_flush(amax_out, amx);
 }
 
 }  // namespace
 
 static int g_attnb16_remap = 1;
 
+extern "C" int dupl_attention_bwd16b(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
+                                     const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T,
+                                     float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
+                                     void* amax_out, dupl_stream_t stream);
 extern "C" int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
                                     const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T,
                                     float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
                                     dupl_stream_t stream) {
+    return dupl_attention_bwd16b(qkv_hi, qkv_lo, out, dout, do_hi, do_lo, do_slot, lse, delta, scratch_T, dqkv, B, N, H, hd, Npad, scale,
+                                 nullptr, stream);
+}
+extern "C" int dupl_attention_bwd16b(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
+                                     const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T,
+                                     float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
+                                     void* amax_out, dupl_stream_t stream) {
     (void)hipGetLastError();
+    unsigned int* ax = static_cast<unsigned int*>(amax_out);
     if (!qkv_hi || !qkv_lo || !out || !dout || !do_hi || !do_lo || !do_slot || !lse || !delta || !scratch_T || !dqkv || B <= 0 ||
         N <= 0 || N > MAXN || H <= 0 || hd != HD || Npad < N || (Npad % 64))
         return DUPL_ERR_ARG;
@@ -431,12 +459,12 @@ extern "C" int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, cons
                        N, H, Npad);
     const dim3 grid((N + 127) / 128, H, B);
     hipLaunchKernelGGL(attn_bwd16_dq_kernel, grid, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo, (const __half*)do_hi,
-                       (const __half*)do_lo, kT_hi, kT_lo, lse, delta, do_slot, dqkv, N, H, Npad, scale, g_attnb16_remap);
+                       (const __half*)do_lo, kT_hi, kT_lo, lse, delta, do_slot, dqkv, ax, N, H, Npad, scale, g_attnb16_remap);
     hipLaunchKernelGGL(attn_bwd16_dkv_kernel<0>, grid, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo,
-                       (const __half*)do_hi, (const __half*)do_lo, oT_hi, oT_lo, lse, delta, do_slot, dqkv, N, H, Npad, scale,
+                       (const __half*)do_hi, (const __half*)do_lo, oT_hi, oT_lo, lse, delta, do_slot, dqkv, ax, N, H, Npad, scale,
                        g_attnb16_remap);
     hipLaunchKernelGGL(attn_bwd16_dkv_kernel<1>, grid, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo,
-                       (const __half*)do_hi, (const __half*)do_lo, qT_hi, qT_lo, lse, delta, do_slot, dqkv, N, H, Npad, scale,
+                       (const __half*)do_hi, (const __half*)do_lo, qT_hi, qT_lo, lse, delta, do_slot, dqkv, ax, N, H, Npad, scale,
                        g_attnb16_remap);
     return dupl_launch_status();
 }

@@ -922,7 +922,7 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         datt = lin_bwd("proj")(P, dx_mid, s.att, p + "attn.proj",
                                **({"dx_feeds_split": bool(att16)} if g and g["proj"] else {}))
         if att16:
-            dqkv = ops.attention_bwd16(s.qkv16, s.att, datt, s.lse, B, N, Hh, hd, scale)
+            dqkv = ops.attention_bwd16(s.qkv16, s.att, datt, s.lse, B, N, Hh, hd, scale, amax_for_next=bool(g["qkv"]))
         else:
             dqkv = ops.attention_bwd(s.qkv, s.att, datt, s.lse, B, N, Hh, hd, scale)
         dln1 = lin_bwd("qkv")(P, dqkv, s.ln1, p + "attn.qkv")

@@ -368,9 +368,10 @@ def attention_fwd16(qkv16, B: int, N: int, H: int, hd: int, scale: float, need_l
     return lse
 
 
-def attention_bwd16(qkv16, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, hd: int, scale: float) -> Tensor:
+def attention_bwd16(qkv16, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, hd: int, scale: float,
+                    amax_for_next: bool = False) -> Tensor:
     """Attention backward on the f16x3 split kernels (head dim 64, N <= 2048): qkv16 = the planes of the qkv GEMM output the
-    forward saved; out / dout fp32 [B*N, H*hd]; returns dqkv fp32 [B*N, 3*H*hd]."""
+    forward saved; out / dout fp32 [B*N, H*hd]; returns dqkv fp32 [B*N, 3*H*hd].  amax_for_next: as in linear16."""
     assert hd == 64 and N <= 2048 and qkv16.rows == B * N
     dev = out.device
     dout = dout.contiguous()
@@ -379,8 +380,12 @@ def attention_bwd16(qkv16, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: in
     scratch = torch.empty((6, B * H * hd * npad), device=dev, dtype=torch.float16)
     delta = torch.empty((B, H, N), device=dev, dtype=torch.float32)
     dqkv = torch.empty((B * N, 3 * H * hd), device=dev, dtype=torch.float32)
-    L().dupl_attention_bwd16(qkv16.hi, qkv16.lo, out.data_ptr(), dout.data_ptr(), do16.hi, do16.lo, alpha - 4, lse.data_ptr(),
-                             delta.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(), B, N, H, hd, npad, float(scale), _stream())
+    word, tok = reserve_amax(dev) if amax_for_next else (None, None)       # after dout's split took its slot
+    L().dupl_attention_bwd16b(qkv16.hi, qkv16.lo, out.data_ptr(), dout.data_ptr(), do16.hi, do16.lo, alpha - 4, lse.data_ptr(),
+                              delta.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(), B, N, H, hd, npad, float(scale), word,
+                              _stream())
+    if tok is not None:
+        dqkv._dupl_amax = tok
     return dqkv
 
 

@@ -415,6 +415,10 @@ int dupl_multilabel_f1_accum(const float* logits, const float* label, int32_t B,
 int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
                          const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T, float* dqkv,
                          int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, dupl_stream_t stream);
+/* the same, and max |dqkv| raised into *amax_out (the amax word of a scale slot, see dupl_split_prepare3) when amax_out != NULL */
+int dupl_attention_bwd16b(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
+                         const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T, float* dqkv,
+                         int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, void* amax_out, dupl_stream_t stream);
 
 /* ------------------------------------------------------------------ per-step strong augmentation
  * utils/imutils.py:305-317 augment_data_strong / utils/randomaug.py RandAugment on the device: planar uint8 images

@@ -779,6 +779,14 @@ def test_attention_bwd16_is_fp32_equivalent(dev, B, N):
         e32 = float((d32[:, sl].double() - ref[:, sl]).abs().max()) / sc
         print(f"B{B} N{N} {name}: f16x3 {e16:.2e} f32 {e32:.2e}")
         assert e16 <= 2.0 * e32 + 5e-7, name
+    # the three kernels leave max |dqkv| for the split that reads dqkv next (dupl_attention_bwd16b; ops.reserve_amax)
+    ring = ops._scale_ring(dev)
+    d16b = ops.attention_bwd16(qkv16, out16, dout, lse16, B, N, H, hd, scale, amax_for_next=True)
+    assert torch.equal(d16b, d16) and d16b._dupl_amax is ring[2]
+    assert float(ring[0][ring[1], 2]) == float(d16.abs().max()) > 0
+    a16, _, _ = ops.split_prepare(d16b, scaled=True, want_rm=True, want_T=False)
+    b16, _, _ = ops.split_prepare(d16, scaled=True, want_rm=True, want_T=False)
+    assert torch.equal(a16.planes, b16.planes) and torch.equal(a16.planes._dupl_scale[:2], b16.planes._dupl_scale[:2])
 
 
 # ------------------------------------------------------------------------------------------ f16x3 range: heavy tails, outliers, non-finite
