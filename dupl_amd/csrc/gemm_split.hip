@@ -370,7 +370,7 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
 // side buffer, 8 rows x 64 columns at a time (4 WM passes: MFMA tile i, register group g = rows 8 g .. 8 g + 7 of it).
 // Same access pattern as gemm16_epilogue_lds (b32 writes of 32 consecutive floats, b128 reads of whole 256-byte rows ->
 // float4 global accesses); in-order LDS execution within the wave orders the passes.
-template <int WM, int WN>
+template <int WM, int WN, bool ACC = false>
 __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN], f32x16 (&accX)[WM][WN],
                                                      float* __restrict__ side, const int mw, const int nw, const int lane,
                                                      float& amx) {
@@ -382,7 +382,7 @@ __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, 
     const int col = nw + cl;
     const int nv = min(4, p.N - col);
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && nv > 0) {
+    if (!ACC && p.bias && nv > 0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < nv) bv[c] = p.bias[col + c];
@@ -396,12 +396,24 @@ __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     side[(q + 4 * hf) * 64 + j * 32 + l31] = (accM[i][j][4 * g + q] + accX[i][j][4 * g + q] * LO_INV) * alpha;
+            if constexpr (ACC) {
+                // C += partial (stream-K pieces of a weight gradient meet in fp32 atomics): lane = column, one instruction adds
+                // to 64 consecutive floats of a row
+                if (nw + lane < p.N) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int r = rl + 4 * k;
-                const f32x4 t = *reinterpret_cast<const f32x4*>(side + r * 64 + cl);
-                const int row = mw + i * 32 + 8 * g + r;
-                if (nv > 0 && row < p.M) epi16_quad(p, E, row, col, nv, t, bv, amx);
+                    for (int r = 0; r < 8; ++r) {
+                        const int row = mw + i * 32 + 8 * g + r;
+                        if (row < p.M) unsafeAtomicAdd(p.C + (size_t)row * p.ldc + nw + lane, side[r * 64 + lane]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int r = rl + 4 * k;
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(side + r * 64 + cl);
+                    const int row = mw + i * 32 + 8 * g + r;
+                    if (nv > 0 && row < p.M) epi16_quad(p, E, row, col, nv, t, bv, amx);
+                }
             }
         }
 }
@@ -820,7 +832,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_ring_kernel(co
 // once every wave has left the k-loop; the tile leaves through the side buffer, gemm16_epilogue_side), so a block pays its
 // ~5 k-cycle pipeline fill once per launch instead of once per tile, and blocks drift apart, which spreads the HBM write
 // bursts of the epilogues that otherwise come from all 256 CUs at once.  No split-K (the weight gradients stay on tile 5).
-template <int WM, int WN, int NWM, int NWN, int WPS>
+// SK (stream-K, the weight gradients C += A . B^T with few output tiles and K = all tokens): the linear space of
+// (tile, k-step) pairs is cut into gridDim.x equal runs, one per block, XCD x taking the x-th eighth; a block walks its run
+// piece by piece (a piece = the part of the run inside one tile) and adds every piece to C with fp32 atomics.  No block waits
+// for another one, every CU gets the same number of k-steps whatever the tile count -- a split-K grid of 288 or 540 blocks
+// on 256 CUs leaves the chip half empty for its second round.  Cuts are moved off the first / last two k-steps of a tile, so
+// that every piece has the >= 3 k-steps the three-stage prologue needs.
+template <int WM, int WN, int NWM, int NWN, int WPS, bool SK = false>
 __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(const dupl_gemm16_desc p, const int g_gm) {
     constexpr int STAGES = 3;
     constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, NW = NWM * NWN;
@@ -839,17 +857,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
     const int l31 = lane & 31, hf = lane >> 5;
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int nblk = nbm * nbn;
-    const int nt = p.K / TBK;                     // >= STAGES (host)
+    const int ntf = p.K / TBK;                    // k-steps of a whole tile, >= STAGES (host)
+    int nt = ntf;                                 // k-steps of the current piece (SK: a part of the tile's)
     const int q8 = nblk >> 3, r8 = nblk & 7;
     const int gspan = g_gm * nbn;
-    auto tile_origin = [&](const int bid, int& m0, int& n0) __attribute__((always_inline)) {
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    auto lid_origin = [&](const int lid, int& m0, int& n0) __attribute__((always_inline)) {
         const int gid = lid / gspan, gin = lid - gid * gspan;
         const int gfirst = gid * g_gm;
         const int gsz = min(nbm - gfirst, g_gm);
         m0 = (gfirst + gin % gsz) * BM;
         n0 = (gin / gsz) * BN;
+    };
+    auto tile_origin = [&](const int bid, int& m0, int& n0) __attribute__((always_inline)) {
+        const int xcd = bid & 7, idx = bid >> 3;
+        lid_origin((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx, m0, n0);
     };
     // a block whose first index is past the last tile of its XCD's share has nothing to do (idx >= q8 + (xcd < r8))
     auto has_tile = [&](const int bid) { return (bid >> 3) < q8 + ((bid & 7) < r8 ? 1 : 0); };
@@ -857,7 +878,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
     const int prow = lane >> 2;
     const int jsrc = (lane & 3) ^ ((prow >> 2) & 3);
     const char* gp[PPW];
-    auto plan = [&](const int m0, const int n0) __attribute__((always_inline)) {
+    auto plan = [&](const int m0, const int n0, const int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int g = wave + NW * i;
@@ -868,7 +889,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
             else if (g < 2 * PA + PB) { plane = static_cast<const __half*>(p.B_hi); ld = p.ldb; r0 = n0; R = p.N; q = g - 2 * PA; }
             else { plane = static_cast<const __half*>(p.B_lo); ld = p.ldb; r0 = n0; R = p.N; q = g - 2 * PA - PB; }
             const int row = min(r0 + q * 16 + prow, R - 1);
-            gp[i] = reinterpret_cast<const char*>(plane + (size_t)row * ld) + jsrc * 16;
+            gp[i] = reinterpret_cast<const char*>(plane + (size_t)row * ld + (size_t)k0 * TBK) + jsrc * 16;
         }
     };
     auto issue = [&](int buf) __attribute__((always_inline)) {
@@ -929,10 +950,30 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
     };
 
     int bid = blockIdx.x;
-    if (!has_tile(bid)) return;
+    int pos = 0, pend = 0;           // SK: this block's run of the linear (tile, k-step) space
     int m0, n0;
-    tile_origin(bid, m0, n0);
-    plan(m0, n0);
+    if constexpr (SK) {
+        const int T = nblk * ntf, G = gridDim.x;
+        const int L = (bid & 7) * (G >> 3) + (bid >> 3);
+        auto cut = [&](const int l) {
+            int x = (int)((long)T * l / G);
+            const int r = x % ntf;
+            if (r && r < 3) x -= r;
+            else if (r > ntf - 3) x += ntf - r;
+            return x;
+        };
+        pos = cut(L);
+        pend = cut(L + 1);
+        if (pos >= pend) return;
+        const int lid = pos / ntf, k0 = pos - lid * ntf;
+        nt = min(pend - pos, ntf - k0);
+        lid_origin(lid, m0, n0);
+        plan(m0, n0, k0);
+    } else {
+        if (!has_tile(bid)) return;
+        tile_origin(bid, m0, n0);
+        plan(m0, n0, 0);
+    }
 #pragma unroll
     for (int s = 0; s < STAGES; ++s) issue(s);
     bool first = true;
@@ -991,15 +1032,29 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int mw = m0 + wm * (32 * WM), nw = n0 + wn * (32 * WN);
-        bid += gridDim.x;
-        const bool more = has_tile(bid);
+        bool more;
+        if constexpr (SK) {
+            pos += nt;
+            more = pos < pend;
+            if (more) {              // the piece ended at its tile's last k-step: the next one starts a tile
+                nt = min(pend - pos, ntf);
+                lid_origin(pos / ntf, m0, n0);
+                plan(m0, n0, 0);
+            }
+        } else {
+            bid += gridDim.x;
+            more = has_tile(bid);
+            if (more) {
+                tile_origin(bid, m0, n0);
+                plan(m0, n0, 0);
+            }
+        }
         if (more) {
-            tile_origin(bid, m0, n0);
-            plan(m0, n0);
 #pragma unroll
             for (int s = 0; s < STAGES; ++s) issue(s);
         }
-        gemm16_epilogue_side<WM, WN>(p, accM, accX, reinterpret_cast<float*>(smem + STAGES * STAGE) + wave * 512, mw, nw, lane, amx);
+        gemm16_epilogue_side<WM, WN, SK>(p, accM, accX, reinterpret_cast<float*>(smem + STAGES * STAGE) + wave * 512, mw, nw, lane,
+                                         amx);
         if (!more) break;
     }
     if (p.amax_out)
@@ -1043,7 +1098,7 @@ extern "C" int dupl_set_gemm16_concurrency(int32_t n) {
 }
 
 extern "C" int dupl_set_gemm16_tile(int32_t t) {
-    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9 && t != 10) return DUPL_ERR_ARG;
+    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9 && t != 10 && t != 11) return DUPL_ERR_ARG;
     g16_tile = t;
     return DUPL_OK;
 }
@@ -1081,17 +1136,27 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         // Measured on the shapes of the step (tools/gemm16_bench -w 200 with and without -2, profiles/r03_gemm16_tiles.txt),
         // sustained clocks.  The persistent 256 x 128 ring kernel (tile 10; 6 = the same, one block per tile) is one block
         // per CU: it wins wherever its grid covers a good part of the chip -- >= 64 tiles when a second stream feeds the chip
-        // as well (the two students: dupl_set_gemm16_concurrency(2)), >= 128 tiles alone.  The weight gradients (split-K
-        // partials: short blocks, atomics) stay on 128 x 128 (tile 5, two blocks per CU), grids that would leave most of
-        // its 512 block slots empty on 128 x 64 (tile 3).
+        // as well (the two students: dupl_set_gemm16_concurrency(2)), >= 128 tiles alone.  The weight gradients go to its
+        // stream-K form (tile 11) when every block gets >= 16 k-steps: 3072 x 768 x 3168 alone 155 -> 205 TF/s-eq, with a
+        // second stream 219 -> 238 (there only from 64 tiles on: 2304 x 768 loses 6 % to two co-resident 128 x 128 blocks of
+        // both streams); the rest stay on split-K grids of 128 x 128 (tile 5, two blocks per CU) / 128 x 64 (tile 3).
         const long b256 = (long)((d->M + 255) / 256) * ((d->N + 127) / 128);
         const long b128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * ksplit;
         const bool ring = b256 >= (g16_concurrency >= 2 ? 64 : 128);
         if (!accum && ring) tile = 10;
+        else if (accum && ksplit > 1 && d->K / TBK >= 8 && b256 * (d->K / TBK) >= 16L * g16_persist_blocks &&
+                 (g16_concurrency < 2 || b256 >= 64))
+            tile = 11;
         else tile = b128 < 200 ? 3 : 5;
     }
     auto blocks = [&](int bm, int bn) { return dim3((unsigned)(((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn)), (unsigned)ksplit); };
     if (tile == 10 && (accum || d->K / TBK < 3)) tile = 6;      // the persistent kernel has no split-K and a 3-stage prologue
+    if (tile == 11 && (!accum || g_dupl_deterministic || d->K / TBK < 8)) tile = accum ? 5 : 6;   // stream-K: atomics, pieces >= 3 k-steps
+    if (tile == 11) {
+        hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d,
+                           g16_group_ring);
+        return dupl_launch_status();
+    }
     if (tile == 10) {
         const int nblk = ((d->M + 255) / 256) * ((d->N + 127) / 128);
         int grid = (nblk + 7) / 8 * 8;

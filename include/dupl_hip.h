@@ -120,7 +120,8 @@ int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_t C, float*
                         void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum, int32_t amax_mode,
                         dupl_stream_t stream);
 /* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 3: 128x64 on 4 waves, 5: 128x128 on 8 waves, 6 / 7: 256x128 ring
- * kernel on 8 / 4 waves; 8 / 9: single-accumulator 256x256 timing probes, results only valid for unscaled lo planes) */
+ * kernel on 8 / 4 waves; 8 / 9: single-accumulator 256x256 timing probes, results only valid for unscaled lo planes;
+ * 10: persistent 256x128 ring kernel; 11: its stream-K form for DUPL_GEMM_ACCUM) */
 int dupl_set_gemm16_tile(int32_t t);
 /* hint for the tile heuristic (no reference counterpart): how many streams issue split GEMMs concurrently -- 2 while the two
  * students of siamese_network run on their own streams (model_dupl.py:157-213 runs them back to back), else 1 */

@@ -1026,3 +1026,31 @@ def test_layernorm_bwd_leaves_amax_for_the_next_split(dev, rows, D):
     a16, _, _ = ops.split_prepare(dx, scaled=True, want_rm=True, want_T=False)
     b16, _, _ = ops.split_prepare(ref, scaled=True, want_rm=True, want_T=False)
     assert torch.equal(a16.planes, b16.planes) and torch.equal(a16.planes._dupl_scale[:2], b16.planes._dupl_scale[:2])
+
+
+@pytest.mark.parametrize("M,N,K", [(3072, 768, 3168), (768, 3072, 3168), (2304, 768, 3168), (1000, 520, 3168), (300, 200, 960),
+                                   (257, 129, 256)])
+def test_stream_k_weight_gradient(dev, M, N, K):
+    """Tile 11 (stream-K form of the persistent kernel: every block takes an equal run of (tile, k-step) pairs, pieces meet in
+    fp32 atomics) accumulates the same weight gradient as the split-K grid (tile 5) and as fp64, on top of existing content,
+    incl. ragged M / N, runs that span several tiles and cuts that are moved off a tile's first / last k-steps."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    B = torch.randn(N, K, generator=g).to(dev)
+    A16, B16 = ops.split16(A), ops.split16(B)
+    c0 = torch.randn(M, N, generator=g).to(dev)
+    ref = c0.double() + A.double() @ B.double().t()
+    outs = {}
+    try:
+        for tile in (5, 11):
+            ops.L().dupl_set_gemm16_tile(tile)
+            c = c0.clone()
+            ops.linear16(A16, B16, out=c, accumulate=True)
+            outs[tile] = c
+    finally:
+        ops.L().dupl_set_gemm16_tile(0)
+    sc = float(ref.abs().max())
+    e5, e11 = (float((outs[t].double() - ref).abs().max()) / sc for t in (5, 11))
+    print(f"wgrad {M}x{N}x{K}: tile 5 {e5:.2e} stream-K {e11:.2e}")
+    assert e11 <= 2.0 * e5 + 1e-7
