@@ -103,7 +103,7 @@ class _Lib:
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
             # getters return a value, everything else a status (0 = ok) that is checked on every call
-            setattr(self, name, fn if name in ("dupl_abi_version", "dupl_get_deterministic") else self._checked(name, fn))
+            setattr(self, name, fn if name in ("dupl_abi_version", "dupl_get_deterministic", "dupl_layernorm_bwd_blocks") else self._checked(name, fn))
 
     @staticmethod
     def _checked(name, fn):

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, long rows, int D,
-                                                            unsigned int* __restrict__ amax_out) {
+                                                            unsigned int* __restrict__ amax_out, const int rpw,
+                                                            float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][D] + the block's max |dx| (bits)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int t = threadIdx.x; t < 2 * D + 1; t += blockDim.x) lds[t] = 0.f;
     __syncthreads();
     float amx = 0.f;
-    const long row0 = ((long)blockIdx.x * 4 + wave) * LNB_ROWS;
-    for (int rr = 0; rr < LNB_ROWS; ++rr) {
+    const long row0 = ((long)blockIdx.x * 4 + wave) * rpw;
+    for (int rr = 0; rr < rpw; ++rr) {
         const long row = row0 + rr;
         if (row >= rows) break;
         const float mu = mean[row], rs = rstd[row];
@@ -137,6 +138,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
+    if (part) {          // two-stage form: this WAVE's [dgamma | dbeta] partial (fixed content whatever the schedule), summed by
+                         // ln_dgb_reduce_kernel
+        float4* pg = reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 4 + wave) * 2 * D);
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                pg[c] = dg[i];
+                pg[nch + c] = db[i];
+            }
+        }
+        if (amax_out) {
+            amx = wave_max(amx);
+            if (lane == 0 && amx > 0.f) atomicMax(amax_out, __float_as_uint(amx));
+        }
+        return;
+    }
     // block reduce of dgamma / dbeta through LDS atomics, then one global atomic per column
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
@@ -160,6 +178,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int t = threadIdx.x; t < D; t += blockDim.x) {
         if (dgamma) atomicAdd(&dgamma[t], lds[t]);
         if (dbeta) atomicAdd(&dbeta[t], lds[D + t]);
+    }
+}
+
+// second stage of the two-stage dgamma / dbeta reduction: part [nblk][2 D] (one row per wave of the main kernel) -> dgamma[c] += sum_b part[b][c], dbeta likewise.
+// block = 64 columns x 4 block-groups; gridDim.y > 1 splits the blocks further (atomics); gridDim.y == 1: fixed order, plain +=
+__global__ __launch_bounds__(256) void ln_dgb_reduce_kernel(const float* __restrict__ part, int nblk, int D,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (col < 2 * D) {
+        for (int b = blockIdx.y * 4 + rg; b < nblk; b += gridDim.y * 4) s += part[(size_t)b * 2 * D + col];
+    }
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < 2 * D) {
+        const float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        float* out = col < D ? dgamma : dbeta;
+        if (out) {
+            out += col < D ? col : col - D;
+            if (gridDim.y > 1) atomicAdd(out, v);
+            else *out += v;
+        }
     }
 }
 
@@ -254,31 +296,59 @@ extern "C" int dupl_layernorm_fwd16b(const float* x, const float* gamma, const f
     return dupl_launch_status();
 }
 
-extern "C" int dupl_layernorm_bwd2(const float* dy, const float* x, const float* gamma, const float* mean,
+static int g_lnb_rows = LNB_ROWS;   // rows per wave, atomic form
+static int g_lnb_rows_p = LNB_ROWS; // rows per wave, two-stage form (measured 8 / 4 / 2 / 1: 37 / 27 / 30 / 45 us at 3140 x 768)
+extern "C" int dupl_set_lnb_rows(int32_t n) {
+    if (n < 0 || n > 64) return DUPL_ERR_ARG;
+    g_lnb_rows = n ? n : LNB_ROWS;
+    g_lnb_rows_p = n ? n : LNB_ROWS;
+    return DUPL_OK;
+}
+extern "C" int dupl_layernorm_bwd_blocks(int64_t rows) { return 4 * (int)((rows + 4 * g_lnb_rows_p - 1) / (4 * g_lnb_rows_p)); }
+
+extern "C" int dupl_layernorm_bwd3(const float* dy, const float* x, const float* gamma, const float* mean,
                                    const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                                   int64_t rows, int32_t D, void* amax_out, dupl_stream_t s);
+                                   int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows, dupl_stream_t s);
 extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                                   int64_t rows, int32_t D, dupl_stream_t s) {
-    return dupl_layernorm_bwd2(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, nullptr, s);
+    return dupl_layernorm_bwd3(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, nullptr, nullptr, 0, s);
 }
 extern "C" int dupl_layernorm_bwd2(const float* dy, const float* x, const float* gamma, const float* mean,
                                    const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                                    int64_t rows, int32_t D, void* amax_out, dupl_stream_t s) {
+    return dupl_layernorm_bwd3(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, amax_out, nullptr, 0, s);
+}
+extern "C" int dupl_layernorm_bwd3(const float* dy, const float* x, const float* gamma, const float* mean,
+                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                                   int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256)
         return DUPL_ERR_ARG;
-    const int grid = (int)((rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS));
-    const bool det = g_dupl_deterministic && (dgamma || dbeta);
+    const bool want_dgb = dgamma || dbeta;
+    const bool two_stage = partials && want_dgb;
+    const int rpw = two_stage ? g_lnb_rows_p : g_lnb_rows;
+    const int grid = (int)((rows + 4 * rpw - 1) / (4 * rpw));
+    if (two_stage && partial_rows < 4 * (int64_t)grid) return DUPL_ERR_ARG;      // one partial row per wave
+    // deterministic mode: the two-stage form with a single, fixed-order second stage; without a partials buffer the
+    // separate column-walk pass (ln_dgb_det_kernel)
+    const bool det = g_dupl_deterministic && want_dgb && !two_stage;
     float* dg_k = det ? nullptr : dgamma;
     float* db_k = det ? nullptr : dbeta;
 #define LN_BWD(MC) hipLaunchKernelGGL(layernorm_bwd_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
-                                      dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D, (unsigned int*)amax_out)
+                                      dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D, (unsigned int*)amax_out, rpw, \
+                                      two_stage ? partials : nullptr)
     if (D <= 256) LN_BWD(1);
     else if (D <= 768) LN_BWD(3);
     else if (D <= 1024) LN_BWD(4);
     else LN_BWD(8);
 #undef LN_BWD
+    if (two_stage) {
+        int gy = g_dupl_deterministic ? 1 : (grid + 63) / 64;
+        if (gy > 16) gy = 16;
+        hipLaunchKernelGGL(ln_dgb_reduce_kernel, dim3((2 * D + 63) / 64, gy), dim3(256), 0, (hipStream_t)s, partials, 4 * grid, D,
+                           dgamma, dbeta);
+    }
     if (det)
         hipLaunchKernelGGL(ln_dgb_det_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)s, dy, x, mean, rstd, dgamma, dbeta,
                            (long)rows, D);

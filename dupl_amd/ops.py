@@ -325,13 +325,21 @@ def layernorm_fwd16(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bo
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor,
-                  dres: Optional[Tensor] = None, amax_for_next: bool = False) -> Tensor:
-    """Returns dx = dres + LN'(dy); accumulates into dgamma / dbeta (atomics).  amax_for_next: as in linear16."""
+                  dres: Optional[Tensor] = None, amax_for_next: bool = False, two_stage: Optional[bool] = None) -> Tensor:
+    """Returns dx = dres + LN'(dy); accumulates into dgamma / dbeta -- fp32 atomics from the main kernel, or (two_stage; the
+    default in deterministic mode) per-block partial sums + a fixed-order reduce kernel (dupl_layernorm_bwd3).
+    amax_for_next: as in linear16."""
     rows, D = x.shape
+    if two_stage is None:
+        two_stage = deterministic()
     dx = torch.empty_like(x)
     word, tok = reserve_amax(x.device) if amax_for_next else (None, None)
-    L().dupl_layernorm_bwd2(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
-                            dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, word, _stream())
+    part, nb = None, 0
+    if two_stage:
+        nb = L().dupl_layernorm_bwd_blocks(rows)
+        part = torch.empty((nb, 2 * D), device=x.device, dtype=torch.float32)
+    L().dupl_layernorm_bwd3(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
+                            dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, word, _p(part), nb, _stream())
     if tok is not None:
         dx._dupl_amax = tok
     return dx

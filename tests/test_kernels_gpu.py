@@ -1026,6 +1026,25 @@ def test_layernorm_bwd_leaves_amax_for_the_next_split(dev, rows, D):
     a16, _, _ = ops.split_prepare(dx, scaled=True, want_rm=True, want_T=False)
     b16, _, _ = ops.split_prepare(ref, scaled=True, want_rm=True, want_T=False)
     assert torch.equal(a16.planes, b16.planes) and torch.equal(a16.planes._dupl_scale[:2], b16.planes._dupl_scale[:2])
+    # two-stage dgamma / dbeta (dupl_layernorm_bwd3: per-block partials + reduce kernel): same sums, same dx; fixed order
+    # (bit-reproducible) in deterministic mode
+    xh = ((x - mean[:, None]) * rstd[:, None]).double()
+    for det in (0, 1):
+        ops.L().dupl_set_deterministic(det)
+        try:
+            runs = []
+            for _ in range(2):
+                dg2, db2 = torch.full((D,), 1e-4, device=dev), torch.full((D,), 1e-4, device=dev)   # accumulated into
+                dx2 = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg2, db2, dres=dres, two_stage=True)
+                runs.append((dg2, db2))
+                assert torch.equal(dx2, ref)
+        finally:
+            ops.L().dupl_set_deterministic(0)
+        sg = float((dy.double() * xh).sum(0).abs().max())
+        assert float((runs[0][0].double() - 1e-4 - (dy.double() * xh).sum(0)).abs().max()) <= 1e-5 * (sg + 1e-4)
+        assert float((runs[0][1].double() - 1e-4 - dy.double().sum(0)).abs().max()) <= 1e-5 * (float(dy.double().sum(0).abs().max()) + 1e-4)
+        if det:
+            assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
 
 
 @pytest.mark.parametrize("M,N,K", [(3072, 768, 3168), (768, 3072, 3168), (2304, 768, 3168), (1000, 520, 3168), (300, 200, 960),
