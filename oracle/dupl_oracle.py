@@ -94,10 +94,19 @@ def student_param_shapes(cfg: ViTConfig, num_classes: int) -> Dict[str, Tuple[in
 
 
 def make_student_params(cfg: ViTConfig, num_classes: int, seed: int = 0, prefix: str = "",
-                        std: float = 0.02, randomize_affine: bool = True) -> Dict[str, Tensor]:
+                        std: float = 0.02, randomize_affine: bool = True, pretrained_like: bool = False) -> Dict[str, Tensor]:
     """Hash-generated weights.  Unlike the reference init (biases 0, LN (1,0)) every
-    tensor is randomised when `randomize_affine` so that bias / LN-affine paths are exercised."""
+    tensor is randomised when `randomize_affine` so that bias / LN-affine paths are exercised.
+
+    pretrained_like: the reference starts from ImageNet checkpoints (deit.py:102-108, train_final_voc.py:52-53) that cannot
+    be fetched here; this option gives the tensors the STATISTICS such checkpoints are known for instead of N(0, 0.02):
+    heavy-tailed Linear weights (a log-normal scale mixture, std 0.04), LayerNorm gains spread over more than a decade
+    with four x6 outlier channels, LayerNorm / Linear biases of O(0.3), q / k biases of O(1), pos-embed of O(0.3), and
+    two fc2 output channels per middle block (3 .. 8) with x25 weights that write "massive activations" -- tens to
+    hundreds of times the median -- into the residual stream.  Everything stays inside fp32 comfortably; what it probes is
+    the fp16 exponent window of the product's f16x3 operand planes (range guard, csrc/range.hip)."""
     out: Dict[str, Tensor] = {}
+    D = cfg.embed_dim
     for k, shp in student_param_shapes(cfg, num_classes).items():
         name = prefix + k
         is_norm_w = k.endswith("weight") and ("norm" in k)
@@ -106,10 +115,31 @@ def make_student_params(cfg: ViTConfig, num_classes: int, seed: int = 0, prefix:
             t = hash_normal(name, shp, std=1.0 / math.sqrt(fan_in), seed=seed)
         elif is_norm_w:
             t = 1.0 + hash_normal(name, shp, std=0.1 if randomize_affine else 0.0, seed=seed)
+            if pretrained_like:
+                t = torch.exp(0.6 * hash_normal(name, shp, seed=seed)).clamp(0.05, 6.0)
+                idx = (hash_normal(name + "#oc", (4,), seed=seed).abs() * 1e4).long() % D
+                t[idx] *= 6.0
         elif k.endswith("bias"):
             t = hash_normal(name, shp, std=std if randomize_affine else 0.0, seed=seed)
+            if pretrained_like:
+                t = hash_normal(name, shp, std=0.3, seed=seed)
+                if k.endswith("attn.qkv.bias"):
+                    t[:2 * D] = hash_normal(name + "#qk", (2 * D,), std=1.0, seed=seed)
         else:
             t = hash_normal(name, shp, std=std, seed=seed)
+            if pretrained_like:
+                if k.endswith("pos_embed"):
+                    t = hash_normal(name, shp, std=0.3, seed=seed)
+                elif k.endswith("cls_token"):
+                    t = hash_normal(name, shp, std=0.5, seed=seed)
+                elif k.endswith("patch_embed.proj.weight"):
+                    t = hash_normal(name, shp, std=0.05, seed=seed)
+                elif len(shp) == 2 and "blocks." in k:
+                    t = 0.04 * hash_normal(name, shp, seed=seed) * torch.exp(0.5 * hash_normal(name + "#ht", shp, seed=seed))
+                    blk = int(k.split("blocks.")[1].split(".")[0])
+                    if k.endswith("mlp.fc2.weight") and 3 <= blk <= 8:
+                        rows = (hash_normal(name + "#ma", (2,), seed=seed).abs() * 1e4).long() % D
+                        t[rows] *= 25.0
         out[k] = t
     return out
 
