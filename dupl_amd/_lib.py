@@ -49,6 +49,15 @@ class Gemm16Desc(ctypes.Structure):
 GEMM_A_MCONTIG, GEMM_B_NCONTIG, GEMM_GELU, GEMM_ACCUM = 1, 2, 4, 8
 GEMM_MUL_DGELU, GEMM_RELU, GEMM_MUL_RELUMASK, GEMM_ABS, GEMM_STORE_PRE = 16, 32, 64, 128, 256
 
+class SplitItem(ctypes.Structure):
+    """dupl_split_item (include/dupl_hip.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("hi", ctypes.c_void_p), ("lo", ctypes.c_void_p), ("hiT", ctypes.c_void_p),
+                ("loT", ctypes.c_void_p), ("ld", ctypes.c_int32), ("R", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("Rp", ctypes.c_int32)]
+
+
+SPLIT_MULTI_MAX = 16
+
 _PROTO = re.compile(r"^\s*int\s+(dupl_\w+)\s*\(([^;{]*)\)\s*;", re.M | re.S)
 
 

@@ -49,23 +49,12 @@ __device__ __forceinline__ void scale_from_amax(unsigned int bits, int target, f
 // (optional; rows R .. Rp-1 of the transposed image are written as zeros).  scale: device float or NULL (= 1).
 // slot (scaled tensors): {scale, 1 / scale, amax bits, -} in device memory; next_bits: the amax word of the ring slot the
 // NEXT scaled tensor on this stream will use, zeroed here (stream order makes that safe) so that no memset node is needed.
-__global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__ x, int ld, int R, int C, float* __restrict__ slot,
-                                                       unsigned int* __restrict__ next_bits, __half* __restrict__ hi,
-                                                       __half* __restrict__ lo, __half* __restrict__ hiT, __half* __restrict__ loT,
-                                                       int Rp, int target, float* __restrict__ colsum) {
+__device__ __forceinline__ void split_rt_tile(const float* __restrict__ x, const int ld, const int R, const int C, const float s,
+                                              __half* __restrict__ hi, __half* __restrict__ lo, __half* __restrict__ hiT,
+                                              __half* __restrict__ loT, const int Rp, float* __restrict__ colsum, const int r0,
+                                              const int c0) {
     __shared__ unsigned int tile[64][65];            // (hi | lo << 16) per element; odd stride: conflict-free both ways
     __shared__ float csum[4][64];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    float s = 1.f;
-    if (slot) {
-        float inv;
-        scale_from_amax(reinterpret_cast<const unsigned int*>(slot)[2], target, s, inv);
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-            slot[0] = s;
-            slot[1] = inv;
-            if (next_bits) *next_bits = 0u;
-        }
-    }
     const int tid = threadIdx.x;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);     // column sums of the UNSCALED values over this thread's 4 rows
 #pragma unroll
@@ -128,7 +117,63 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__ x, int ld, int R, int C, float* __restrict__ slot,
+                                                       unsigned int* __restrict__ next_bits, __half* __restrict__ hi,
+                                                       __half* __restrict__ lo, __half* __restrict__ hiT, __half* __restrict__ loT,
+                                                       int Rp, int target, float* __restrict__ colsum) {
+    float s = 1.f;
+    if (slot) {
+        float inv;
+        scale_from_amax(reinterpret_cast<const unsigned int*>(slot)[2], target, s, inv);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            slot[0] = s;
+            slot[1] = inv;
+            if (next_bits) *next_bits = 0u;
+        }
+    }
+    split_rt_tile(x, ld, R, C, s, hi, lo, hiT, loT, Rp, colsum, blockIdx.y * 64, blockIdx.x * 64);
+}
+
+// Several unscaled matrices in one launch (dupl_split_prepare_multi): block b works on tile b - first[i] of item i
+struct split_multi_args {
+    dupl_split_item it[DUPL_SPLIT_MULTI_MAX];
+    int first[DUPL_SPLIT_MULTI_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void split_rt_multi_kernel(const split_multi_args a) {
+    int i = 0;
+#pragma unroll 1
+    while (i + 1 < a.n && (int)blockIdx.x >= a.first[i + 1]) ++i;
+    const dupl_split_item& d = a.it[i];
+    const int t = blockIdx.x - a.first[i];
+    const int tx = (d.C + 63) / 64;
+    split_rt_tile(d.x, d.ld, d.R, d.C, 1.f, (__half*)d.hi, (__half*)d.lo, (__half*)d.hiT, (__half*)d.loT, d.Rp, nullptr,
+                  (t / tx) * 64, (t % tx) * 64);
+}
+
 }  // namespace
+
+extern "C" int dupl_split_prepare_multi(const dupl_split_item* items, int32_t n, dupl_stream_t stream) {
+    (void)hipGetLastError();
+    if (!items || n < 1 || n > DUPL_SPLIT_MULTI_MAX) return DUPL_ERR_ARG;
+    split_multi_args a;
+    a.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const dupl_split_item& d = items[i];
+        if (!d.x || d.R <= 0 || d.C <= 0 || (d.C & 3) || (d.ld & 3) || d.ld < d.C || (!d.hi && !d.hiT) ||
+            ((d.hi == nullptr) != (d.lo == nullptr)) || ((d.hiT == nullptr) != (d.loT == nullptr)) ||
+            (d.hiT && (d.Rp < d.R || (d.Rp & 7))) || (reinterpret_cast<uintptr_t>(d.x) & 15))
+            return DUPL_ERR_ARG;
+        a.it[i] = d;
+        a.first[i] = total;
+        const int Rt = d.hiT ? d.Rp : d.R;
+        total += ((d.C + 63) / 64) * ((Rt + 63) / 64);
+    }
+    a.first[n] = total;
+    hipLaunchKernelGGL(split_rt_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
+    return dupl_launch_status();
+}
 
 extern "C" int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
                                    void* lo, void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum,

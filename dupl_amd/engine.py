@@ -204,6 +204,20 @@ class FlatStorage:
         self._w16T[(student, key)] = (ver, T)
         return T
 
+    def w16T_missing(self, student: int, keys_rows):
+        """[(key, rows, fp32 view [rows, cols])] of the parameters whose transposed planes are stale: the caller splits them
+        (together with other operands, ops.split_prepare_multi) and hands the planes back through w16T_put."""
+        ver = (self.data._version, self.dirty, self.data.data_ptr())
+        out = []
+        for key, rows in keys_rows:
+            hit = self._w16T.get((student, key))
+            if hit is None or hit[0] != ver:
+                out.append((key, rows, self.view(student, key).view(rows, -1)))
+        return out
+
+    def w16T_put(self, student: int, key: str, T):
+        self._w16T[(student, key)] = ((self.data._version, self.dirty, self.data.data_ptr()), T)
+
     def w16(self, student: int, key: str, rows: int) -> "ops.W16":
         """Operand planes of parameter `key` viewed as a [rows, numel / rows] matrix."""
         off, n = self.layout[key]
@@ -814,7 +828,7 @@ def _linear_backward32(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
 
 
 def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu_of: Optional[Tensor] = None,
-                       has_bias: bool = True, dx_feeds_split: bool = False) -> Tensor:
+                       has_bias: bool = True, dx_feeds_split: bool = False, xT16=None) -> Tensor:
     """The same on the f16x3 split GEMM (fp32-equivalent).  The gradient dy is scaled by a power of two from its own
     max-abs before it is split (its values are far below fp16's normal range); both GEMMs run as k-contiguous products
     through transposed operand planes:  dW += dy^T16 . (x^T16)^T,  dx = dy16 . (W^T16)^T  (csrc/split_prep.hip)."""
@@ -823,7 +837,8 @@ def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
     fuse_bias = has_bias and not ops.deterministic()         # the bias gradient rides in the split pass (fp32 atomics)
     dy16, dyT16, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=True, rows_pad=Mp,
                                            colsum_into=P.g[name + ".bias"] if fuse_bias else None)
-    _, xT16, _ = ops.split_prepare(x, scaled=False, want_rm=False, want_T=True, rows_pad=Mp)
+    if xT16 is None:         # (the transformer blocks prepare x^T and W^T of all four Linears in one launch: _block_operands16)
+        _, xT16, _ = ops.split_prepare(x, scaled=False, want_rm=False, want_T=True, rows_pad=Mp)
     gw = P.g[name + ".weight"]
     ops.linear16(dyT16, xT16, out=gw.view(N, -1), accumulate=True, alpha=alpha)
     if has_bias and not fuse_bias:
@@ -831,6 +846,30 @@ def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
     # dx_feeds_split: dx is the next Linear's dy -> its max-abs comes out of this epilogue (ops.reserve_amax)
     dx, _ = ops.linear16(dy16, P.w16T(name + ".weight", N), alpha=alpha, dgelu_of=dgelu_of, amax_for_next=dx_feeds_split)
     return dx
+
+
+BLOCK_OPERANDS_MULTI = os.environ.get("DUPL_BLOCK_OPERANDS_MULTI", "1") != "0"
+
+
+def _block_operands16(P: StudentParams, p: str, s: "BlockSaved", g: dict, D: int, Hd: int) -> dict:
+    """The unscaled operands of one transformer block's f16x3 backward in ONE launch (ops.split_prepare_multi): x^T planes of
+    the four Linear inputs (weight gradients) and, where stale, the W^T planes (data gradients).  Between the persistent
+    GEMMs -- which own every CU's LDS and registers -- each of these short kernels runs alone on the chip, so eight
+    launches of ~10 us become one of ~35.  Returns {site: x^T planes}."""
+    sites = [("fc2", s.h1, "mlp.fc2", D), ("fc1", s.ln2, "mlp.fc1", Hd), ("proj", s.att, "attn.proj", D), ("qkv", s.ln1, "attn.qkv", 3 * D)]
+    sites = [t for t in sites if g[t[0]]]
+    if not sites:
+        return {}
+    items = []
+    for _, x, _, _ in sites:
+        items.append((x, False, True, (x.shape[0] + 31) // 32 * 32))
+    stale = P.store.w16T_missing(P.student, [(p + nm + ".weight", N) for _, _, nm, N in sites])
+    for _, rows, w in stale:
+        items.append((w, False, True, rows))
+    out = ops.split_prepare_multi(items)
+    for (key, _, _), (_, T) in zip(stale, out[len(sites):]):
+        P.store.w16T_put(P.student, key, T)
+    return {site: T for (site, _, _, _), (_, T) in zip(sites, out)}
 
 
 def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], dseg: Optional[Tensor],
@@ -912,21 +951,25 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         def feeds(site):        # does the tensor go into a scaled split next (= is `site`'s backward an f16x3 one)?
             return {"dx_feeds_split": bool(g[site])} if f16 else {}
         att16 = f16 and s.qkv16 is not None and N <= 2048
+        xT = _block_operands16(P, p, s, g, D, D * cfg.mlp_ratio) if (f16 and BLOCK_OPERANDS_MULTI) else {}
+
+        def pre(site):          # x^T planes prepared above (f16x3 sites only)
+            return {"xT16": xT[site]} if site in xT else {}
         # MLP
-        dpre1 = lin_bwd("fc2")(P, dx, s.h1, p + "mlp.fc2", dgelu_of=s.pre1, **(feeds("fc1") if g and g["fc2"] else {}))
-        dln2 = lin_bwd("fc1")(P, dpre1, s.ln2, p + "mlp.fc1")
+        dpre1 = lin_bwd("fc2")(P, dx, s.h1, p + "mlp.fc2", dgelu_of=s.pre1, **(feeds("fc1") if g and g["fc2"] else {}), **pre("fc2"))
+        dln2 = lin_bwd("fc1")(P, dpre1, s.ln2, p + "mlp.fc1", **pre("fc1"))
         del dpre1
         dx_mid = ops.layernorm_bwd(dln2, s.x_mid, W[p + "norm2.weight"], s.mean2, s.rstd2,
                                    G[p + "norm2.weight"], G[p + "norm2.bias"], dres=dx, amax_for_next=f16 and g["proj"])
         # attention
         datt = lin_bwd("proj")(P, dx_mid, s.att, p + "attn.proj",
-                               **({"dx_feeds_split": bool(att16)} if g and g["proj"] else {}))
+                               **({"dx_feeds_split": bool(att16)} if g and g["proj"] else {}), **pre("proj"))
         if att16:
             dqkv = ops.attention_bwd16(s.qkv16, s.att, datt, s.lse, B, N, Hh, hd, scale, amax_for_next=bool(g["qkv"]))
         else:
             dqkv = ops.attention_bwd(s.qkv, s.att, datt, s.lse, B, N, Hh, hd, scale)
-        dln1 = lin_bwd("qkv")(P, dqkv, s.ln1, p + "attn.qkv")
-        del dqkv, datt
+        dln1 = lin_bwd("qkv")(P, dqkv, s.ln1, p + "attn.qkv", **pre("qkv"))
+        del dqkv, datt, xT
         dx = ops.layernorm_bwd(dln1, s.x_in, W[p + "norm1.weight"], s.mean1, s.rstd1,
                                G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid,
                                amax_for_next=f16 and i > 0 and gb[i - 1]["fc2"])

@@ -194,6 +194,29 @@ def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad
     return rm, T, None
 
 
+def split_prepare_multi(items):
+    """Unscaled split_prepare of several matrices in as few launches as possible (dupl_split_prepare_multi, 16 per launch).
+    items: [(x fp32 [R, C], want_rm, want_T, rows_pad)]; returns [(rm Split16 | None, T Split16 | None)]."""
+    out, descs = [], []
+    for x, want_rm, want_T, rows_pad in items:
+        _chk(x)
+        R, C = x.shape
+        Rp = rows_pad if rows_pad else (R + 31) // 32 * 32
+        rm = split16_empty(R, C, x.device) if want_rm else None
+        T = split16_empty(C, Rp, x.device) if want_T else None
+        d = _lib.SplitItem()
+        d.x, d.ld, d.R, d.C, d.Rp = x.data_ptr(), x.stride(0), R, C, Rp
+        d.hi, d.lo = (rm.hi, rm.lo) if rm else (None, None)
+        d.hiT, d.loT = (T.hi, T.lo) if T else (None, None)
+        descs.append(d)
+        out.append((rm, T))
+    for i in range(0, len(descs), _lib.SPLIT_MULTI_MAX):
+        chunk = descs[i:i + _lib.SPLIT_MULTI_MAX]
+        arr = (_lib.SplitItem * len(chunk))(*chunk)
+        L().dupl_split_prepare_multi(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _stream())
+    return out
+
+
 def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False, relu: bool = False,
              res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None,
              want_f32: bool = True, out16: Optional[Split16] = None, want16: bool = False, device=None,

@@ -119,6 +119,16 @@ int dupl_split_prepare2(const float* x, int32_t ld, int32_t R, int32_t C, float*
 int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
                         void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum, int32_t amax_mode,
                         dupl_stream_t stream);
+/* several UNSCALED matrices (saved activations, weights: the x^T / W^T operands of one transformer block's backward) in ONE
+ * launch: items[i] is the argument set of dupl_split_prepare with slot = NULL.  items: host array, n <= DUPL_SPLIT_MULTI_MAX.
+ * The short operand-preparation kernels run chip-exclusive between the persistent GEMMs (which take every CU's LDS and
+ * registers), so a launch saved is its whole duration saved. */
+#define DUPL_SPLIT_MULTI_MAX 16
+typedef struct dupl_split_item {
+    const float* x; void* hi; void* lo; void* hiT; void* loT;
+    int32_t ld, R, C, Rp;
+} dupl_split_item;
+int dupl_split_prepare_multi(const dupl_split_item* items, int32_t n, dupl_stream_t stream);
 /* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 3: 128x64 on 4 waves, 5: 128x128 on 8 waves, 6 / 7: 256x128 ring
  * kernel on 8 / 4 waves; 8 / 9: single-accumulator 256x256 timing probes, results only valid for unscaled lo planes;
  * 10: persistent 256x128 ring kernel; 11: its stream-K form for DUPL_GEMM_ACCUM) */

@@ -1073,3 +1073,25 @@ def test_stream_k_weight_gradient(dev, M, N, K):
     e5, e11 = (float((outs[t].double() - ref).abs().max()) / sc for t in (5, 11))
     print(f"wgrad {M}x{N}x{K}: tile 5 {e5:.2e} stream-K {e11:.2e}")
     assert e11 <= 2.0 * e5 + 1e-7
+
+
+def test_split_prepare_multi_equals_single_launches(dev):
+    """dupl_split_prepare_multi: up to 16 unscaled matrices per launch (the x^T / W^T operands of one transformer block's
+    backward) -- bit-identical planes to one dupl_split_prepare each; ragged shapes, row padding, > 16 items."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    mats = [(torch.randn(3140, 768, generator=g).to(dev), False, True, 3168),
+            (torch.randn(785, 3072, generator=g).to(dev), False, True, 800),
+            (torch.randn(768, 2304, generator=g).to(dev), False, True, 768),
+            (torch.randn(130, 96, generator=g).to(dev), True, True, 160),
+            (torch.randn(37, 44, generator=g).to(dev), True, False, 0)]
+    mats = mats + [(torch.randn(64 + 8 * i, 68, generator=g).to(dev), True, True, 0) for i in range(14)]      # 20 items: two launches
+    got = ops.split_prepare_multi(mats)
+    assert len(got) == len(mats)
+    for (x, want_rm, want_T, rp), (rm, T) in zip(mats, got):
+        rm1, T1, _ = ops.split_prepare(x, scaled=False, want_rm=want_rm, want_T=want_T, rows_pad=rp)
+        assert (rm is None) == (rm1 is None) and (T is None) == (T1 is None)
+        if rm is not None:
+            assert torch.equal(rm.planes, rm1.planes)
+        if T is not None:
+            assert torch.equal(T.planes, T1.planes)

@@ -22,7 +22,7 @@ def timeit(fn, n=200, warm=20):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"ln_bwd", "ln_fwd", "split", "attn_bwd"}
+    which = set(sys.argv[1:]) or {"ln_bwd", "ln_fwd", "split", "attn_bwd", "multi"}
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     rows, D = 3140, 768
@@ -52,6 +52,27 @@ def main():
             t = timeit(lambda: ops.split_prepare(xx, scaled=True, want_rm=True, want_T=True, rows_pad=3168))
             t2 = timeit(lambda: ops.split_prepare(xx, scaled=False, want_rm=False, want_T=True, rows_pad=3168))
             print(f"split_prepare {r}x{c}: scaled rm+T {t:.1f} us (amax + split), T only {t2:.1f} us")
+    if "multi" in which:
+        xs = [torch.randn(3140, c, generator=g).to(dev) for c in (3072, 768, 768, 768)]
+        ws = [torch.randn(r, c, generator=g).to(dev) for r, c in ((768, 3072), (3072, 768), (768, 768), (2304, 768))]
+        items = [(x, False, True, 3168) for x in xs] + [(w, False, True, w.shape[0]) for w in ws]
+
+        def singles():
+            for x, rm, T, rp in items:
+                ops.split_prepare(x, scaled=False, want_rm=rm, want_T=T, rows_pad=rp)
+        t1 = timeit(singles, n=100)
+        t2 = timeit(lambda: ops.split_prepare_multi(items), n=100)
+        t3 = timeit(lambda: ops.split_prepare_multi(items[:4]), n=100)
+        print(f"block operands (4 x^T + 4 W^T): 8 launches {t1:.1f} us, one multi launch {t2:.1f} us; x^T only, one launch {t3:.1f} us")
+        t4 = timeit(lambda: ops.split_prepare_multi(items[4:]), n=100)
+        print(f"  W^T only, one launch {t4:.1f} us")
+        for k in range(8):
+            tk = timeit(lambda: ops.split_prepare_multi(items[k:k + 1]), n=100)
+            ts = timeit(lambda: ops.split_prepare(items[k][0], scaled=False, want_rm=False, want_T=True, rows_pad=items[k][3]), n=100)
+            print(f"  item {k} {tuple(items[k][0].shape)}: multi(1) {tk:.1f} us, single {ts:.1f} us")
+        for m in (5, 6, 7):
+            tm = timeit(lambda: ops.split_prepare_multi(items[:m]), n=100)
+            print(f"  first {m} items: {tm:.1f} us")
     if "attn_bwd" in which:
         B, N, H, hd = 4, 785, 12, 64
         qkv = torch.randn(B * N, 3 * H * hd, generator=g).to(dev)
