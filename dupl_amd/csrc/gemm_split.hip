@@ -1067,7 +1067,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
 static int g16_group_m = 8;
 static int g16_group_ring = 2;   // row tiles (256 rows) per group of the ring kernel's block order: 512-row A bands stay in an
                                   // XCD's L2 while it sweeps the columns (2 / 3: 320, 4: 312, 8: 304, 16: 285 TF/s-eq on 15696 x 3072 x 768)
-static int g16_persist_blocks = 256;   // blocks of the persistent kernel: one per CU (a multiple of 8: a block keeps its XCD)
+static int g16_persist_blocks_set = 0;  // blocks of the persistent kernels (a multiple of 8: a block keeps its XCD); 0 = auto:
+                                        // one per CU alone; 192 when a second stream feeds the chip as well -- the kernel is power-bound
+                                        // (176 .. 208 blocks run a GEMM as fast as 256: fewer CUs, higher clock), and the CUs left over
+                                        // let the other student's kernels in earlier (step 61.55 -> 61.0 ms, same box; 128: 63.5)
+#define g16_persist_blocks (g16_persist_blocks_set ? g16_persist_blocks_set : (g16_concurrency >= 2 ? 192 : 256))
 static int g16_concurrency = 1;  // how many streams feed split GEMMs at a time (dupl_set_gemm16_concurrency)
 static int g16_tile = 0;     // 0 = heuristic; 3: 128x64 on 4 waves; 5: 128x128 on 8 waves (wave tile 64x32 in both).  Measured
                              // and dropped: 64x64 wave tiles on 4 / 8 waves (2 waves / SIMD: -10..25 %), 256x128 on 16 waves
@@ -1094,6 +1098,12 @@ extern "C" int dupl_set_gemm16_group(int32_t gm) {
 extern "C" int dupl_set_gemm16_concurrency(int32_t n) {
     if (n < 1 || n > 8) return DUPL_ERR_ARG;
     g16_concurrency = n;
+    return DUPL_OK;
+}
+
+extern "C" int dupl_set_gemm16_persist_blocks(int32_t n) {
+    if (n != 0 && (n < 8 || n > 1024 || (n & 7))) return DUPL_ERR_ARG;
+    g16_persist_blocks_set = n;
     return DUPL_OK;
 }
 

@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -269,6 +271,31 @@ def _reference_init(store: FlatStorage, student: int):
             _trunc_normal_(t, 0.02)
 
 
+def _cu_masked_streams(dev, spec: str):
+    """Experiment knob DUPL_CU_MASK="lo:hi,lo:hi": the two student streams as HIP streams restricted to the CU bit ranges
+    [lo, hi) of the 256-bit CU mask (hipExtStreamCreateWithCUMask; the driver deals mask bits round-robin over the 8 XCDs,
+    so "0:128,128:256" gives each student half of every XCD).  Default (unset): two ordinary streams on all CUs."""
+    import ctypes
+    path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln), "libamdhip64.so")
+    hip = ctypes.CDLL(path)
+    out = []
+    for part in spec.split(","):
+        lo, hi = (int(v) for v in part.split(":"))
+        bits = sum(1 << b for b in range(lo, hi))
+        words = [(bits >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        arr = (ctypes.c_uint32 * 8)(*words)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, arr)
+        if rc != 0:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+        out.append(torch.cuda.ExternalStream(h.value, device=dev))
+    assert len(out) == 2
+    lo, hi = (int(v) for v in spec.split(",")[0].split(":"))
+    ops.L().dupl_set_gemm16_persist_blocks(int(os.environ.get("DUPL_PERSIST_BLOCKS", (hi - lo) // 8 * 8)))
+    return out
+
+
 class siamese_network(nn.Module):
     def __init__(self, backbone, num_classes=None, pretrained=None, aux_layer=None):
         super().__init__()
@@ -313,7 +340,9 @@ class siamese_network(nn.Module):
             # off and on with fresh streams ran at single-stream speed)
             dev = self._store.data.device
             if dev not in _STREAM_PAIRS:
-                _STREAM_PAIRS[dev] = [torch.cuda.Stream(device=dev) for _ in range(2)]
+                spec = os.environ.get("DUPL_CU_MASK", "")
+                _STREAM_PAIRS[dev] = (_cu_masked_streams(dev, spec) if spec else
+                                      [torch.cuda.Stream(device=dev) for _ in range(2)])
             self._store.streams = list(_STREAM_PAIRS[dev])
         if not on:
             self._store.streams = []
@@ -321,6 +350,8 @@ class siamese_network(nn.Module):
         from .. import ops
         if self._store.data.is_cuda:
             ops.L().dupl_set_gemm16_concurrency(2 if (on and self._store.streams) else 1)
+            if os.environ.get("DUPL_PERSIST_BLOCKS"):
+                ops.L().dupl_set_gemm16_persist_blocks(int(os.environ["DUPL_PERSIST_BLOCKS"]))
         return self
 
     def ms_cam_and_forward(self, inputs, scales, inputs_aug=None):

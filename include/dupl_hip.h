@@ -133,6 +133,9 @@ int dupl_split_prepare_multi(const dupl_split_item* items, int32_t n, dupl_strea
  * kernel on 8 / 4 waves; 8 / 9: single-accumulator 256x256 timing probes, results only valid for unscaled lo planes;
  * 10: persistent 256x128 ring kernel; 11: its stream-K form for DUPL_GEMM_ACCUM) */
 int dupl_set_gemm16_tile(int32_t t);
+/* tuning knob: blocks of the persistent kernels (tiles 10 / 11), a multiple of 8; 0 = auto (256 = one per CU when one stream
+ * issues GEMMs, 192 under dupl_set_gemm16_concurrency(2)) */
+int dupl_set_gemm16_persist_blocks(int32_t n);
 /* hint for the tile heuristic (no reference counterpart): how many streams issue split GEMMs concurrently -- 2 while the two
  * students of siamese_network run on their own streams (model_dupl.py:157-213 runs them back to back), else 1 */
 int dupl_set_gemm16_concurrency(int32_t n);

@@ -37,5 +37,50 @@ def main(path):
         print(f"{k:92s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:10.2f} {a[2] / 1e3:9.2f} {a[3] / 1e3:9.2f} {100.0 * a[1] / tot:6.2f}")
 
 
+HEAVY = re.compile(r"gemm_f16x3|attn_fwd16|attn_bwd16|gemm_f32")
+
+
+def timeline(path, tail_frac=0.5):
+    """How the two student streams share the chip: over the last `tail_frac` of the trace (the timed steps), the time with
+    >= 1 MFMA-heavy kernel (split GEMMs, attention) in flight, with only light kernels, and with nothing at all; and how
+    long 2 heavy kernels overlap.  python tools/rocpd_stats.py --timeline x.db"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {namecol}, start, end from kernels order by start").fetchall()
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    lo = t1 - (t1 - t0) * tail_frac
+    ev = []
+    for n, s, e in rows:
+        if e <= lo:
+            continue
+        h = 1 if HEAVY.search(n) else 0
+        ev.append((max(s, lo), 1, h))
+        ev.append((e, -1, h))
+    ev.sort()
+    heavy = light = 0
+    acc = {"idle": 0, "light only": 0, "1 heavy": 0, "1 heavy + light": 0, ">= 2 heavy": 0}
+    prev = lo
+    for t, d, h in ev:
+        dt = t - prev
+        if dt > 0:
+            if heavy == 0 and light == 0: acc["idle"] += dt
+            elif heavy == 0: acc["light only"] += dt
+            elif heavy == 1 and light == 0: acc["1 heavy"] += dt
+            elif heavy == 1: acc["1 heavy + light"] += dt
+            else: acc[">= 2 heavy"] += dt
+        prev = t
+        if h: heavy += d
+        else: light += d
+    tot = t1 - lo
+    print(f"# chip occupancy over the last {tail_frac:.0%} of {path} ({tot / 1e6:.1f} ms)")
+    for k, v in acc.items():
+        print(f"{k:18s} {v / 1e6:9.2f} ms {100.0 * v / tot:6.1f} %")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if sys.argv[1] == "--timeline":
+        timeline(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.5)
+    else:
+        main(sys.argv[1])
