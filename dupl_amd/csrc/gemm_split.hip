@@ -1168,9 +1168,13 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         return dupl_launch_status();
     }
     if (tile == 10) {
+        // every block walks the same number of tiles: with tx tiles per XCD and at most maxb / 8 blocks per XCD the walk takes
+        // rounds = ceil(tx / (maxb / 8)) tiles, and ceil(tx / rounds) blocks per XCD are enough for that -- 600 tiles run as
+        // 3 x 200 instead of 2.3 x 256 (the kernel is power-bound: a few CUs less cost nothing, an idle last round does)
         const int nblk = ((d->M + 255) / 256) * ((d->N + 127) / 128);
-        int grid = (nblk + 7) / 8 * 8;
-        if (grid > g16_persist_blocks) grid = g16_persist_blocks;
+        const int tx = (nblk + 7) / 8, bmax = g16_persist_blocks / 8;
+        const int rounds = (tx + bmax - 1) / bmax;
+        const int grid = 8 * ((tx + rounds - 1) / rounds);
         hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2>), dim3((unsigned)grid), dim3(512), 0, s, *d, g16_group_ring);
         return dupl_launch_status();
     }
