@@ -35,6 +35,22 @@ __device__ __forceinline__ float bil_blend(float hy, float ly, float lx, float a
     return __fmaf_rn(ly, bot, __fmul_rn(hy, top));
 }
 
+// max(a, b, 0) in ONE instruction (fmaxf(fmaxf(a, b), 0.f) costs three more for input canonicalisation in IEEE mode); used by both
+// fusion kernels, so they agree bit for bit whatever the inputs
+__device__ __forceinline__ float max3_relu(float a, float b) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// The same for two pixels at a time (v_pk_mul_f32 / v_pk_fma_f32: the IEEE operations of bil_blend, lane-wise -> the same bits)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// in two steps: the horizontal blends (top, bot) depend on the low-resolution row pair only, the vertical one on the output row
+__device__ __forceinline__ f32x2 bil_blend_h2(f32x2 lx, f32x2 hx, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(lx, b, hx * a); }
+__device__ __forceinline__ f32x2 bil_blend_v2(f32x2 hy, f32x2 ly, f32x2 top, f32x2 bot) {
+    return __builtin_elementwise_fma(ly, bot, hy * top);
+}
+
 struct CamFuseDesc {
     const float* low[4];   // token-major CAM logits [2B][rows][ldc]  (rows = row_off + hs*ws)
     int hs[4], ws[4];
@@ -70,7 +86,7 @@ __global__ __launch_bounds__(256) void cam_fuse_kernel(CamFuseDesc d, float* __r
                                        p[(long)(y1 * ws + x0) * d.ldc], p[(long)(y1 * ws + x1) * d.ldc]);
             const float v2 = bil_blend(hy, ly, lf, q[(long)(y0 * ws + f0) * d.ldc], q[(long)(y0 * ws + f1) * d.ldc],
                                        q[(long)(y1 * ws + f0) * d.ldc], q[(long)(y1 * ws + f1) * d.ldc]);
-            acc += fmaxf(fmaxf(v1, v2), 0.f);
+            acc += max3_relu(v1, v2);
         }
         cam[(long)plane * HW + i] = acc;
         vmin = fminf(vmin, acc);
@@ -87,21 +103,33 @@ __global__ __launch_bounds__(256) void cam_fuse_kernel(CamFuseDesc d, float* __r
 // The same fusion, restructured for HBM (round 3): the strided token-major reads (8 taps x nscale per pixel at stride ldc,
 // 0.46 TB/s of output in the per-pixel kernel above) go through LDS.  One block = one (b, c) plane x one band of output rows:
 // it stages, per scale, the few low-resolution rows of (b, c) and of the flipped image (B + b, c) that the band touches
-// (<= band * hs / H + 2 rows of ws floats), then every thread produces 4 consecutive pixels per item from LDS taps and
-// writes one float4 per row.  The arithmetic per pixel is the expression of cam_fuse_kernel, token for token (bit-identical output:
-// tests/test_kernels_gpu.py::test_cam_fuse_band_kernel_is_bit_identical).  Needs W % 4 == 0.
+// (<= band * hs / H + 2 rows of ws floats) and a table of the vertical weights / row pairs of its output rows, then every thread
+// produces PX (2 or 4) consecutive pixels per output row from cached horizontal blends and writes them as one vector.  The
+// arithmetic per pixel is the expression of cam_fuse_kernel, operation for operation (bit-identical output:
+// tests/test_kernels_gpu.py::test_cam_fuse_band_kernel_is_bit_identical).  Needs W % 4 == 0.  448^2, 3 scales: C = 20 (64 MB) 28 us,
+// C = 80 (256 MB) 72 us = 3.5 TB/s of output (tools/op_bench.py cam; the per-pixel kernel: 137 / 840 us).
 constexpr int CAM_BAND_MAX_LDS = 60 * 1024;
-template <int NS>
+template <int NS, int PX>
 __global__ __launch_bounds__(256) void cam_fuse_band_kernel(CamFuseDesc d, float* __restrict__ cam, float* __restrict__ mm, int B,
                                                             int C, int H, int W, int band) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[16];
     const int plane = blockIdx.y;
     const int b = plane / C, c = plane - b * C;
     const int ya = blockIdx.x * band, yb = min(H, ya + band);      // output rows [ya, yb)
+    // ---- per (output row, scale): {ly, 1 - ly, y0, y1} once per block instead of once per thread and row
+    float4* rowtab = reinterpret_cast<float4*>(lds);
+    for (int t = threadIdx.x; t < (yb - ya) * NS; t += 256) {
+        const int s = t % NS;
+        const int hs = d.hs[s];
+        int y0, y1;
+        float ly;
+        bil_src(ya + t / NS, (float)hs / (float)H, hs, false, y0, y1, ly);
+        rowtab[t] = make_float4(ly, 1.f - ly, __int_as_float(y0), __int_as_float(y1));
+    }
     // ---- stage: per scale the low-res rows [r0_s, r1_s] of both images
     int base[NS + 1], r0s[NS];             // statically indexed (unrolled loops): registers, not scratch
-    int off = 0;
+    int off = band * NS * 4;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int hs = d.hs[s], ws = d.ws[s];
@@ -124,70 +152,95 @@ __global__ __launch_bounds__(256) void cam_fuse_band_kernel(CamFuseDesc d, float
     }
     base[NS] = off;
     __syncthreads();
-    // Every thread owns ONE quad of 4 consecutive columns (its horizontal weights per scale are computed once) and walks down
-    // the rows of the band; the 16 low-resolution values a quad needs per scale (2 rows x (x0, x1) x 4 pixels x {image,
+    // Every thread owns PX (2 or 4) consecutive columns (its horizontal weights and tap columns per scale are computed once) and
+    // walks down the rows of the band; the low-resolution values it needs per scale (2 rows x (x0, x1) x PX pixels x {image,
     // flipped image}) live in registers and are re-read from LDS only when the row pair (y0, y1) of that scale changes --
-    // every H / hs output rows, a block-uniform event.  What remains per pixel and row is the arithmetic.
-    const int W4 = W >> 2;
-    const int nrp = 256 / W4;                          // row phases per block (host guarantees W4 <= 256)
-    const int xq = threadIdx.x % W4, rp = threadIdx.x / W4;
-    const int x4 = xq << 2;
-    float wlx[NS][4], wlf[NS][4];
+    // every H / hs output rows -- and with them their horizontal blends (the `top` / `bot` of bil_blend: same operations, same
+    // operands, computed once per row pair instead of once per output row).  What remains per pixel, scale and row is the vertical
+    // blend of both images, max3 and the sum: 7 instructions per pixel pair (packed fp32).
+    // PX = 2 wherever a row fits the block (W <= 512): all four waves then work on the same row, so the reload is a
+    // block-uniform event, and 130 instead of 232 registers double the waves that hide the LDS latency of the row table.
+    constexpr int NP = PX / 2;
+    const int WQ = W / PX;
+    const int nrp = 256 / WQ;                          // row phases per block (host guarantees WQ <= 256)
+    const int xq = threadIdx.x % WQ, rp = threadIdx.x / WQ;
+    const int x4 = xq * PX;
+    f32x2 wlx[NS][NP], whx[NS][NP], wlf[NS][NP], whf[NS][NP];  // [scale][pixel pair]: lx, 1 - lx of the image / the flipped image
+    int xpk[NS][PX], fpk[NS][PX];                               // [scale][pixel]: x0 | x1 << 16 and the flipped image's f0 | f1 << 16
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const float sx = (float)d.ws[s] / (float)W;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PX; ++j) {
             int i0, i1;
-            bil_src(x4 + j, sx, d.ws[s], false, i0, i1, wlx[s][j]);
-            bil_src(W - 1 - (x4 + j), sx, d.ws[s], false, i0, i1, wlf[s][j]);
+            float lx, lf;
+            bil_src(x4 + j, sx, d.ws[s], false, i0, i1, lx);
+            xpk[s][j] = i0 | (i1 << 16);
+            bil_src(W - 1 - (x4 + j), sx, d.ws[s], false, i0, i1, lf);
+            fpk[s][j] = i0 | (i1 << 16);
+            wlx[s][j >> 1][j & 1] = lx;
+            whx[s][j >> 1][j & 1] = __fsub_rn(1.f, lx);
+            wlf[s][j >> 1][j & 1] = lf;
+            whf[s][j >> 1][j & 1] = __fsub_rn(1.f, lf);
         }
     }
-    float pa[NS][4][4], qa[NS][4][4];                  // [scale][pixel][y0x0, y0x1, y1x0, y1x1] of the image / the flipped image
+    f32x2 pa[NS][NP][2], qa[NS][NP][2];                // [scale][pixel pair][top, bot] of the image / the flipped image
     int cy0[NS], cy1[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) { cy0[s] = -1; cy1[s] = -1; }
     float vmin = INFINITY, vmax = -INFINITY;
     if (rp < nrp) {
         for (int y = ya + rp; y < yb; y += nrp) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            f32x2 acc[NP];
+            float4 rt[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) rt[s] = rowtab[(y - ya) * NS + s];
+#pragma unroll
+            for (int jp = 0; jp < NP; ++jp) acc[jp] = f32x2{0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const int hs = d.hs[s], ws = d.ws[s];
-                const float sy = (float)hs / (float)H;
-                int y0, y1;
-                float ly;
-                bil_src(y, sy, hs, false, y0, y1, ly);
+                const int ws = d.ws[s];
+                const float ly = rt[s].x, hy = rt[s].y;
+                const int y0 = __float_as_int(rt[s].z), y1 = __float_as_int(rt[s].w);
                 if (y0 != cy0[s] || y1 != cy1[s]) {
                     cy0[s] = y0;
                     cy1[s] = y1;
                     const int nrws = (base[s + 1] - base[s]) >> 1;
                     const float* p = lds + base[s] + (y0 - r0s[s]) * ws;
                     const float* p1 = lds + base[s] + (y1 - r0s[s]) * ws;
-                    const float sx = (float)ws / (float)W;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        int x0, x1, f0, f1;
-                        float t;
-                        bil_src(x4 + j, sx, ws, false, x0, x1, t);
-                        bil_src(W - 1 - (x4 + j), sx, ws, false, f0, f1, t);
-                        pa[s][j][0] = p[x0]; pa[s][j][1] = p[x1];
-                        pa[s][j][2] = p1[x0]; pa[s][j][3] = p1[x1];
-                        qa[s][j][0] = p[nrws + f0]; qa[s][j][1] = p[nrws + f1];
-                        qa[s][j][2] = p1[nrws + f0]; qa[s][j][3] = p1[nrws + f1];
+                    for (int jp = 0; jp < NP; ++jp) {
+                        f32x2 t[8];        // y0x0, y0x1, y1x0, y1x1 of the image, then of the flipped image
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int j = 2 * jp + k;
+                            const int x0 = xpk[s][j] & 0xffff, x1 = xpk[s][j] >> 16, f0 = fpk[s][j] & 0xffff, f1 = fpk[s][j] >> 16;
+                            t[0][k] = p[x0]; t[1][k] = p[x1]; t[2][k] = p1[x0]; t[3][k] = p1[x1];
+                            t[4][k] = p[nrws + f0]; t[5][k] = p[nrws + f1]; t[6][k] = p1[nrws + f0]; t[7][k] = p1[nrws + f1];
+                        }
+                        pa[s][jp][0] = bil_blend_h2(wlx[s][jp], whx[s][jp], t[0], t[1]);
+                        pa[s][jp][1] = bil_blend_h2(wlx[s][jp], whx[s][jp], t[2], t[3]);
+                        qa[s][jp][0] = bil_blend_h2(wlf[s][jp], whf[s][jp], t[4], t[5]);
+                        qa[s][jp][1] = bil_blend_h2(wlf[s][jp], whf[s][jp], t[6], t[7]);
                     }
                 }
-                const float hy = 1.f - ly;
+                const f32x2 hy2 = {hy, hy}, ly2 = {ly, ly};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v1 = bil_blend(hy, ly, wlx[s][j], pa[s][j][0], pa[s][j][1], pa[s][j][2], pa[s][j][3]);
-                    const float v2 = bil_blend(hy, ly, wlf[s][j], qa[s][j][0], qa[s][j][1], qa[s][j][2], qa[s][j][3]);
-                    acc[j] += fmaxf(fmaxf(v1, v2), 0.f);
+                for (int jp = 0; jp < NP; ++jp) {
+                    const f32x2 v1 = bil_blend_v2(hy2, ly2, pa[s][jp][0], pa[s][jp][1]);
+                    const f32x2 v2 = bil_blend_v2(hy2, ly2, qa[s][jp][0], qa[s][jp][1]);
+                    const f32x2 m = {max3_relu(v1[0], v2[0]), max3_relu(v1[1], v2[1])};
+                    acc[jp] += m;
                 }
             }
-            *reinterpret_cast<float4*>(cam + (long)plane * H * W + (long)y * W + x4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            vmin = fminf(fminf(vmin, acc[0]), fminf(acc[1], fminf(acc[2], acc[3])));
-            vmax = fmaxf(fmaxf(vmax, acc[0]), fmaxf(acc[1], fmaxf(acc[2], acc[3])));
+            float* op = cam + (long)plane * H * W + (long)y * W + x4;
+            if constexpr (PX == 4) *reinterpret_cast<float4*>(op) = make_float4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+            else *reinterpret_cast<float2*>(op) = make_float2(acc[0][0], acc[0][1]);
+#pragma unroll
+            for (int jp = 0; jp < NP; ++jp) {
+                vmin = fminf(vmin, fminf(acc[jp][0], acc[jp][1]));
+                vmax = fmaxf(vmax, fmaxf(acc[jp][0], acc[jp][1]));
+            }
         }
     }
     vmin = -block_max(-vmin, red);
@@ -308,6 +361,13 @@ extern "C" int dupl_set_cam_fuse_impl(int32_t impl) {
     return DUPL_OK;
 }
 
+static int g_cam_band_blocks = 768;    // measured 256 .. 4096 at 448^2: C = 20: 40 / 33.3 (768) / 39 / 56 us, C = 80: 126 / 77.4 (768) / 82 us
+extern "C" int dupl_set_cam_fuse_blocks(int32_t n) {
+    if (n < 1 || n > (1 << 20)) return DUPL_ERR_ARG;
+    g_cam_band_blocks = n;
+    return DUPL_OK;
+}
+
 extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const int32_t* ws, int32_t nscale, int32_t row_off,
                              int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
@@ -322,23 +382,31 @@ extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const 
     d.nscale = nscale; d.row_off = row_off; d.ldc = ldc;
     const int planes = B * C;
     hipLaunchKernelGGL(minmax_init_kernel, dim3((planes + 255) / 256), dim3(256), 0, (hipStream_t)s, mm, planes);
-    if (g_cam_fuse_impl == 1 && !(W & 3) && W <= 1024 && !(reinterpret_cast<uintptr_t>(cam) & 15)) {
-        // bands: enough blocks to fill the chip a few times over, at least 8 rows each
-        int nb = (2048 + planes - 1) / planes;
+    bool ws_ok = true;             // tap columns travel as 16-bit pairs
+    for (int i = 0; i < nscale; ++i) ws_ok = ws_ok && ws[i] < 32768;
+    if (g_cam_fuse_impl == 1 && !(W & 3) && W <= 1024 && ws_ok && !(reinterpret_cast<uintptr_t>(cam) & 15)) {
+        // bands: ~3 blocks per CU (long bands amortise the staging and the per-thread set-up), at least 8 rows each
+        int nb = (g_cam_band_blocks + planes - 1) / planes;
         int band = (H + nb - 1) / nb;
         if (band < 8) band = 8;
         for (;; band = (band + 1) / 2) {       // LDS need of a band (upper bound): per scale 2 images x (band * hs / H + 3) rows x ws
-            size_t need = 0;
+            size_t need = (size_t)band * nscale * 16;        // the per-row table {ly, 1 - ly, y0, y1}
             for (int i = 0; i < nscale; ++i) need += 2 * ((size_t)band * hs[i] / H + 3) * ws[i] * sizeof(float);
             if (need <= (size_t)CAM_BAND_MAX_LDS || band <= 1) {
                 if (need > (size_t)CAM_BAND_MAX_LDS) break;      // does not fit even at one row: per-pixel kernel below
                 const dim3 grid((H + band - 1) / band, planes);
+#define CAM_BAND(NS_)                                                                                                            \
+    if (W <= 512)                                                                                                                \
+        hipLaunchKernelGGL((cam_fuse_band_kernel<NS_, 2>), grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); \
+    else                                                                                                                         \
+        hipLaunchKernelGGL((cam_fuse_band_kernel<NS_, 4>), grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band)
                 switch (nscale) {
-                    case 1: hipLaunchKernelGGL(cam_fuse_band_kernel<1>, grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); break;
-                    case 2: hipLaunchKernelGGL(cam_fuse_band_kernel<2>, grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); break;
-                    case 3: hipLaunchKernelGGL(cam_fuse_band_kernel<3>, grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); break;
-                    default: hipLaunchKernelGGL(cam_fuse_band_kernel<4>, grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); break;
+                    case 1: CAM_BAND(1); break;
+                    case 2: CAM_BAND(2); break;
+                    case 3: CAM_BAND(3); break;
+                    default: CAM_BAND(4); break;
                 }
+#undef CAM_BAND
                 return dupl_launch_status();
             }
         }

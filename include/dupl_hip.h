@@ -267,6 +267,8 @@ int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const int32_t* ws
                   int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, dupl_stream_t s);
 /* test / tuning knob (no reference counterpart): 1 = LDS-staged band kernel (default), 0 = per-pixel kernel; same bits */
 int dupl_set_cam_fuse_impl(int32_t impl);
+/* tuning knob: blocks the band kernel aims at (bands = blocks / planes, at least 8 rows each) */
+int dupl_set_cam_fuse_blocks(int32_t n);
 /* per plane, in place: cam = (cam - min) / ((max - min) + 1e-5)  == `cam + maxpool(-cam); cam /= maxpool(cam) + 1e-5`
  * (cam_helper.py:197-199).  mm [planes][2]; have_minmax = 0 recomputes it first. */
 int dupl_cam_minmax_normalise(float* cam, float* mm, int32_t planes, int32_t HW, int32_t have_minmax, dupl_stream_t s);

@@ -1,5 +1,6 @@
 """Micro-timings of the small (non-GEMM) kernels of the step at their step shapes, through dupl_amd.ops (torch events on the
 current stream, 200 launches each).  Usage: python tools/op_bench.py [ln_bwd] [ln_fwd] [split] [attn_bwd]"""
+import gc
 import sys
 
 import torch
@@ -9,6 +10,7 @@ from dupl_amd import ops  # noqa: E402
 
 
 def timeit(fn, n=200, warm=20):
+    gc.collect()            # a generation-2 collection inside the timed loop shows up as a 40 ms outlier
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -22,7 +24,7 @@ def timeit(fn, n=200, warm=20):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"ln_bwd", "ln_fwd", "split", "attn_bwd", "multi"}
+    which = set(sys.argv[1:]) or {"ln_bwd", "ln_fwd", "split", "attn_bwd", "multi", "cam"}
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     rows, D = 3140, 768
@@ -73,6 +75,16 @@ def main():
         for m in (5, 6, 7):
             tm = timeit(lambda: ops.split_prepare_multi(items[:m]), n=100)
             print(f"  first {m} items: {tm:.1f} us")
+    if "cam" in which:
+        for C in (20, 80):
+            B, H, W = 4, 448, 448
+            sizes = [(28, 28), (14, 14), (42, 42)]
+            lows = [torch.randn(2 * B * (1 + h * w), C, generator=g).to(dev) for h, w in sizes]
+            for nb in (384, 512, 768, 1024, 1536, 2048, 4096):
+                ops.L().dupl_set_cam_fuse_blocks(nb)
+                t = timeit(lambda: ops.cam_fuse(lows, sizes, B, C, H, W, 1, C), n=100)
+                print(f"cam_fuse C={C} band kernel, {nb} blocks aimed at: {t:.1f} us = {B * C * H * W * 4 / t / 1e6:.2f} TB/s of output (incl. the min/max init launch)")
+            ops.L().dupl_set_cam_fuse_blocks(2048)
     if "attn_bwd" in which:
         B, N, H, hd = 4, 785, 12, 64
         qkv = torch.randn(B * N, 3 * H * hd, generator=g).to(dev)
