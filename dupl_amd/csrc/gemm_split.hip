@@ -1147,14 +1147,14 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         // sustained clocks.  The persistent 256 x 128 ring kernel (tile 10; 6 = the same, one block per tile) is one block
         // per CU: it wins wherever its grid covers a good part of the chip -- >= 64 tiles when a second stream feeds the chip
         // as well (the two students: dupl_set_gemm16_concurrency(2)), >= 128 tiles alone.  The weight gradients go to its
-        // stream-K form (tile 11) when every block gets >= 16 k-steps: 3072 x 768 x 3168 alone 155 -> 205 TF/s-eq, with a
+        // stream-K form (tile 11) when every block gets >= 10 k-steps (K = 1600, one stream: 3072 x 768 143 vs 117, 2304 x 768 116 vs 100): 3072 x 768 x 3168 alone 155 -> 205 TF/s-eq, with a
         // second stream 219 -> 238 (there only from 64 tiles on: 2304 x 768 loses 6 % to two co-resident 128 x 128 blocks of
         // both streams); the rest stay on split-K grids of 128 x 128 (tile 5, two blocks per CU) / 128 x 64 (tile 3).
         const long b256 = (long)((d->M + 255) / 256) * ((d->N + 127) / 128);
         const long b128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * ksplit;
         const bool ring = b256 >= (g16_concurrency >= 2 ? 64 : 128);
         if (!accum && ring) tile = 10;
-        else if (accum && ksplit > 1 && d->K / TBK >= 8 && b256 * (d->K / TBK) >= 16L * g16_persist_blocks &&
+        else if (accum && ksplit > 1 && d->K / TBK >= 8 && b256 * (d->K / TBK) >= 10L * g16_persist_blocks &&
                  (g16_concurrency < 2 || b256 >= 64))
             tile = 11;
         else tile = b128 < 200 ? 3 : 5;

@@ -125,8 +125,8 @@ def _scale_ring(device):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ring = _SCALE_RINGS.get(key)
     if ring is None:
-        # [records, next index, pending producer token]
-        ring = [torch.zeros((_RING, 4), device=device, dtype=torch.float32), 0, None]
+        # [records, next index, pending producer token, scaled splits so far (slot generation)]
+        ring = [torch.zeros((_RING, 4), device=device, dtype=torch.float32), 0, None, 0]
         _SCALE_RINGS[key] = ring
     return ring
 
@@ -137,8 +137,24 @@ def _scale_slot(device):
     ring = _scale_ring(device)
     buf, i = ring[0], ring[1]
     ring[1] = (i + 1) % _RING
+    ring[3] += 1
     base = buf.data_ptr()
     return base + 16 * i, base + 16 * ((i + 1) % _RING) + 8, buf[i]
+
+
+class _Alpha(int):
+    """Device pointer of a scale record's 1 / scale, with what it takes to use it safely: the record lives in a ring of _RING
+    slots of ONE stream and is rewritten _RING scaled splits later, so consumers check() that they run on that stream and
+    that the slot has not been handed out again."""
+
+    def bind(self, ring, stream):
+        self.ring, self.stream, self.gen = ring, stream, ring[3]
+        return self
+
+    def check(self):
+        cur = torch.cuda.current_stream().cuda_stream
+        assert cur == self.stream, "a scaled operand's alpha is only valid on the stream that prepared it"
+        assert self.ring[3] - self.gen < _RING - 1, "scale slot reused: the alpha of a scaled split_prepare expires after ~128 later ones"
 
 
 class _AmaxToken:
@@ -190,7 +206,7 @@ def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad
         for o in (rm, T):
             if o is not None:
                 o.planes._dupl_scale = rec      # view of the ring record {scale, 1 / scale, ...} (tests read it)
-        return rm, T, slot + 4
+        return rm, T, _Alpha(slot + 4).bind(ring, torch.cuda.current_stream(x.device).cuda_stream)
     return rm, T, None
 
 
@@ -253,7 +269,9 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     aux_flag = _lib.GEMM_MUL_DGELU if dgelu_of is not None else (_lib.GEMM_MUL_RELUMASK if relumask_of is not None else
                                                                   (_lib.GEMM_STORE_PRE if store_pre is not None else 0))
     d.flags = (_lib.GEMM_GELU if gelu else 0) | (_lib.GEMM_RELU if relu else 0) | aux_flag | (_lib.GEMM_ACCUM if accumulate else 0)
-    d.alpha_dev = alpha
+    if isinstance(alpha, _Alpha):
+        alpha.check()
+    d.alpha_dev = int(alpha) if alpha is not None else None
     d.c_rows = int(c_rows)
     tok = None
     if amax_for_next and y is not None and not accumulate and not c_rows:
@@ -407,12 +425,13 @@ def attention_bwd16(qkv16, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: in
     dev = out.device
     dout = dout.contiguous()
     do16, _, alpha = split_prepare(dout, scaled=True, want_rm=True, want_T=False, target_exp=4)
+    alpha.check()
     npad = (N + 63) // 64 * 64
     scratch = torch.empty((6, B * H * hd * npad), device=dev, dtype=torch.float16)
     delta = torch.empty((B, H, N), device=dev, dtype=torch.float32)
     dqkv = torch.empty((B * N, 3 * H * hd), device=dev, dtype=torch.float32)
     word, tok = reserve_amax(dev) if amax_for_next else (None, None)       # after dout's split took its slot
-    L().dupl_attention_bwd16b(qkv16.hi, qkv16.lo, out.data_ptr(), dout.data_ptr(), do16.hi, do16.lo, alpha - 4, lse.data_ptr(),
+    L().dupl_attention_bwd16b(qkv16.hi, qkv16.lo, out.data_ptr(), dout.data_ptr(), do16.hi, do16.lo, int(alpha) - 4, lse.data_ptr(),
                               delta.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(), B, N, H, hd, npad, float(scale), word,
                               _stream())
     if tok is not None:

@@ -1095,3 +1095,25 @@ def test_split_prepare_multi_equals_single_launches(dev):
             assert torch.equal(rm.planes, rm1.planes)
         if T is not None:
             assert torch.equal(T.planes, T1.planes)
+
+
+def test_scaled_operand_alpha_is_guarded(dev):
+    """The 1 / scale of a scaled split lives in a per-stream ring of 128 records: using it on another stream, or after the slot
+    has been handed out again, must fail loudly instead of multiplying by somebody else's scale."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(11)
+    dy = (torch.randn(64, 96, generator=g) * 1e-5).to(dev)
+    W = torch.randn(32, 96, generator=g).to(dev)
+    W16 = ops.split16(W)
+    dy16, _, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False)
+    ref, _ = ops.linear16(dy16, W16, alpha=alpha)
+    assert relerr(ref, dy @ W.t()) < 1e-5
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), pytest.raises(AssertionError, match="stream"):
+        ops.linear16(dy16, W16, alpha=alpha)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(130):
+        ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False)
+    with pytest.raises(AssertionError, match="reused"):
+        ops.linear16(dy16, W16, alpha=alpha)
