@@ -16,7 +16,9 @@ B=tools/gemm16_bench
   echo "# the same with -2 (every launch on two streams at a time: the two students)"; $B -s all -t 3,5,6,10 -w 200 -2;
   echo "# epilogue 1 (bias -> planes), 2 (bias + GELU + stored pre-activation -> planes), 3 (bias + residual -> fp32), two streams";
   for e in 1 2 3; do $B -s fwd -t 5,10 -w 150 -2 -e $e; done;
-  echo "# epilogue 4 (ACCUM, split-K atomics: the weight gradients), two streams"; $B -s bwd -t 3,5,6 -w 150 -2 -e 4;
+  W=3072x768x3168,768x3072x3168,2304x768x3168,768x768x3168,3072x768x1600,768x3072x1600,2304x768x1600,768x768x1600
+  echo "# epilogue 4 (ACCUM: the weight gradients at 4 / 2 img per GPU; 3 / 5: split-K grids, 11: stream-K form of the persistent kernel), one stream"; $B -s $W -t 3,5,11,0 -w 150 -e 4;
+  echo "# the same, two streams"; $B -s $W -t 3,5,11,0 -w 150 -2 -e 4;
   echo "# single-accumulator 256 x 256 timing probes (tiles 8 / 9; results invalid by construction: lo planes are scaled), two streams";
   $B -s 15696x3072x768,15696x768x3072,6280x3072x768,3140x3072x768 -t 10,8,9 -w 150 -2; } > $OUT/${TAG}_gemm16_tiles.txt 2>&1
 { echo "# LD_LIBRARY_PATH=tools/abl/16 (G16_ABL=16: s_memtime stamps of wave 0 per block): prologue / k-loop / epilogue cycles";
