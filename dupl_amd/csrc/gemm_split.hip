@@ -33,15 +33,23 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr int TBK = 32;
 constexpr float LO_INV = 1.f / DUPL_LO_SCALE;
 
+template <bool F1>
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, __half* __restrict__ hi, __half* __restrict__ lo,
-                                                    long n4) {
+                                                    long n4, float scale) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         __half h[4], l[4];
-        split_f32(v.x, h[0], l[0]);
-        split_f32(v.y, h[1], l[1]);
-        split_f32(v.z, h[2], l[2]);
-        split_f32(v.w, h[3], l[3]);
+        if constexpr (F1) {
+            split_f32_u(v.x * scale, h[0], l[0]);
+            split_f32_u(v.y * scale, h[1], l[1]);
+            split_f32_u(v.z * scale, h[2], l[2]);
+            split_f32_u(v.w * scale, h[3], l[3]);
+        } else {
+            split_f32(v.x, h[0], l[0]);
+            split_f32(v.y, h[1], l[1]);
+            split_f32(v.z, h[2], l[2]);
+            split_f32(v.w, h[3], l[3]);
+        }
         reinterpret_cast<uint2*>(hi)[i] = *reinterpret_cast<uint2*>(h);
         reinterpret_cast<uint2*>(lo)[i] = *reinterpret_cast<uint2*>(l);
     }
@@ -139,7 +147,8 @@ __device__ __forceinline__ void gemm16_epilogue_lds(const dupl_gemm16_desc& p, f
     const int fl = p.flags;
     const bool f_pre = fl & DUPL_GEMM_STORE_PRE, f_gelu = fl & DUPL_GEMM_GELU, f_relu = fl & DUPL_GEMM_RELU;
     const bool f_acc = fl & DUPL_GEMM_ACCUM, f_dgelu = fl & DUPL_GEMM_MUL_DGELU, f_rmask = fl & DUPL_GEMM_MUL_RELUMASK;
-    const float alpha = p.alpha_dev ? *p.alpha_dev : 1.f;
+    const float alpha = (p.alpha_dev ? *p.alpha_dev : 1.f) * (p.post_scale != 0.f ? p.post_scale : 1.f);
+    const float out_scale = p.out_exp > 0 ? ldexpf(1.f, p.out_exp) : 0.f;      // > 0: the planes go out in format 1
 #pragma unroll
     for (int ps = 0; ps < WM / WMP; ++ps) {
     const int mw = mw0 + ps * TH;
@@ -248,8 +257,13 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) cp[c] = v[c]; }
         }
         if (Ch) {
             __half h[4], l[4];
+            if (out_scale > 0.f) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) split_f32(v[c], h[c], l[c]);
+                for (int c = 0; c < 4; ++c) split_f32_u(v[c] * out_scale, h[c], l[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) split_f32(v[c], h[c], l[c]);
+            }
             __half* hp = Ch + (size_t)row * p.ldo + col;
             __half* lp = Cl + (size_t)row * p.ldo + col;
             if (fast) {
@@ -1072,6 +1086,7 @@ static int g16_persist_blocks_set = 0;  // blocks of the persistent kernels (a m
                                         // (176 .. 208 blocks run a GEMM as fast as 256: fewer CUs, higher clock), and the CUs left over
                                         // let the other student's kernels in earlier (step 61.55 -> 61.0 ms, same box; 128: 63.5)
 #define g16_persist_blocks (g16_persist_blocks_set ? g16_persist_blocks_set : (g16_concurrency >= 2 ? 192 : 256))
+static int g16_f1_big_from = 96;  // format 1: 256 x 256 tiles from this many of them
 static int g16_concurrency = 1;  // how many streams feed split GEMMs at a time (dupl_set_gemm16_concurrency)
 static int g16_tile = 0;     // 0 = heuristic; 3: 128x64 on 4 waves; 5: 128x128 on 8 waves (wave tile 64x32 in both).  Measured
                              // and dropped: 64x64 wave tiles on 4 / 8 waves (2 waves / SIMD: -10..25 %), 256x128 on 16 waves
@@ -1084,7 +1099,20 @@ extern "C" int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, d
     const long n4 = n / 4;
     long g = (n4 + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(split_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4);
+    hipLaunchKernelGGL(split_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4, 1.f);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_split_f16x2b(const float* x, void* hi, void* lo, int64_t n, int32_t scale_exp, dupl_stream_t stream) {
+    (void)hipGetLastError();
+    if (!x || !hi || !lo || n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(hi) & 7) ||
+        (reinterpret_cast<uintptr_t>(lo) & 7) || scale_exp < 0 || scale_exp > 15)
+        return DUPL_ERR_ARG;
+    const long n4 = n / 4;
+    long g = (n4 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(split_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4,
+                       ldexpf(1.f, scale_exp));
     return dupl_launch_status();
 }
 
@@ -1108,7 +1136,7 @@ extern "C" int dupl_set_gemm16_persist_blocks(int32_t n) {
 }
 
 extern "C" int dupl_set_gemm16_tile(int32_t t) {
-    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9 && t != 10 && t != 11) return DUPL_ERR_ARG;
+    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9 && t != 10 && t != 11 && t != 12) return DUPL_ERR_ARG;
     g16_tile = t;
     return DUPL_OK;
 }
@@ -1129,6 +1157,8 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
     if (accum && (!d->C || d->C_hi || d->bias || d->res || d->c_rows)) return DUPL_ERR_ARG;   // C += alpha * A B^T, nothing else
     if (d->c_rows < 0 || (d->c_rows && (d->flags & (DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK)))) return DUPL_ERR_ARG;
     if (d->amax_out && (accum || d->c_rows || (reinterpret_cast<uintptr_t>(d->amax_out) & 3))) return DUPL_ERR_ARG;
+    if (d->fmt < 0 || d->fmt > 1 || d->out_exp < 0 || d->out_exp > 15 || (d->out_exp && d->fmt != 1) || (d->fmt == 1 && (accum || d->amax_out)))
+        return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     // split-K for accumulating GEMMs (weight gradients: few output tiles, K = all tokens): >= ~2 blocks per CU,
     // >= 8 k-tiles per split
@@ -1160,6 +1190,15 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         else tile = b128 < 200 ? 3 : 5;
     }
     auto blocks = [&](int bm, int bn) { return dim3((unsigned)(((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn)), (unsigned)ksplit); };
+    if (d->fmt == 1) {
+        // format 1 operands: one accumulator set.  256 x 256 on 8 waves (wave tile 128 x 64, two LDS stages of 64 KB) where the grid
+        // fills the chip, 256 x 128 (the ring kernel's tile, half the accumulators) below
+        const long b22 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+        const int t = (g16_tile == 8 || g16_tile == 12) ? g16_tile : (b22 >= g16_f1_big_from ? 8 : 12);
+        if (t == 8) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), blocks(256, 256), dim3(512), 0, s, *d, g16_group_ring);
+        else hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2, 3, true>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
+        return dupl_launch_status();
+    }
     if (tile == 10 && (accum || d->K / TBK < 3)) tile = 6;      // the persistent kernel has no split-K and a 3-stage prologue
     if (tile == 11 && (!accum || g_dupl_deterministic || d->K / TBK < 8)) tile = accum ? 5 : 6;   // stream-K: atomics, pieces >= 3 k-steps
     if (tile == 11) {
