@@ -113,6 +113,11 @@ def param_segment(key: str) -> int:
     return SEG_CLS
 
 
+# operand plane format of the encoder's forward GEMMs: 1 = prescaled planes with an unscaled lo (one accumulator set, 256 x 256
+# tiles: +12-15 % on the big shapes), 0 = the x 2048 lo planes everywhere (DUPL_FMT1=0; the backward always uses those)
+FMT1 = os.environ.get("DUPL_FMT1", "1") != "0"
+
+
 class FlatStorage:
     """All parameters of `n_students` students in ONE fp32 buffer (+ a same-shaped gradient buffer):
         [student 0: frozen | backbone | norm | cls | decoder][student 1: ...]
@@ -185,8 +190,22 @@ class FlatStorage:
             self.data16 = torch.empty((2, self.data.numel()), device=self.data.device, dtype=torch.float16)
             self._w16_key = [None] * self.n_students
         n, base = self.student_numel, student * self.student_numel
-        ops.L().dupl_split_f16x2(self.data.data_ptr() + 4 * base, self.data16.data_ptr() + 2 * base,
-                                 self.data16.data_ptr() + 2 * (self.data.numel() + base), n, ops._stream())
+        tot = self.data.numel()
+        if FMT1:
+            # the backbone segment (every encoder Linear weight) as format 1 planes of w * 2^EXP_W (single-accumulator forward
+            # GEMMs), everything else (decoder convs) as format 0
+            b0, b1 = self.seg_bounds[SEG_BACKBONE]
+            for lo_, hi_, e in ((0, b0, 0), (b0, b1, ops.EXP_W), (b1, n, 0)):
+                if hi_ > lo_:
+                    o = base + lo_
+                    args = (self.data.data_ptr() + 4 * o, self.data16.data_ptr() + 2 * o, self.data16.data_ptr() + 2 * (tot + o), hi_ - lo_)
+                    if e:
+                        ops.L().dupl_split_f16x2b(*args, e, ops._stream())
+                    else:
+                        ops.L().dupl_split_f16x2(*args, ops._stream())
+        else:
+            ops.L().dupl_split_f16x2(self.data.data_ptr() + 4 * base, self.data16.data_ptr() + 2 * base,
+                                     self.data16.data_ptr() + 2 * (tot + base), n, ops._stream())
         old = self._w16_key[student]
         self._w16_key[student] = key
         # the operands changed: re-check their range (synchronously unless this was an optimiser step)
@@ -223,7 +242,8 @@ class FlatStorage:
         off, n = self.layout[key]
         base = student * self.student_numel + off
         p = self.data16.data_ptr()
-        return ops.W16(p + 2 * base, p + 2 * (self.data.numel() + base), rows, n // rows)
+        exp = ops.EXP_W if (FMT1 and param_segment(key) == SEG_BACKBONE) else 0
+        return ops.W16(p + 2 * base, p + 2 * (self.data.numel() + base), rows, n // rows, exp)
 
     def trainable_range(self, student: int) -> Tuple[int, int]:
         s = student * self.student_numel
@@ -368,7 +388,10 @@ class RangeGuard:
         def rown(k):
             return v[ix[k], 1]
 
-        out = {"patch": ok(amax("encoder.patch_embed.proj.weight")), "blocks": []}
+        # format 1 planes hold x * 2^EXP_ACT / w * 2^EXP_W: the bounds of the encoder sites are checked at that scale
+        sa = 2.0 ** ops.EXP_ACT if FMT1 else 1.0
+        sw = 2.0 ** ops.EXP_W if FMT1 else 1.0
+        out = {"patch": ok(3.0 * sa, amax("encoder.patch_embed.proj.weight") * sw), "blocks": []}
         for i in range(cfg.depth):
             p = f"encoder.blocks.{i}."
             g1, g2 = amax(p + "norm1.weight"), amax(p + "norm2.weight")
@@ -377,11 +400,11 @@ class RangeGuard:
             e_qkv = n1 * rown(p + "attn.qkv.weight") + amax(p + "attn.qkv.bias")
             e_h = n2 * rown(p + "mlp.fc1.weight") + amax(p + "mlp.fc1.bias")
             out["blocks"].append({
-                "qkv": ok(el1, amax(p + "attn.qkv.weight")),
+                "qkv": ok(el1 * sa, amax(p + "attn.qkv.weight") * sw),
                 "attn": ok(e_qkv),
-                "proj": ok(e_qkv, amax(p + "attn.proj.weight")),
-                "fc1": ok(el2, amax(p + "mlp.fc1.weight")),
-                "fc2": ok(e_h, amax(p + "mlp.fc2.weight")),
+                "proj": ok(e_qkv * sa, amax(p + "attn.proj.weight") * sw),
+                "fc1": ok(el2 * sa, amax(p + "mlp.fc1.weight") * sw),
+                "fc2": ok(e_h * sa, amax(p + "mlp.fc2.weight") * sw),
             })
         gf = amax("encoder.norm.weight")
         elf, nf = gf * sq + amax("encoder.norm.bias"), gf * sq + rown("encoder.norm.bias")
@@ -555,6 +578,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
     # Only while every site runs on planes (an f32-routed consumer needs its fp32 input for all rows).
     if save_rows and not (hd == 64 and all(b[k] for b in guard["blocks"] for k in RangeGuard.SITES)):
         save_rows = 0
+    EA = ops.EXP_ACT if FMT1 else 0       # plane format of the activations that feed the encoder's GEMMs
     toks, groups = [], []
     r0 = 0
     for x in xs:
@@ -562,7 +586,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         h, w = Himg // cfg.patch, Wimg // cfg.patch
         n = h * w
         if guard["patch"]:
-            rows16 = ops.split16(ops.patch_im2row(x, cfg.patch))
+            rows16 = ops.split16(ops.patch_im2row(x, cfg.patch), exp=EA)
             patch, _ = ops.linear16(rows16, P.w16("encoder.patch_embed.proj.weight", D), W["encoder.patch_embed.proj.bias"])
             del rows16
         else:
@@ -585,7 +609,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         g = guard["blocks"][i]
         attn16 = hd == 64 and g["attn"]          # q, k, v as planes into the split attention kernel
         ln1, ln1_16, m1, r1 = ops.layernorm_fwd16(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, save,
-                                                  want_f32=save or not g["qkv"], f32_rows=save_rows)
+                                                  want_f32=save or not g["qkv"], f32_rows=save_rows, exp=EA)
         lse = None
         # q, k, v stay fp16 planes end to end where their range allows: the qkv GEMM writes them, the split attention kernel
         # reads them and writes the planes the projection GEMM consumes; fp32 copies only where the backward (save) or an
@@ -602,7 +626,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         del ln1_16
         need_att32 = save or not g["proj"]
         att = torch.empty((save_rows or R, D), device=t.device, dtype=torch.float32) if (need_att32 or not attn16) else None
-        att16 = ops.split16_empty(R, D, t.device) if (attn16 and g["proj"]) else None
+        att16 = ops.split16_empty(R, D, t.device, EA) if (attn16 and g["proj"]) else None
         for (g0, B, N, _, _) in groups:
             if attn16:
                 bf = save_rows // N if save_rows else 0
@@ -612,7 +636,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
             else:   # other head dims (the 96-dim test backbone) or q / k / v beyond fp16's range: exact-f32 attention kernel
                 _, lse = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
         if not attn16 and g["proj"]:
-            att16 = ops.split16(att)
+            att16 = ops.split16(att, exp=EA)
         qkv16_keep = qkv16 if (save and attn16) else None
         del qkv16
         if g["proj"]:
@@ -621,14 +645,14 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
             x_mid = ops.linear(att, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], res=t)
         del att16
         ln2, ln2_16, m2, r2 = ops.layernorm_fwd16(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save,
-                                                  want_f32=save or not g["fc1"], f32_rows=save_rows)
+                                                  want_f32=save or not g["fc1"], f32_rows=save_rows, exp=EA)
         pre1 = torch.empty((save_rows or R, D * cfg.mlp_ratio), device=t.device, dtype=torch.float32) if save else None
         if g["fc1"]:
             h1, h1_16 = ops.linear16(ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio), W[p + "mlp.fc1.bias"], gelu=True,
-                                     store_pre=pre1, want_f32=save or not g["fc2"], want16=g["fc2"], c_rows=save_rows)
+                                     store_pre=pre1, want_f32=save or not g["fc2"], want16=g["fc2"], c_rows=save_rows, out_exp=EA)
         else:
             h1 = ops.linear(ln2, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], gelu=True, store_pre=pre1)
-            h1_16 = ops.split16(h1) if g["fc2"] else None
+            h1_16 = ops.split16(h1, exp=EA) if g["fc2"] else None
         del ln2_16
         if g["fc2"]:
             x_out, _ = ops.linear16(h1_16, P.w16(p + "mlp.fc2.weight", D), W[p + "mlp.fc2.bias"], res=x_mid)

@@ -179,6 +179,9 @@ int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, 
 /* the same with the fp32 copy y (and mean / rstd) written for the first f32_rows rows only (0 = all): y then has f32_rows rows */
 int dupl_layernorm_fwd16b(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
                           float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows, dupl_stream_t s);
+/* the same with the planes in format 1 (y * 2^plane_exp, unscaled lo: dupl_gemm16_desc.fmt) when plane_exp > 0 */
+int dupl_layernorm_fwd16c(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
+                          float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows, int32_t plane_exp, dupl_stream_t s);
 /* LayerNorm backward (autograd of vit.py:157,159,323), optionally fused with the residual-stream gradient add */
 int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
@@ -225,6 +228,9 @@ int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, vo
 int dupl_attention_fwd16b(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi, void* out_lo,
                           float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, int32_t B_f32,
                           dupl_stream_t s);
+/* the same with the output planes in format 1 (out * 2^out_exp, unscaled lo) when out_exp > 0 */
+int dupl_attention_fwd16c(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi, void* out_lo,
+                          float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s);
 /* backward (what autograd derives for vit.py:123-135): dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N]. */
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,
