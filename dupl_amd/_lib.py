@@ -42,7 +42,8 @@ class Gemm16Desc(ctypes.Structure):
         ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("ldo", ctypes.c_int32),
         ("ldr", ctypes.c_int32), ("ldaux", ctypes.c_int32),
         ("flags", ctypes.c_int32), ("c_rows", ctypes.c_int32),
-        ("alpha_dev", ctypes.c_void_p), ("amax_out", ctypes.c_void_p),
+        ("alpha_dev", ctypes.c_void_p), ("fmt", ctypes.c_int32), ("out_exp", ctypes.c_int32), ("post_scale", ctypes.c_float),
+        ("amax_out", ctypes.c_void_p),
     ]
 
 

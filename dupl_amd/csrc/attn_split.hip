@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
                                                             const __half* __restrict__ vT_hi, const __half* __restrict__ vT_lo,
                                                             float* __restrict__ out, __half* __restrict__ out_hi,
                                                             __half* __restrict__ out_lo, float* __restrict__ lse, int N, int H,
-                                                            int Npad, float scale, int remap, int B_f32) {
+                                                            int Npad, float scale, int remap, int B_f32, float out_scale) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     int bx, h, b;
@@ -320,7 +320,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
                 if (out_hi) {
                     __half hh[4], ll[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) split_f32(v[j], hh[j], ll[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (out_scale > 0.f) split_f32_u(v[j] * out_scale, hh[j], ll[j]);     // format 1 planes for the projection GEMM
+                        else split_f32(v[j], hh[j], ll[j]);
+                    }
                     *reinterpret_cast<uint2*>(out_hi + ro + col) = *reinterpret_cast<const uint2*>(hh);
                     *reinterpret_cast<uint2*>(out_lo + ro + col) = *reinterpret_cast<const uint2*>(ll);
                 }
@@ -341,10 +344,19 @@ extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void
     return dupl_attention_fwd16b(qkv_hi, qkv_lo, vT_hi, vT_lo, out, out_hi, out_lo, lse, B, N, H, hd, Npad, scale, B, s);
 }
 
+extern "C" int dupl_attention_fwd16c(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
+                                     void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
+                                     float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s);
 extern "C" int dupl_attention_fwd16b(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
                                      void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
                                      float scale, int32_t B_f32, dupl_stream_t s) {
+    return dupl_attention_fwd16c(qkv_hi, qkv_lo, vT_hi, vT_lo, out, out_hi, out_lo, lse, B, N, H, hd, Npad, scale, B_f32, 0, s);
+}
+extern "C" int dupl_attention_fwd16c(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
+                                     void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
+                                     float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s) {
     (void)hipGetLastError();
+    if (out_exp < 0 || out_exp > 15) return DUPL_ERR_ARG;
     if (B_f32 < 0 || B_f32 > B || (B_f32 < B && !out_hi)) return DUPL_ERR_ARG;
     if (!qkv_hi || !qkv_lo || !vT_hi || !vT_lo || (!out && !out_hi) || ((out_hi == nullptr) != (out_lo == nullptr)) || B <= 0 ||
         N <= 0 || H <= 0 || hd != HD || Npad < N || (Npad % KT))
@@ -355,6 +367,6 @@ extern "C" int dupl_attention_fwd16b(const void* qkv_hi, const void* qkv_lo, voi
                        (const __half*)qkv_lo, (__half*)vT_hi, (__half*)vT_lo, N, H, Npad);
     hipLaunchKernelGGL(attn_fwd16_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
                        (const __half*)qkv_lo, (const __half*)vT_hi, (const __half*)vT_lo, out, (__half*)out_hi, (__half*)out_lo, lse,
-                       N, H, Npad, scale, g_attn16_remap, B_f32);
+                       N, H, Npad, scale, g_attn16_remap, B_f32, out_exp ? ldexpf(1.f, out_exp) : 0.f);
     return dupl_launch_status();
 }

@@ -105,6 +105,18 @@ constexpr float DUPL_LO_SCALE = 2048.f;
 // Range: finite |x| > 65504 saturates -- tensors that could get there are kept off this path by the range guard
 // (engine.RangeGuard, csrc/range.hip); NaN / Inf propagate as in fp32 arithmetic (hi = NaN / Inf, lo = NaN), they are not
 // laundered into finite values (fmaxf(NaN, a) = a would do that).
+// Format 1 of the operand planes (single-accumulator GEMM tiles): the value travels pre-scaled by a power of two chosen per
+// tensor class (X = x * 2^s: activations s = 3, weights s = 9) and lo = fp16(X - hi) WITHOUT the x 2048 -- all three products
+// hi hi + hi lo + lo hi then have the same scale and can share one accumulator.  lo is ~2^-12 X: normal down to |X| ~ 2^-2,
+// below that its absolute error is <= 2^-25, i.e. 2^-28 relative to an element of typical size 8 -- the error budget of the
+// format is relative to the tensor's scale, not to each element (the range guard bounds the top end: |X| <= 65504).
+__device__ __forceinline__ void split_f32_u(float x, __half& hi, __half& lo) {
+    const float c = fminf(fmaxf(x, -65504.f), 65504.f);
+    x = fabsf(x) <= 3.0e38f ? c : x;
+    asm volatile("" : "+v"(x));
+    hi = __float2half_rn(x);
+    lo = __float2half_rn(x - __half2float(hi));
+}
 __device__ __forceinline__ void split_f32(float x, __half& hi, __half& lo) {
     const float c = fminf(fmaxf(x, -65504.f), 65504.f);
     x = fabsf(x) <= 3.0e38f ? c : x;

@@ -33,15 +33,23 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr int TBK = 32;
 constexpr float LO_INV = 1.f / DUPL_LO_SCALE;
 
+template <bool F1>
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, __half* __restrict__ hi, __half* __restrict__ lo,
-                                                    long n4) {
+                                                    long n4, float scale) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         __half h[4], l[4];
-        split_f32(v.x, h[0], l[0]);
-        split_f32(v.y, h[1], l[1]);
-        split_f32(v.z, h[2], l[2]);
-        split_f32(v.w, h[3], l[3]);
+        if constexpr (F1) {
+            split_f32_u(v.x * scale, h[0], l[0]);
+            split_f32_u(v.y * scale, h[1], l[1]);
+            split_f32_u(v.z * scale, h[2], l[2]);
+            split_f32_u(v.w * scale, h[3], l[3]);
+        } else {
+            split_f32(v.x, h[0], l[0]);
+            split_f32(v.y, h[1], l[1]);
+            split_f32(v.z, h[2], l[2]);
+            split_f32(v.w, h[3], l[3]);
+        }
         reinterpret_cast<uint2*>(hi)[i] = *reinterpret_cast<uint2*>(h);
         reinterpret_cast<uint2*>(lo)[i] = *reinterpret_cast<uint2*>(l);
     }
@@ -139,7 +147,8 @@ __device__ __forceinline__ void gemm16_epilogue_lds(const dupl_gemm16_desc& p, f
     const int fl = p.flags;
     const bool f_pre = fl & DUPL_GEMM_STORE_PRE, f_gelu = fl & DUPL_GEMM_GELU, f_relu = fl & DUPL_GEMM_RELU;
     const bool f_acc = fl & DUPL_GEMM_ACCUM, f_dgelu = fl & DUPL_GEMM_MUL_DGELU, f_rmask = fl & DUPL_GEMM_MUL_RELUMASK;
-    const float alpha = p.alpha_dev ? *p.alpha_dev : 1.f;
+    const float alpha = (p.alpha_dev ? *p.alpha_dev : 1.f) * (p.post_scale != 0.f ? p.post_scale : 1.f);
+    const float out_scale = p.out_exp > 0 ? ldexpf(1.f, p.out_exp) : 0.f;      // > 0: the planes go out in format 1
 #pragma unroll
     for (int ps = 0; ps < WM / WMP; ++ps) {
     const int mw = mw0 + ps * TH;
@@ -248,8 +257,13 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) cp[c] = v[c]; }
         }
         if (Ch) {
             __half h[4], l[4];
+            if (out_scale > 0.f) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) split_f32(v[c], h[c], l[c]);
+                for (int c = 0; c < 4; ++c) split_f32_u(v[c] * out_scale, h[c], l[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) split_f32(v[c], h[c], l[c]);
+            }
             __half* hp = Ch + (size_t)row * p.ldo + col;
             __half* lp = Cl + (size_t)row * p.ldo + col;
             if (fast) {
@@ -273,6 +287,7 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c)
 // them inside N.  Bias, activation, aux / res traffic and the stores exactly as gemm16_epilogue_lds does them (ACCUM excluded).
 struct Epi16 {
     bool f_pre, f_gelu, f_relu, f_dgelu, f_rmask, vec;
+    float out_scale;        // > 0: the result planes go out in format 1 (C * out_scale, unscaled lo)
     __half *Ch, *Cl;
 };
 __device__ __forceinline__ Epi16 epi16_setup(const dupl_gemm16_desc& p) {
@@ -282,6 +297,7 @@ __device__ __forceinline__ Epi16 epi16_setup(const dupl_gemm16_desc& p) {
     e.f_dgelu = fl & DUPL_GEMM_MUL_DGELU; e.f_rmask = fl & DUPL_GEMM_MUL_RELUMASK;
     e.Ch = static_cast<__half*>(p.C_hi);
     e.Cl = static_cast<__half*>(p.C_lo);
+    e.out_scale = p.out_exp > 0 ? ldexpf(1.f, p.out_exp) : 0.f;
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     e.vec = !(p.N & 3) && !(p.ldc & 3) && !(p.ldo & 3) && !(p.ldr & 3) && !(p.ldaux & 3) && a16(p.C) && a16(p.res) && a16(p.aux) &&
             a16(p.bias) && !(reinterpret_cast<uintptr_t>(e.Ch) & 7) && !(reinterpret_cast<uintptr_t>(e.Cl) & 7);
@@ -348,8 +364,13 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
     }
     if (E.Ch) {
         __half h[4], l[4];
+        if (E.out_scale > 0.f) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_f32(v[c], h[c], l[c]);
+            for (int c = 0; c < 4; ++c) split_f32_u(v[c] * E.out_scale, h[c], l[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) split_f32(v[c], h[c], l[c]);
+        }
         __half* hp = E.Ch + (size_t)row * p.ldo + col;
         __half* lp = E.Cl + (size_t)row * p.ldo + col;
         if (fast) {
@@ -370,13 +391,14 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
 // side buffer, 8 rows x 64 columns at a time (4 WM passes: MFMA tile i, register group g = rows 8 g .. 8 g + 7 of it).
 // Same access pattern as gemm16_epilogue_lds (b32 writes of 32 consecutive floats, b128 reads of whole 256-byte rows ->
 // float4 global accesses); in-order LDS execution within the wave orders the passes.
-template <int WM, int WN, bool ACC = false>
-__device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN], f32x16 (&accX)[WM][WN],
+template <int WM, int WN, bool ACC = false, bool SINGLE = false>
+__device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN],
+                                                     f32x16 (&accX)[SINGLE ? 1 : WM][SINGLE ? 1 : WN],
                                                      float* __restrict__ side, const int mw, const int nw, const int lane,
                                                      float& amx) {
     static_assert(WN == 2, "side buffer rows are 64 floats");
     const int l31 = lane & 31, hf = lane >> 5;
-    const float alpha = p.alpha_dev ? *p.alpha_dev : 1.f;
+    const float alpha = (p.alpha_dev ? *p.alpha_dev : 1.f) * (p.post_scale != 0.f ? p.post_scale : 1.f);
     const Epi16 E = epi16_setup(p);
     const int cl = (lane & 15) * 4, rl = lane >> 4;
     const int col = nw + cl;
@@ -395,7 +417,12 @@ __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, 
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    side[(q + 4 * hf) * 64 + j * 32 + l31] = (accM[i][j][4 * g + q] + accX[i][j][4 * g + q] * LO_INV) * alpha;
+                {
+                    float v;
+                    if constexpr (SINGLE) v = accM[i][j][4 * g + q] * alpha;
+                    else v = (accM[i][j][4 * g + q] + accX[SINGLE ? 0 : i][SINGLE ? 0 : j][4 * g + q] * LO_INV) * alpha;
+                    side[(q + 4 * hf) * 64 + j * 32 + l31] = v;
+                }
             if constexpr (ACC) {
                 // C += partial (stream-K pieces of a weight gradient meet in fp32 atomics): lane = column, one instruction adds
                 // to 64 consecutive floats of a row
@@ -838,9 +865,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_ring_kernel(co
 // for another one, every CU gets the same number of k-steps whatever the tile count -- a split-K grid of 288 or 540 blocks
 // on 256 CUs leaves the chip half empty for its second round.  Cuts are moved off the first / last two k-steps of a tile, so
 // that every piece has the >= 3 k-steps the three-stage prologue needs.
-template <int WM, int WN, int NWM, int NWN, int WPS, bool SK = false>
+template <int WM, int WN, int NWM, int NWN, int WPS, bool SK = false, bool SINGLE = false, int STAGES = 3>
 __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(const dupl_gemm16_desc p, const int g_gm) {
-    constexpr int STAGES = 3;
     constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, NW = NWM * NWN;
     constexpr int PA = BM / 16, PB = BN / 16;
     constexpr int NP = 2 * PA + 2 * PB;
@@ -904,7 +930,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
     const int sw = (l31 >> 2) & 3;
     const int a_row = (wm * (32 * WM) + l31) * 64, b_row = 2 * PA * 1024 + (wn * (32 * WN) + l31) * 64;
     const int c0 = ((0 | hf) ^ sw) * 16, c1 = ((2 | hf) ^ sw) * 16;
-    f32x16 accM[WM][WN], accX[WM][WN];
+    f32x16 accM[WM][WN], accX[SINGLE ? 1 : WM][SINGLE ? 1 : WN];      // SINGLE (format 1 operands): the cross terms go into accM
     h8 f0a[2 * WM], f0b[2 * WN], f1a[2 * WM], f1b[2 * WN];
     auto read_frags = [&](const char* st, const int cs, h8(&fa)[2 * WM], h8(&fb)[2 * WN]) __attribute__((always_inline)) {
 #pragma unroll
@@ -928,12 +954,18 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j) accX[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[WN + j], accX[i][j], 0, 0, 0);
+            for (int j = 0; j < WN; ++j) {
+                if constexpr (SINGLE) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[WN + j], accM[i][j], 0, 0, 0);
+                else accX[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[WN + j], accX[i][j], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(XMFMA);
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j) accX[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WM + i], fb[j], accX[i][j], 0, 0, 0);
+            for (int j = 0; j < WN; ++j) {
+                if constexpr (SINGLE) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WM + i], fb[j], accM[i][j], 0, 0, 0);
+                else accX[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WM + i], fb[j], accX[i][j], 0, 0, 0);
+            }
     };
     auto read_item = [&](auto rc, const char* st, const int cs, h8(&fa)[2 * WM], h8(&fb)[2 * WN]) __attribute__((always_inline)) {
         constexpr int R = decltype(rc)::value;
@@ -986,7 +1018,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     accM[i][j][e] = 0.f;
-                    accX[i][j][e] = 0.f;
+                    if constexpr (!SINGLE) accX[i][j][e] = 0.f;
                 }
         // tile 0 of this k-loop has landed.  First tile of the block: the two younger stages may still fly; later tiles: the
         // prologue was issued before the previous epilogue, whose stores are younger in the same counter -> drain everything
@@ -1053,7 +1085,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
 #pragma unroll
             for (int s = 0; s < STAGES; ++s) issue(s);
         }
-        gemm16_epilogue_side<WM, WN, SK>(p, accM, accX, reinterpret_cast<float*>(smem + STAGES * STAGE) + wave * 512, mw, nw, lane,
+        gemm16_epilogue_side<WM, WN, SK, SINGLE>(p, accM, accX, reinterpret_cast<float*>(smem + STAGES * STAGE) + wave * 512, mw, nw, lane,
                                          amx);
         if (!more) break;
     }
@@ -1072,6 +1104,7 @@ static int g16_persist_blocks_set = 0;  // blocks of the persistent kernels (a m
                                         // (176 .. 208 blocks run a GEMM as fast as 256: fewer CUs, higher clock), and the CUs left over
                                         // let the other student's kernels in earlier (step 61.55 -> 61.0 ms, same box; 128: 63.5)
 #define g16_persist_blocks (g16_persist_blocks_set ? g16_persist_blocks_set : (g16_concurrency >= 2 ? 192 : 256))
+static int g16_f1_big_from = 96;  // format 1: 256 x 256 tiles from this many of them
 static int g16_concurrency = 1;  // how many streams feed split GEMMs at a time (dupl_set_gemm16_concurrency)
 static int g16_tile = 0;     // 0 = heuristic; 3: 128x64 on 4 waves; 5: 128x128 on 8 waves (wave tile 64x32 in both).  Measured
                              // and dropped: 64x64 wave tiles on 4 / 8 waves (2 waves / SIMD: -10..25 %), 256x128 on 16 waves
@@ -1084,7 +1117,20 @@ extern "C" int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, d
     const long n4 = n / 4;
     long g = (n4 + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(split_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4);
+    hipLaunchKernelGGL(split_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4, 1.f);
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_split_f16x2b(const float* x, void* hi, void* lo, int64_t n, int32_t scale_exp, dupl_stream_t stream) {
+    (void)hipGetLastError();
+    if (!x || !hi || !lo || n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(hi) & 7) ||
+        (reinterpret_cast<uintptr_t>(lo) & 7) || scale_exp < 0 || scale_exp > 15)
+        return DUPL_ERR_ARG;
+    const long n4 = n / 4;
+    long g = (n4 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(split_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4,
+                       ldexpf(1.f, scale_exp));
     return dupl_launch_status();
 }
 
@@ -1108,7 +1154,7 @@ extern "C" int dupl_set_gemm16_persist_blocks(int32_t n) {
 }
 
 extern "C" int dupl_set_gemm16_tile(int32_t t) {
-    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9 && t != 10 && t != 11) return DUPL_ERR_ARG;
+    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9 && t != 10 && t != 11 && t != 12 && t != 14) return DUPL_ERR_ARG;
     g16_tile = t;
     return DUPL_OK;
 }
@@ -1129,6 +1175,8 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
     if (accum && (!d->C || d->C_hi || d->bias || d->res || d->c_rows)) return DUPL_ERR_ARG;   // C += alpha * A B^T, nothing else
     if (d->c_rows < 0 || (d->c_rows && (d->flags & (DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK)))) return DUPL_ERR_ARG;
     if (d->amax_out && (accum || d->c_rows || (reinterpret_cast<uintptr_t>(d->amax_out) & 3))) return DUPL_ERR_ARG;
+    if (d->fmt < 0 || d->fmt > 1 || d->out_exp < 0 || d->out_exp > 15 || (d->out_exp && d->fmt != 1) || (d->fmt == 1 && (accum || d->amax_out)))
+        return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     // split-K for accumulating GEMMs (weight gradients: few output tiles, K = all tokens): >= ~2 blocks per CU,
     // >= 8 k-tiles per split
@@ -1160,6 +1208,25 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         else tile = b128 < 200 ? 3 : 5;
     }
     auto blocks = [&](int bm, int bn) { return dim3((unsigned)(((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn)), (unsigned)ksplit); };
+    // grid of a persistent kernel: every block walks the same number of tiles (see tile 10 below)
+    auto persist_grid = [&](const int nblk) {
+        const int tx = (nblk + 7) / 8, bmax = g16_persist_blocks / 8;
+        const int rounds = (tx + bmax - 1) / bmax;
+        return dim3((unsigned)(8 * ((tx + rounds - 1) / rounds)));
+    };
+    if (d->fmt == 1) {
+        // format 1 operands: one accumulator set.  256 x 256 on 8 waves (wave tile 128 x 64, two LDS stages of 64 KB; tile 8) where
+        // the grid fills the chip, 256 x 128 (the ring kernel's tile with half the accumulators; 12) below.  One block per tile: the
+        // persistent form of 256 x 128 (14) measures the same or 1-3 % less, that of 256 x 256 spills (228 vs 353 TF/s-eq)
+        const int nb22 = ((d->M + 255) / 256) * ((d->N + 255) / 256), nb21 = ((d->M + 255) / 256) * ((d->N + 127) / 128);
+        int t = (g16_tile == 8 || g16_tile == 12 || g16_tile == 14) ? g16_tile : (nb22 >= g16_f1_big_from ? 8 : 12);
+        if (d->K / TBK < 3 && t == 14) t = 12;
+        if (t == 8) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), blocks(256, 256), dim3(512), 0, s, *d, g16_group_ring);
+        else if (t == 12) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2, 3, true>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
+        else
+            hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2, false, true, 3>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
+        return dupl_launch_status();
+    }
     if (tile == 10 && (accum || d->K / TBK < 3)) tile = 6;      // the persistent kernel has no split-K and a 3-stage prologue
     if (tile == 11 && (!accum || g_dupl_deterministic || d->K / TBK < 8)) tile = accum ? 5 : 6;   // stream-K: atomics, pieces >= 3 k-steps
     if (tile == 11) {

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                             long rows, int D, float eps, __half* __restrict__ y_hi,
-                                                            __half* __restrict__ y_lo, long f32_rows) {
+                                                            __half* __restrict__ y_lo, long f32_rows, float plane_scale) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -56,10 +56,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             if (yr) yr[c] = o;
             if (hr) {
                 __half h[4], l[4];
-                split_f32(o.x, h[0], l[0]);
-                split_f32(o.y, h[1], l[1]);
-                split_f32(o.z, h[2], l[2]);
-                split_f32(o.w, h[3], l[3]);
+                if (plane_scale > 0.f) {       // format 1 planes (x * 2^s, unscaled lo): the A operand of a single-accumulator GEMM
+                    split_f32_u(o.x * plane_scale, h[0], l[0]);
+                    split_f32_u(o.y * plane_scale, h[1], l[1]);
+                    split_f32_u(o.z * plane_scale, h[2], l[2]);
+                    split_f32_u(o.w * plane_scale, h[3], l[3]);
+                } else {
+                    split_f32(o.x, h[0], l[0]);
+                    split_f32(o.y, h[1], l[1]);
+                    split_f32(o.z, h[2], l[2]);
+                    split_f32(o.w, h[3], l[3]);
+                }
                 hr[c] = *reinterpret_cast<uint2*>(h);
                 lr[c] = *reinterpret_cast<uint2*>(l);
             }
@@ -278,16 +285,26 @@ extern "C" int dupl_layernorm_fwd16(const float* x, const float* gamma, const fl
     return dupl_layernorm_fwd16b(x, gamma, beta, y, y_hi, y_lo, mean, rstd, rows, D, eps, 0, s);
 }
 
+extern "C" int dupl_layernorm_fwd16c(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
+                                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
+                                     int32_t plane_exp, dupl_stream_t s);
 extern "C" int dupl_layernorm_fwd16b(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
                                      float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
                                      dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
+    return dupl_layernorm_fwd16c(x, gamma, beta, y, y_hi, y_lo, mean, rstd, rows, D, eps, f32_rows, 0, s);
+}
+extern "C" int dupl_layernorm_fwd16c(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
+                                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
+                                     int32_t plane_exp, dupl_stream_t s) {
+    (void)hipGetLastError();
+    if (plane_exp < 0 || plane_exp > 15) return DUPL_ERR_ARG;
+    const float plane_scale = plane_exp ? ldexpf(1.f, plane_exp) : 0.f;  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !gamma || !beta || (!y && !y_hi) || ((y_hi == nullptr) != (y_lo == nullptr)) || rows <= 0 || D <= 0 || (D & 3) ||
         D > LN_MAXC_LIMIT * 256 || f32_rows < 0 || f32_rows > rows || (f32_rows && !y_hi))
         return DUPL_ERR_ARG;
     const int grid = (int)((rows + 3) / 4);
 #define LN_FWD(MC) hipLaunchKernelGGL(layernorm_fwd_kernel<MC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, gamma, beta, y, \
-                                      mean, rstd, (long)rows, D, eps, (__half*)y_hi, (__half*)y_lo, (long)f32_rows)
+                                      mean, rstd, (long)rows, D, eps, (__half*)y_hi, (__half*)y_lo, (long)f32_rows, plane_scale)
     if (D <= 256) LN_FWD(1);
     else if (D <= 768) LN_FWD(3);
     else if (D <= 1024) LN_FWD(4);

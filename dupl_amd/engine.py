@@ -113,6 +113,11 @@ def param_segment(key: str) -> int:
     return SEG_CLS
 
 
+# operand plane format of the encoder's forward GEMMs: 1 = prescaled planes with an unscaled lo (one accumulator set, 256 x 256
+# tiles: +12-15 % on the big shapes), 0 = the x 2048 lo planes everywhere (DUPL_FMT1=0; the backward always uses those)
+FMT1 = os.environ.get("DUPL_FMT1", "1") != "0"
+
+
 class FlatStorage:
     """All parameters of `n_students` students in ONE fp32 buffer (+ a same-shaped gradient buffer):
         [student 0: frozen | backbone | norm | cls | decoder][student 1: ...]
@@ -150,6 +155,7 @@ class FlatStorage:
         self.dirty = 0
         self._w16_key = [None] * n_students
         self._w16T: Dict = {}
+        self._w16F0: Dict = {}
         self.guard = RangeGuard(self)
 
     def wait_streams(self):
@@ -185,8 +191,22 @@ class FlatStorage:
             self.data16 = torch.empty((2, self.data.numel()), device=self.data.device, dtype=torch.float16)
             self._w16_key = [None] * self.n_students
         n, base = self.student_numel, student * self.student_numel
-        ops.L().dupl_split_f16x2(self.data.data_ptr() + 4 * base, self.data16.data_ptr() + 2 * base,
-                                 self.data16.data_ptr() + 2 * (self.data.numel() + base), n, ops._stream())
+        tot = self.data.numel()
+        if FMT1:
+            # the backbone segment (every encoder Linear weight) as format 1 planes of w * 2^EXP_W (single-accumulator forward
+            # GEMMs), everything else (decoder convs) as format 0
+            b0, b1 = self.seg_bounds[SEG_BACKBONE]
+            for lo_, hi_, e in ((0, b0, 0), (b0, b1, ops.EXP_W), (b1, n, 0)):
+                if hi_ > lo_:
+                    o = base + lo_
+                    args = (self.data.data_ptr() + 4 * o, self.data16.data_ptr() + 2 * o, self.data16.data_ptr() + 2 * (tot + o), hi_ - lo_)
+                    if e:
+                        ops.L().dupl_split_f16x2b(*args, e, ops._stream())
+                    else:
+                        ops.L().dupl_split_f16x2(*args, ops._stream())
+        else:
+            ops.L().dupl_split_f16x2(self.data.data_ptr() + 4 * base, self.data16.data_ptr() + 2 * base,
+                                     self.data16.data_ptr() + 2 * (tot + base), n, ops._stream())
         old = self._w16_key[student]
         self._w16_key[student] = key
         # the operands changed: re-check their range (synchronously unless this was an optimiser step)
@@ -218,12 +238,25 @@ class FlatStorage:
     def w16T_put(self, student: int, key: str, T):
         self._w16T[(student, key)] = ((self.data._version, self.dirty, self.data.data_ptr()), T)
 
-    def w16(self, student: int, key: str, rows: int) -> "ops.W16":
+    def w16(self, student: int, key: str, rows: int, fmt1: Optional[bool] = None) -> "ops.W16":
         """Operand planes of parameter `key` viewed as a [rows, numel / rows] matrix."""
         off, n = self.layout[key]
         base = student * self.student_numel + off
         p = self.data16.data_ptr()
-        return ops.W16(p + 2 * base, p + 2 * (self.data.numel() + base), rows, n // rows)
+        have = ops.EXP_W if (FMT1 and param_segment(key) == SEG_BACKBONE) else 0
+        if fmt1 is None:
+            fmt1 = bool(have)
+        if bool(have) == bool(fmt1):
+            return ops.W16(p + 2 * base, p + 2 * (self.data.numel() + base), rows, n // rows, have)
+        # a backbone weight whose site does not fit the format 1 scale (RangeGuard "<site>_f1"): format 0 planes, built on first
+        # use after every parameter change
+        assert not fmt1
+        ver = (self.data._version, self.dirty, self.data.data_ptr())
+        hit = self._w16F0.get((student, key))
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.split16(self.view(student, key).view(rows, -1)))
+            self._w16F0[(student, key)] = hit
+        return hit[1]
 
     def trainable_range(self, student: int) -> Tuple[int, int]:
         s = student * self.student_numel
@@ -309,6 +342,7 @@ class RangeGuard:
         self._steps = [0] * store.n_students
         self.safe: List[Optional[dict]] = [None] * store.n_students      # per student: site flags, None = not computed yet
         self.headroom = float("inf")   # min over sites of 65504 / (margin * bound) at the last check (< 1: some site is on f32)
+        self.headroom1 = float("inf")  # the same at the format 1 scales (< 1: some encoder site runs on format 0 planes)
         self.checks = 0
 
     # ---- device side
@@ -343,7 +377,7 @@ class RangeGuard:
         elif not self._event.query():
             return
         self._pending = False
-        self.headroom = float("inf")
+        self.headroom = self.headroom1 = float("inf")
         for s in range(self.store.n_students):
             self.safe[s] = self._decide(self._host[s].double().numpy())
         self.checks += 1
@@ -368,7 +402,18 @@ class RangeGuard:
         def rown(k):
             return v[ix[k], 1]
 
-        out = {"patch": ok(amax("encoder.patch_embed.proj.weight")), "blocks": []}
+        # format 1 planes hold x * 2^EXP_ACT / w * 2^EXP_W: "<site>_f1" says whether the site's operands also fit at that scale;
+        # a site that is fp16-safe but not at the format 1 scale runs on format 0 planes (two accumulator sets), not on f32
+        sa, sw = 2.0 ** ops.EXP_ACT, 2.0 ** ops.EXP_W
+        worst1 = [0.0]
+
+        def ok1(*bounds):
+            b = max(bounds)
+            worst1[0] = max(worst1[0], b)
+            return bool(FMT1 and b <= lim)
+
+        wp = amax("encoder.patch_embed.proj.weight")
+        out = {"patch": ok(wp), "patch_f1": ok1(3.0 * sa, wp * sw), "blocks": []}
         for i in range(cfg.depth):
             p = f"encoder.blocks.{i}."
             g1, g2 = amax(p + "norm1.weight"), amax(p + "norm2.weight")
@@ -376,19 +421,20 @@ class RangeGuard:
             el2, n2 = g2 * sq + amax(p + "norm2.bias"), g2 * sq + rown(p + "norm2.bias")
             e_qkv = n1 * rown(p + "attn.qkv.weight") + amax(p + "attn.qkv.bias")
             e_h = n2 * rown(p + "mlp.fc1.weight") + amax(p + "mlp.fc1.bias")
-            out["blocks"].append({
-                "qkv": ok(el1, amax(p + "attn.qkv.weight")),
-                "attn": ok(e_qkv),
-                "proj": ok(e_qkv, amax(p + "attn.proj.weight")),
-                "fc1": ok(el2, amax(p + "mlp.fc1.weight")),
-                "fc2": ok(e_h, amax(p + "mlp.fc2.weight")),
-            })
+            ops_ = {"qkv": (el1, amax(p + "attn.qkv.weight")), "proj": (e_qkv, amax(p + "attn.proj.weight")),
+                    "fc1": (el2, amax(p + "mlp.fc1.weight")), "fc2": (e_h, amax(p + "mlp.fc2.weight"))}
+            blk = {"attn": ok(e_qkv)}
+            for site, (ea, ew) in ops_.items():
+                blk[site] = ok(ea, ew)
+                blk[site + "_f1"] = blk[site] and ok1(ea * sa, ew * sw)
+            out["blocks"].append(blk)
         gf = amax("encoder.norm.weight")
         elf, nf = gf * sq + amax("encoder.norm.bias"), gf * sq + rown("encoder.norm.bias")
         e_c6 = 3.0 * nf * rown("decoder.conv6.weight")                   # 9 taps: ||patch||_2 <= 3 max ||token||_2
         out["conv6"] = ok(elf, amax("decoder.conv6.weight"))
         out["conv7"] = ok(e_c6, amax("decoder.conv7.weight"))
         self.headroom = min(self.headroom, float(lim / max(worst[0], 1e-30)))
+        self.headroom1 = min(self.headroom1, float(lim / max(worst1[0], 1e-30)))
         return out
 
     def params_changed(self, student: int, rewritten: bool):
@@ -413,13 +459,17 @@ class RangeGuard:
     def summary(self) -> dict:
         """For logs / bench.py: how many sites run on the f32 kernels because their operands could leave fp16's range."""
         self._harvest(wait=False)
-        n = 0
+        n = n0 = 0
         for s in self.safe:
             if s is None:
                 continue
             n += sum(not s[k] for k in ("patch", "conv6", "conv7")) + sum(not b[k] for b in s["blocks"] for k in self.SITES)
-        return {"sites_on_f32": n, "checks": self.checks, "margin": self.margin,
-                "headroom": (None if self.headroom == float("inf") else round(self.headroom, 1))}
+            if FMT1:
+                n0 += int(s["patch"] and not s["patch_f1"]) + sum(b[k] and not b[k + "_f1"] for b in s["blocks"]
+                                                                  for k in ("qkv", "proj", "fc1", "fc2"))
+        return {"sites_on_f32": n, "sites_on_fmt0": n0, "checks": self.checks, "margin": self.margin,
+                "headroom": (None if self.headroom == float("inf") else round(self.headroom, 1)),
+                "headroom_fmt1": (None if self.headroom1 == float("inf") else round(self.headroom1, 1))}
 
 
 
@@ -450,8 +500,8 @@ class StudentParams:
     def mark_grad(self, seg: int):
         self.store.seg_has_grad[self.student][seg] = True
 
-    def w16(self, key: str, rows: int):
-        return self.store.w16(self.student, key, rows)
+    def w16(self, key: str, rows: int, fmt1: Optional[bool] = None):
+        return self.store.w16(self.student, key, rows, fmt1)
 
     def w16T(self, key: str, rows: int):
         return self.store.w16T(self.student, key, rows)
@@ -555,6 +605,8 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
     # Only while every site runs on planes (an f32-routed consumer needs its fp32 input for all rows).
     if save_rows and not (hd == 64 and all(b[k] for b in guard["blocks"] for k in RangeGuard.SITES)):
         save_rows = 0
+    def ea(site_flags, site):             # plane format of the activations that feed `site`'s GEMM (and of its weight planes)
+        return ops.EXP_ACT if (FMT1 and site_flags[site + "_f1"]) else 0
     toks, groups = [], []
     r0 = 0
     for x in xs:
@@ -562,8 +614,9 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         h, w = Himg // cfg.patch, Wimg // cfg.patch
         n = h * w
         if guard["patch"]:
-            rows16 = ops.split16(ops.patch_im2row(x, cfg.patch))
-            patch, _ = ops.linear16(rows16, P.w16("encoder.patch_embed.proj.weight", D), W["encoder.patch_embed.proj.bias"])
+            e = ea(guard, "patch")
+            rows16 = ops.split16(ops.patch_im2row(x, cfg.patch), exp=e)
+            patch, _ = ops.linear16(rows16, P.w16("encoder.patch_embed.proj.weight", D, bool(e)), W["encoder.patch_embed.proj.bias"])
             del rows16
         else:
             patch = ops.linear(ops.patch_im2row(x, cfg.patch), W["encoder.patch_embed.proj.weight"], W["encoder.patch_embed.proj.bias"])
@@ -585,7 +638,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         g = guard["blocks"][i]
         attn16 = hd == 64 and g["attn"]          # q, k, v as planes into the split attention kernel
         ln1, ln1_16, m1, r1 = ops.layernorm_fwd16(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, save,
-                                                  want_f32=save or not g["qkv"], f32_rows=save_rows)
+                                                  want_f32=save or not g["qkv"], f32_rows=save_rows, exp=ea(g, "qkv"))
         lse = None
         # q, k, v stay fp16 planes end to end where their range allows: the qkv GEMM writes them, the split attention kernel
         # reads them and writes the planes the projection GEMM consumes; fp32 copies only where the backward (save) or an
@@ -594,7 +647,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         # out-of-range verdict) and the f32 attention backward of sequences beyond 2 048 tokens
         need_qkv32 = (not attn16) or (save and max(gr[2] for gr in groups) > 2048)
         if g["qkv"]:
-            qkv, qkv16 = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D), W[p + "attn.qkv.bias"],
+            qkv, qkv16 = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D, bool(ln1_16.exp)), W[p + "attn.qkv.bias"],
                                       want_f32=need_qkv32, want16=attn16)
         else:
             qkv = ops.linear(ln1, W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"])
@@ -602,7 +655,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         del ln1_16
         need_att32 = save or not g["proj"]
         att = torch.empty((save_rows or R, D), device=t.device, dtype=torch.float32) if (need_att32 or not attn16) else None
-        att16 = ops.split16_empty(R, D, t.device) if (attn16 and g["proj"]) else None
+        att16 = ops.split16_empty(R, D, t.device, ea(g, "proj")) if (attn16 and g["proj"]) else None
         for (g0, B, N, _, _) in groups:
             if attn16:
                 bf = save_rows // N if save_rows else 0
@@ -612,26 +665,29 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
             else:   # other head dims (the 96-dim test backbone) or q / k / v beyond fp16's range: exact-f32 attention kernel
                 _, lse = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
         if not attn16 and g["proj"]:
-            att16 = ops.split16(att)
+            att16 = ops.split16(att, exp=ea(g, "proj"))
         qkv16_keep = qkv16 if (save and attn16) else None
         del qkv16
         if g["proj"]:
-            x_mid, _ = ops.linear16(att16, P.w16(p + "attn.proj.weight", D), W[p + "attn.proj.bias"], res=t)
+            x_mid, _ = ops.linear16(att16, P.w16(p + "attn.proj.weight", D, bool(att16.exp)), W[p + "attn.proj.bias"], res=t)
         else:
             x_mid = ops.linear(att, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], res=t)
         del att16
         ln2, ln2_16, m2, r2 = ops.layernorm_fwd16(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save,
-                                                  want_f32=save or not g["fc1"], f32_rows=save_rows)
+                                                  want_f32=save or not g["fc1"], f32_rows=save_rows, exp=ea(g, "fc1"))
         pre1 = torch.empty((save_rows or R, D * cfg.mlp_ratio), device=t.device, dtype=torch.float32) if save else None
         if g["fc1"]:
-            h1, h1_16 = ops.linear16(ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio), W[p + "mlp.fc1.bias"], gelu=True,
-                                     store_pre=pre1, want_f32=save or not g["fc2"], want16=g["fc2"], c_rows=save_rows)
+            # the planes of h1 in the format fc2 takes; format 1 planes can only come out of a format 1 GEMM
+            e2 = ea(g, "fc2") if ln2_16.exp else 0
+            h1, h1_16 = ops.linear16(ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio, bool(ln2_16.exp)), W[p + "mlp.fc1.bias"],
+                                     gelu=True, store_pre=pre1, want_f32=save or not g["fc2"], want16=g["fc2"], c_rows=save_rows,
+                                     out_exp=e2)
         else:
             h1 = ops.linear(ln2, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], gelu=True, store_pre=pre1)
-            h1_16 = ops.split16(h1) if g["fc2"] else None
+            h1_16 = ops.split16(h1, exp=ea(g, "fc2")) if g["fc2"] else None
         del ln2_16
         if g["fc2"]:
-            x_out, _ = ops.linear16(h1_16, P.w16(p + "mlp.fc2.weight", D), W[p + "mlp.fc2.bias"], res=x_mid)
+            x_out, _ = ops.linear16(h1_16, P.w16(p + "mlp.fc2.weight", D, bool(h1_16.exp)), W[p + "mlp.fc2.bias"], res=x_mid)
         else:
             x_out = ops.linear(h1, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"], res=x_mid)
         del h1_16

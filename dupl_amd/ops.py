@@ -65,13 +65,16 @@ def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int,
 
 # ------------------------------------------------------------------------------------------ f16x3 split GEMM
 class Split16:
-    """A matrix as two fp16 planes (hi, lo*2048): the operand format of dupl_gemm_f16x3 (csrc/gemm_split.hip).
-    `planes` is one [2, rows, cols] fp16 tensor (plane 0 = hi, plane 1 = lo)."""
-    __slots__ = ("planes", "rows", "cols")
+    """A matrix as two fp16 planes: the operand format of dupl_gemm_f16x3 (csrc/gemm_split.hip).
+    `planes` is one [2, rows, cols] fp16 tensor (plane 0 = hi, plane 1 = lo).
+    exp = 0: format 0, x = hi + lo / 2048 (two accumulator sets in the GEMM).  exp = s > 0: format 1, the planes hold
+    X = x * 2^s as hi + lo with an UNSCALED lo -- all three products share one accumulator (256 x 256 tiles); both operands
+    of a GEMM must be in the same format (csrc/common.h split_f32_u, dupl_gemm16_desc.fmt)."""
+    __slots__ = ("planes", "rows", "cols", "exp")
 
-    def __init__(self, planes: Tensor):
+    def __init__(self, planes: Tensor, exp: int = 0):
         assert planes.dtype == torch.float16 and planes.dim() == 3 and planes.shape[0] == 2 and planes.is_contiguous()
-        self.planes, self.rows, self.cols = planes, planes.shape[1], planes.shape[2]
+        self.planes, self.rows, self.cols, self.exp = planes, planes.shape[1], planes.shape[2], int(exp)
 
     @property
     def hi(self) -> int:
@@ -87,10 +90,11 @@ class Split16:
 
 class Split16View:
     """Row range [r0, r1) of a Split16 (both planes), as an A operand."""
-    __slots__ = ("hi", "lo", "rows", "cols", "base")
+    __slots__ = ("hi", "lo", "rows", "cols", "base", "exp")
 
     def __init__(self, base: Split16, r0: int, r1: int):
         self.base = base
+        self.exp = base.exp
         self.hi = base.hi + 2 * r0 * base.cols
         self.lo = base.lo + 2 * r0 * base.cols
         self.rows, self.cols = r1 - r0, base.cols
@@ -98,22 +102,31 @@ class Split16View:
 
 class W16:
     """Raw operand planes (pointers) of a [rows, cols] matrix living in someone else's buffer (parameter planes)."""
-    __slots__ = ("hi", "lo", "rows", "cols")
+    __slots__ = ("hi", "lo", "rows", "cols", "exp")
 
-    def __init__(self, hi: int, lo: int, rows: int, cols: int):
-        self.hi, self.lo, self.rows, self.cols = hi, lo, rows, cols
-
-
-def split16_empty(rows: int, cols: int, device) -> Split16:
-    return Split16(torch.empty((2, rows, cols), device=device, dtype=torch.float16))
+    def __init__(self, hi: int, lo: int, rows: int, cols: int, exp: int = 0):
+        self.hi, self.lo, self.rows, self.cols, self.exp = hi, lo, rows, cols, int(exp)
 
 
-def split16(x: Tensor, out: Optional[Split16] = None) -> Split16:
-    """fp32 [rows, cols] (contiguous, cols % 4 == 0) -> hi / lo planes."""
+# format 1 scales (powers of two): activations * 2^3, weights * 2^9 -- typical |x| ~ 1 and |w| ~ 0.02 both land near 8 .. 10,
+# where lo = X - hi (~2^-12 X) is a normal fp16; the range guard (engine.RangeGuard) checks bound * 2^exp <= 65504 / margin
+EXP_ACT, EXP_W = 3, 9
+
+
+def split16_empty(rows: int, cols: int, device, exp: int = 0) -> Split16:
+    return Split16(torch.empty((2, rows, cols), device=device, dtype=torch.float16), exp)
+
+
+def split16(x: Tensor, out: Optional[Split16] = None, exp: int = 0) -> Split16:
+    """fp32 [rows, cols] (contiguous, cols % 4 == 0) -> hi / lo planes (format 0, or format 1 of x * 2^exp)."""
     _chk(x)
     rows, cols = x.shape[0], x.numel() // x.shape[0]
-    out = out if out is not None else split16_empty(rows, cols, x.device)
-    L().dupl_split_f16x2(x.data_ptr(), out.hi, out.lo, x.numel(), _stream())
+    out = out if out is not None else split16_empty(rows, cols, x.device, exp)
+    assert out.exp == exp
+    if exp:
+        L().dupl_split_f16x2b(x.data_ptr(), out.hi, out.lo, x.numel(), exp, _stream())
+    else:
+        L().dupl_split_f16x2(x.data_ptr(), out.hi, out.lo, x.numel(), _stream())
     return out
 
 
@@ -237,7 +250,7 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
              res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None,
              want_f32: bool = True, out16: Optional[Split16] = None, want16: bool = False, device=None,
              alpha: Optional[int] = None, accumulate: bool = False, dgelu_of: Optional[Tensor] = None,
-             relumask_of: Optional[Tensor] = None, c_rows: int = 0, amax_for_next: bool = False):
+             relumask_of: Optional[Tensor] = None, c_rows: int = 0, amax_for_next: bool = False, out_exp: int = 0):
     """y = act(alpha * x W^T + bias) (+ res) on the f16x3 split GEMM.  x: Split16 / Split16View [M, K]; W: Split16 [N, K].
     alpha: device pointer of a float (inverse scale of scaled gradient planes).  accumulate: out += alpha * x W^T (weight
     gradients; split-K).  dgelu_of / relumask_of: multiply by gelu'(pre) / (post > 0) (data gradients through an activation).
@@ -254,8 +267,17 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     # c_rows > 0: the fp32 outputs (y, store_pre) exist for the first c_rows rows only (the planes for all M)
     if want_f32 or out is not None:
         y = out if out is not None else torch.empty((c_rows or M, N), device=dev, dtype=torch.float32)
-    y16 = out16 if out16 is not None else (split16_empty(M, N, dev) if want16 else None)
+    y16 = out16 if out16 is not None else (split16_empty(M, N, dev, out_exp) if want16 else None)
     d = _lib.Gemm16Desc()
+    # operand format: both format 0, or both format 1 (then the product carries 2^(xe + we), taken out in the epilogue)
+    xe, we = getattr(x, "exp", 0), getattr(W, "exp", 0)
+    assert (xe > 0) == (we > 0), f"operand planes in different formats (exp {xe} / {we})"
+    if xe:
+        assert not accumulate and not amax_for_next
+        d.fmt, d.post_scale = 1, 2.0 ** -(xe + we)
+    if y16 is not None:
+        assert y16.exp == 0 or xe, "format 1 output planes come from format 1 GEMMs"
+        d.out_exp = y16.exp
     d.A_hi, d.A_lo, d.B_hi, d.B_lo = x.hi, x.lo, W.hi, W.lo
     d.C = _p(y)
     d.C_hi, d.C_lo = (y16.hi, y16.lo) if y16 is not None else (None, None)
@@ -348,20 +370,20 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bool
 
 
 def layernorm_fwd16(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bool = False, want_f32: bool = False,
-                    f32_rows: int = 0):
+                    f32_rows: int = 0, exp: int = 0):
     """LayerNorm whose output goes out as f16x3 operand planes (and as fp32 too when want_f32, e.g. saved for backward).
     f32_rows > 0: the fp32 copy and mean / rstd are produced for the first f32_rows rows only (and have that many rows).
     Returns (y fp32 or None, y16 Split16, mean, rstd)."""
     rows, D = x.shape
     keep = f32_rows or rows
     y = torch.empty((keep, D), device=x.device, dtype=torch.float32) if want_f32 else None
-    y16 = split16_empty(rows, D, x.device)
+    y16 = split16_empty(rows, D, x.device, exp)      # exp > 0: format 1 planes
     mean = rstd = None
     if save:
         mean = torch.empty(keep, device=x.device, dtype=torch.float32)
         rstd = torch.empty(keep, device=x.device, dtype=torch.float32)
-    L().dupl_layernorm_fwd16b(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y), y16.hi, y16.lo, _p(mean), _p(rstd), rows, D,
-                              eps, int(f32_rows), _stream())
+    L().dupl_layernorm_fwd16c(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y), y16.hi, y16.lo, _p(mean), _p(rstd), rows, D,
+                              eps, int(f32_rows), int(exp), _stream())
     return y, y16, mean, rstd
 
 
@@ -411,9 +433,10 @@ def attention_fwd16(qkv16, B: int, N: int, H: int, hd: int, scale: float, need_l
     lse = torch.empty((bf, H, N), device=dev, dtype=torch.float32) if need_lse else None
     if out is not None:
         assert out.shape == (bf * N, H * hd) and out.is_contiguous()
-    L().dupl_attention_fwd16b(qkv16.hi, qkv16.lo, vt.data_ptr(), vt.data_ptr() + 2 * vt.shape[1], _p(out),
+    assert getattr(qkv16, "exp", 0) == 0, "the split attention reads format 0 planes"
+    L().dupl_attention_fwd16c(qkv16.hi, qkv16.lo, vt.data_ptr(), vt.data_ptr() + 2 * vt.shape[1], _p(out),
                               out16.hi if out16 is not None else None, out16.lo if out16 is not None else None, _p(lse),
-                              B, N, H, hd, npad, float(scale), bf, _stream())
+                              B, N, H, hd, npad, float(scale), bf, out16.exp if out16 is not None else 0, _stream())
     return lse
 
 

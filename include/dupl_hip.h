@@ -90,6 +90,10 @@ typedef struct dupl_gemm16_desc {
                                              back-propagated); 0 = all rows */
     const float* alpha_dev;               /* device scalar multiplied into A.B^T before the epilogue (inverse operand scales of
                                              scaled gradient planes, dupl_split_prepare), or NULL (= 1) */
+    int32_t fmt;                          /* operand plane format of A and B: 0 = lo planes scaled by 2048 (two accumulator sets), 1 = planes of
+                                             x * 2^s with unscaled lo (dupl_split_f16x2b: one accumulator set, 256 x 256 tiles) */
+    int32_t out_exp;                      /* C_hi / C_lo: 0 = format 0; s > 0 = format 1 planes of C * 2^s */
+    float post_scale;                     /* multiplied into A.B^T together with alpha (2^-(sA + sB) for format 1 operands); 0 = 1 */
     void* amax_out;                       /* NULL, or the amax word of a scale slot (dupl_split_prepare3, amax_mode 1): the kernel
                                              raises it (atomic max on the bits) to max |C| over the M x N result, so that the
                                              split of C needs no pass of its own.  Not with DUPL_GEMM_ACCUM or c_rows. */
@@ -97,6 +101,8 @@ typedef struct dupl_gemm16_desc {
 int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream);
 /* the operand split of the GEMM above: n fp32 values (n % 4 == 0) -> hi / lo fp16 planes (no reference counterpart) */
 int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, dupl_stream_t stream);
+/* the same into format 1 planes of x * 2^scale_exp (dupl_gemm16_desc.fmt) */
+int dupl_split_f16x2b(const float* x, void* hi, void* lo, int64_t n, int32_t scale_exp, dupl_stream_t stream);
 /* tuning knob: row-tiles per group of the block order of dupl_gemm_f16x3 */
 int dupl_set_gemm16_group(int32_t gm);
 /* operand preparation for the backward split GEMMs (csrc/split_prep.hip): x [R][ld] fp32 (C columns) -> row-major planes
@@ -173,6 +179,9 @@ int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, 
 /* the same with the fp32 copy y (and mean / rstd) written for the first f32_rows rows only (0 = all): y then has f32_rows rows */
 int dupl_layernorm_fwd16b(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
                           float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows, dupl_stream_t s);
+/* the same with the planes in format 1 (y * 2^plane_exp, unscaled lo: dupl_gemm16_desc.fmt) when plane_exp > 0 */
+int dupl_layernorm_fwd16c(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
+                          float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows, int32_t plane_exp, dupl_stream_t s);
 /* LayerNorm backward (autograd of vit.py:157,159,323), optionally fused with the residual-stream gradient add */
 int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
@@ -219,6 +228,9 @@ int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, vo
 int dupl_attention_fwd16b(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi, void* out_lo,
                           float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, int32_t B_f32,
                           dupl_stream_t s);
+/* the same with the output planes in format 1 (out * 2^out_exp, unscaled lo) when out_exp > 0 */
+int dupl_attention_fwd16c(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi, void* out_lo,
+                          float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s);
 /* backward (what autograd derives for vit.py:123-135): dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N]. */
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,

@@ -910,6 +910,9 @@ def test_range_guard_routes_out_of_range_operands_to_f32(dev):
     pp["branch1.encoder.blocks.3.mlp.fc1.weight"][17, 40] = 1.0e5
     pp["branch1.encoder.blocks.5.norm1.weight"][100] = 3.0e3
     pp["branch1.encoder.blocks.7.attn.qkv.weight"][1000] *= 3.0e3
+    # (d) gamma 300 in block 9's norm2: inside fp16's range (bound 8.3e3) but not at the format 1 scale (x 8): fc1 / fc2 of that
+    # block must fall back to format 0 planes (two accumulator sets), NOT to f32
+    pp["branch1.encoder.blocks.9.norm2.weight"][5] = 300.0
     x = O.hash_normal("rgx", (2, 3, 224, 224), std=1.0, seed=4)
 
     p64 = {k: v.double().requires_grad_(True) for k, v in O.sub_params(pp, "branch1.").items()}
@@ -950,6 +953,11 @@ def test_range_guard_routes_out_of_range_operands_to_f32(dev):
         assert (3, "fc1") in off and (3, "fc2") in off and (5, "qkv") in off and (7, "attn") in off and (7, "proj") in off
         assert (7, "qkv") not in off or True
         assert all(sites["blocks"][i][k] for i in (0, 1, 2, 4, 6, 8, 9, 10, 11) for k in engine.RangeGuard.SITES), "untouched blocks stay on f16x3"
+        if engine.FMT1:
+            b9 = sites["blocks"][9]
+            assert b9["fc1"] and not b9["fc1_f1"] and b9["qkv_f1"], b9
+            assert all(sites["blocks"][i][k + "_f1"] for i in (0, 1, 2, 4, 6, 8, 10, 11) for k in ("qkv", "proj", "fc1", "fc2"))
+            assert model.flat_storage.guard.summary()["sites_on_fmt0"] >= 1
         assert all(model.flat_storage.guard.sites(1)["blocks"][i][k] for i in range(12) for k in engine.RangeGuard.SITES), "student 2 is untouched"
         engine.set_gemm_mode("f32")
         e32 = run()
@@ -957,7 +965,8 @@ def test_range_guard_routes_out_of_range_operands_to_f32(dev):
         engine.set_gemm_mode("f16x3")
         g = model.flat_storage.guard
         real = g.safe[0]
-        g.safe[0] = {"patch": True, "conv6": True, "conv7": True, "blocks": [{k: True for k in engine.RangeGuard.SITES} for _ in range(12)]}
+        every = list(engine.RangeGuard.SITES) + [k + "_f1" for k in ("qkv", "proj", "fc1", "fc2")]
+        g.safe[0] = {"patch": True, "patch_f1": True, "conv6": True, "conv7": True, "blocks": [{k: True for k in every} for _ in range(12)]}
         bad = run()
         g.safe[0] = real
     finally:

@@ -1117,3 +1117,86 @@ def test_scaled_operand_alpha_is_guarded(dev):
         ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False)
     with pytest.raises(AssertionError, match="reused"):
         ops.linear16(dy16, W16, alpha=alpha)
+
+
+# ------------------------------------------------------------------------------------------ format 1 operand planes (single accumulator)
+@pytest.mark.parametrize("tile", [0, 8, 12])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (1570, 768, 768), (129, 128, 32), (6280, 3072, 768), (3140, 768, 3072), (15696, 768, 768)])
+def test_gemm_f16x3_format1_is_fp32_equivalent(dev, M, N, K, tile):
+    """Format 1 of the operand planes (csrc/common.h split_f32_u: X = x * 2^s as hi + lo with an UNSCALED lo; activations s = 3,
+    weights s = 9) through the single-accumulator tiles (8: 256 x 256, 12: 256 x 128, 0: the launcher's choice): the same bar
+    as format 0 -- at least as close to fp64 as the exact-f32 MFMA kernel (2x its error + 1e-7) -- with bias / GELU / residual /
+    stored pre-activation epilogues, fp32 rows limited by c_rows, and the result planes in either format; plus the format's
+    own reconstruction error, which is relative to the tensor's scale (absolute 2^-25 * 2^-s below |x| ~ 2^-5), and operands of
+    small overall scale (0.05: every lo is a subnormal's neighbour)."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + tile)
+    x = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    xs, Ws = ops.split16(x, exp=ops.EXP_ACT), ops.split16(W, exp=ops.EXP_W)
+    rec = (xs.planes[0].float() + xs.planes[1].float()) / 2.0 ** ops.EXP_ACT
+    assert float((rec - x).abs().max()) <= 2.0 ** -22 * float(x.abs().max())
+    assert float(((rec - x).abs() / x.abs().clamp_min(2.0 ** -5)).max()) <= 2.0 ** -21
+    ref = x.double() @ W.double().t() + b.double()
+    want = F.gelu(ref) + res.double()
+    sc = float(want.abs().max())
+    ops.L().dupl_set_gemm16_tile(tile)
+    try:
+        pre = torch.empty(M, N, device=dev)
+        y, y16 = ops.linear16(xs, Ws, b, gelu=True, res=res, store_pre=pre, want16=True, out_exp=ops.EXP_ACT)
+        _, y16f0 = ops.linear16(xs, Ws, b, gelu=True, res=res, want_f32=False, want16=True)
+        crow = max(1, M // 3)
+        yc, y16c = ops.linear16(xs, Ws, b, gelu=True, want16=True, out_exp=ops.EXP_ACT, c_rows=crow)
+        yfull, _ = ops.linear16(xs, Ws, b, gelu=True)
+        # small-scale A operand (an attention output of scale 0.05)
+        xsm = x * 0.05
+        ysm, _ = ops.linear16(ops.split16(xsm, exp=ops.EXP_ACT), Ws, b)
+    finally:
+        ops.L().dupl_set_gemm16_tile(0)
+    y32 = ops.linear(x, W, b, gelu=True, res=res)
+    e16, e32 = float((y.double() - want).abs().max()) / sc, float((y32.double() - want).abs().max()) / sc
+    print(f"{M}x{N}x{K} tile {tile}: format 1 {e16:.2e}  f32 {e32:.2e}")
+    assert e16 <= 2.0 * e32 + 1e-7
+    assert float((pre.double() - ref).abs().max()) / float(ref.abs().max()) <= 2.0 * e32 + 1e-7
+    assert y16.exp == ops.EXP_ACT and y16f0.exp == 0
+    rec1 = (y16.planes[0].float() + y16.planes[1].float()) / 2.0 ** ops.EXP_ACT
+    rec0 = y16f0.planes[0].float() + y16f0.planes[1].float() / 2048.0
+    assert float((rec1 - y).abs().max()) <= 2.0 ** -21 * sc and float((rec0 - y).abs().max()) <= 2.0 ** -21 * sc
+    assert yc.shape[0] == crow and torch.equal(yc, yfull[:crow])
+    assert float(((y16c.planes[0].float() + y16c.planes[1].float()) / 8.0 - yfull).abs().max()) <= 2.0 ** -21 * float(yfull.abs().max())
+    refs = xsm.double() @ W.double().t() + b.double()
+    y32s = ops.linear(xsm, W, b)
+    scs = float((xsm.double() @ W.double().t()).abs().max())
+    es, es32 = float((ysm.double() - refs).abs().max()) / scs, float((y32s.double() - refs).abs().max()) / scs
+    print(f"   A scaled by 0.05: format 1 {es:.2e}  f32 {es32:.2e}")
+    assert es <= 2.0 * es32 + 2e-7
+    # mixing formats is refused
+    with pytest.raises(AssertionError):
+        ops.linear16(xs, ops.split16(W), b)
+
+
+def test_format1_planes_from_layernorm_and_attention(dev):
+    """dupl_layernorm_fwd16c / dupl_attention_fwd16c write their output planes in format 1 on request: the same values as the
+    fp32 output, to the format's precision."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(785, 768, generator=g) * 3).to(dev)
+    gamma = (1 + 0.3 * torch.randn(768, generator=g)).to(dev)
+    beta = (0.2 * torch.randn(768, generator=g)).to(dev)
+    y, y16, _, _ = ops.layernorm_fwd16(x, gamma, beta, 1e-6, want_f32=True, exp=ops.EXP_ACT)
+    assert y16.exp == ops.EXP_ACT
+    rec = (y16.planes[0].float() + y16.planes[1].float()) / 8.0
+    assert float((rec - y).abs().max()) <= 2.0 ** -22 * float(y.abs().max())
+    B, N, H, hd = 2, 197, 12, 64
+    qkv = torch.randn(B * N, 3 * H * hd, generator=g).to(dev)
+    qkv16 = ops.split16(qkv)
+    out = torch.empty(B * N, H * hd, device=dev)
+    o1 = ops.split16_empty(B * N, H * hd, dev, ops.EXP_ACT)
+    o0 = ops.split16_empty(B * N, H * hd, dev)
+    ops.attention_fwd16(qkv16, B, N, H, hd, hd ** -0.5, out=out, out16=o1)
+    ops.attention_fwd16(qkv16, B, N, H, hd, hd ** -0.5, out16=o0)
+    sc = float(out.abs().max())
+    assert float(((o1.planes[0].float() + o1.planes[1].float()) / 8.0 - out).abs().max()) <= 2.0 ** -21 * sc
+    assert float((o0.planes[0].float() + o0.planes[1].float() / 2048.0 - out).abs().max()) <= 2.0 ** -21 * sc

@@ -55,9 +55,9 @@ __global__ void maxdiff_kernel(const float* a, const float* b, long n, float* ou
     atomicMax((int*)out, __float_as_int(d));
     atomicMax((int*)out + 1, __float_as_int(m));
 }
-__global__ void planes_to_f32(const __half* hi, const __half* lo, float* x, long n) {
+__global__ void planes_to_f32(const __half* hi, const __half* lo, float* x, long n, float lo_scale, float scale) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        x[i] = __half2float(hi[i]) + __half2float(lo[i]) * (1.f / 2048.f);
+        x[i] = (__half2float(hi[i]) + __half2float(lo[i]) * lo_scale) * scale;
 }
 // shader clock (s_memtime) and 100 MHz wall clock per XCD (the counters are per-XCD): slot xcc_id of out[8][2]
 __global__ void clock_probe(long long* out) {
@@ -115,7 +115,7 @@ static std::vector<int> parse_ints(const char* s) {
 int main(int argc, char** argv) {
     std::vector<int> tiles = {5, 6, 7};
     int iters = 20, epi = 0, probe_iters = 40000, window_ms = 0;
-    bool check_only = false, two = false, dbg = false, probe = false;
+    bool check_only = false, two = false, dbg = false, probe = false, f1 = false;   // f1: format 1 operand planes (single accumulator)
     std::string sel = "fwd";
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-t") && i + 1 < argc) tiles = parse_ints(argv[++i]);
@@ -128,6 +128,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "-g") && i + 1 < argc) dupl_set_gemm16_group(atoi(argv[++i]));
         else if (!strcmp(argv[i], "-p")) probe = true;
         else if (!strcmp(argv[i], "-P") && i + 1 < argc) { probe = true; probe_iters = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "-f")) f1 = true;     // format 1 planes: A * 2^3, B * 2^9, unscaled lo; tiles 8 (256 x 256) / 12 (256 x 128)
         else if (!strcmp(argv[i], "-d")) dbg = true;   // ablation build with G16_ABL & 16: per-block s_memtime stamps through aux
     }
     std::vector<Shape> shapes;
@@ -203,7 +204,8 @@ int main(int argc, char** argv) {
             fill_kernel<<<1024, 256>>>(A[s], nA, 11 + s, 1.0f);
             fill_kernel<<<1024, 256>>>(B[s], nB, 23 + s, 0.05f);
             fill_kernel<<<1024, 256>>>(res[s], nC, 37 + s, 1.0f);
-            if (dupl_split_f16x2(A[s], Ah[s], Ah[s] + nA, nA, nullptr) || dupl_split_f16x2(B[s], Bh[s], Bh[s] + nB, nB, nullptr)) {
+            if (f1 ? (dupl_split_f16x2b(A[s], Ah[s], Ah[s] + nA, nA, 3, nullptr) || dupl_split_f16x2b(B[s], Bh[s], Bh[s] + nB, nB, 9, nullptr))
+                   : (dupl_split_f16x2(A[s], Ah[s], Ah[s] + nA, nA, nullptr) || dupl_split_f16x2(B[s], Bh[s], Bh[s] + nB, nB, nullptr))) {
                 fprintf(stderr, "split failed (n %% 4?)\n");
                 return 2;
             }
@@ -224,6 +226,11 @@ int main(int argc, char** argv) {
                 case 2: d.C_hi = Ch[s]; d.C_lo = Ch[s] + nC; d.bias = bias; d.aux = aux[s]; d.flags = DUPL_GEMM_GELU | DUPL_GEMM_STORE_PRE; break;
                 case 3: d.C = C[s]; d.bias = bias; d.res = res[s]; break;
                 case 4: d.C = C[s]; d.flags = DUPL_GEMM_ACCUM; break;
+            }
+            if (f1) {
+                d.fmt = 1;
+                d.post_scale = 1.f / 4096.f;
+                if (d.C_hi) d.out_exp = 3;
             }
             return d;
         };
@@ -248,7 +255,7 @@ int main(int argc, char** argv) {
             if (rc) { printf("  t%d rc=%d", tile, rc); continue; }
             const float* got = C[0];
             if (epi == 1 || epi == 2) {
-                planes_to_f32<<<1024, 256, 0, st[0]>>>(Ch[0], Ch[0] + nC, C[0], nC);
+                planes_to_f32<<<1024, 256, 0, st[0]>>>(Ch[0], Ch[0] + nC, C[0], nC, f1 ? 1.f : 1.f / 2048.f, f1 ? 0.125f : 1.f);
             }
             CK(hipMemsetAsync(d_stat, 0, 8, st[0]));
             maxdiff_kernel<<<1024, 256, 0, st[0]>>>(got, Cref, nC, d_stat);
