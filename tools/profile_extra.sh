@@ -19,8 +19,10 @@ B=tools/gemm16_bench
   W=3072x768x3168,768x3072x3168,2304x768x3168,768x768x3168,3072x768x1600,768x3072x1600,2304x768x1600,768x768x1600
   echo "# epilogue 4 (ACCUM: the weight gradients at 4 / 2 img per GPU; 3 / 5: split-K grids, 11: stream-K form of the persistent kernel), one stream"; $B -s $W -t 3,5,11,0 -w 150 -e 4;
   echo "# the same, two streams"; $B -s $W -t 3,5,11,0 -w 150 -2 -e 4;
-  echo "# single-accumulator 256 x 256 timing probes (tiles 8 / 9; results invalid by construction: lo planes are scaled), two streams";
-  $B -s 15696x3072x768,15696x768x3072,6280x3072x768,3140x3072x768 -t 10,8,9 -w 150 -2; } > $OUT/${TAG}_gemm16_tiles.txt 2>&1
+  echo "# format 1 operand planes (-f: A * 2^3, B * 2^9, unscaled lo; one accumulator set): 8 = 256 x 256, 12 = 256 x 128, 14 = persistent 256 x 128, 0 = the launcher's choice; two streams";
+  $B -s fwd -t 8,12,14,0 -w 150 -2 -f; $B -s 1576x3072x768,1576x768x3072,1576x768x768 -t 8,12,14,0 -w 150 -2 -f;
+  echo "# the same, one stream"; $B -s fwd -t 8,12,0 -w 150 -f;
+  echo "# format 1, epilogues 1 / 2 / 3 (planes out in format 1), two streams"; for e in 1 2 3; do $B -s fwd -t 8,12 -w 150 -2 -f -e $e; done; } > $OUT/${TAG}_gemm16_tiles.txt 2>&1
 { echo "# LD_LIBRARY_PATH=tools/abl/16 (G16_ABL=16: s_memtime stamps of wave 0 per block): prologue / k-loop / epilogue cycles";
   LD_LIBRARY_PATH=tools/abl/16 $B -s 15696x3072x768,15696x768x3072,6280x3072x768,3140x3072x768 -t 6,7 -d -p; } > $OUT/${TAG}_gemm16_phases.txt 2>&1
 S=15696x3072x768
