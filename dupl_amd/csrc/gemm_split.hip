@@ -1154,7 +1154,7 @@ extern "C" int dupl_set_gemm16_persist_blocks(int32_t n) {
 }
 
 extern "C" int dupl_set_gemm16_tile(int32_t t) {
-    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 9 && t != 10 && t != 11 && t != 12 && t != 14) return DUPL_ERR_ARG;
+    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 10 && t != 11 && t != 12 && t != 14) return DUPL_ERR_ARG;
     g16_tile = t;
     return DUPL_OK;
 }
@@ -1245,10 +1245,8 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2>), dim3((unsigned)grid), dim3(512), 0, s, *d, g16_group_ring);
         return dupl_launch_status();
     }
-    // 8 / 9: experimental single-accumulator 256 x 256 forms (need UNSCALED lo planes: timing probes only, tools/gemm16_bench)
-    if (tile == 8) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), blocks(256, 256), dim3(512), 0, s, *d, g16_group_ring);
-    else if (tile == 9) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 4, 2, 2, 1, 2, true>), blocks(256, 256), dim3(256), 0, s, *d, g16_group_ring);
-    else if (tile == 6) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
+    if (tile == 8 || tile == 9 || tile == 12 || tile == 14) tile = 5;      // single-accumulator tiles: format 1 operands only (above)
+    if (tile == 6) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
     else if (tile == 7) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 2, 1>), blocks(256, 128), dim3(256), 0, s, *d, g16_group_ring);
     else if (tile == 3) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 2, 2>), blocks(128, 64), dim3(256), 0, s, *d, g16_group_m);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 4, 4>), blocks(128, 128), dim3(512), 0, s, *d, g16_group_m);

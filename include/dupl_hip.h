@@ -135,9 +135,9 @@ typedef struct dupl_split_item {
     int32_t ld, R, C, Rp;
 } dupl_split_item;
 int dupl_split_prepare_multi(const dupl_split_item* items, int32_t n, dupl_stream_t stream);
-/* tuning knob: block tile of dupl_gemm_f16x3 (0 heuristic, 3: 128x64 on 4 waves, 5: 128x128 on 8 waves, 6 / 7: 256x128 ring
- * kernel on 8 / 4 waves; 8 / 9: single-accumulator 256x256 timing probes, results only valid for unscaled lo planes;
- * 10: persistent 256x128 ring kernel; 11: its stream-K form for DUPL_GEMM_ACCUM) */
+/* tuning knob: block tile of dupl_gemm_f16x3: 0 = heuristic.  Format 0 operands: 3: 128x64 on 4 waves, 5: 128x128 on 8 waves,
+ * 6 / 7: 256x128 ring kernel on 8 / 4 waves, 10: its persistent form, 11: the stream-K form of that for DUPL_GEMM_ACCUM.
+ * Format 1 operands (one accumulator set): 8: 256x256 on 8 waves, 12: 256x128, 14: persistent 256x128. */
 int dupl_set_gemm16_tile(int32_t t);
 /* tuning knob: blocks of the persistent kernels (tiles 10 / 11), a multiple of 8; 0 = auto (256 = one per CU when one stream
  * issues GEMMs, 192 under dupl_set_gemm16_concurrency(2)) */
