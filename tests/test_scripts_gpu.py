@@ -246,7 +246,7 @@ def test_bench_contract_line(dev):
     # a 1-GPU line carries the exchange fields too (no exchange: zeros), N = 1 runs BASELINE configs[1]
     cm = d["comm"]
     assert cm["world"] == 1 and cm["backend"] == "none" and cm["allreduce_bytes"] == 0 and cm["comm_exposed_ms"] == 0.0
-    assert cm["grad_bytes_per_rank"] > 7.0e8 and d["weak_4img_per_gpu"] is None
+    assert cm["grad_bytes_per_rank"] > 7.0e8 and d["listed_config"] is None
     assert d["config"]["baseline_config"] == "configs[1]" and d["config"]["img_per_gpu"] == 4
 
 
@@ -367,10 +367,10 @@ def test_bench_multi_rank_control_flow(dev):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    # N = 2 defaults to BASELINE configs[2]: VOC, 2 img/GPU (global batch 4)
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["img_per_gpu"] == 2
-    assert d["config"]["baseline_config"] == "configs[2]" and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
-    assert abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) < 0.05 * d["value"] and d["cpu_baseline"] is None
+    # every N steps the N = 1 workload (configs[1]: VOC, 4 img/GPU) on each rank: `value` is a point of the weak-scaling curve
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["img_per_gpu"] == 4
+    assert d["config"]["baseline_config"].startswith("configs[1]") and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 0.05 * d["value"] and d["cpu_baseline"] is None
     # the line explains its own exchange: backend, world, bytes all-reduced per step (= the trainable gradient range of
     # both students), how many calls, and the communication time the overlap left exposed
     cm = d["comm"]
@@ -378,10 +378,10 @@ def test_bench_multi_rank_control_flow(dev):
     assert cm["allreduce_calls"] >= 16 and cm["comm_exposed_ms"] >= 0.0
     # the run validates its own exchange: bit-identical parameter buffers on all ranks after the steps, world == --gpus
     assert cm["params_identical_on_all_ranks"] is True and cm["world_matches_gpus"] is True and len(cm["param_checksum"]) == 2
-    # second field: the N = 1 workload (VOC, 4 img/GPU) on both ranks = the weak-scaling point
-    w4 = d["weak_4img_per_gpu"]
-    assert w4 is not None and w4["comm"]["world"] == 2 and "4 img/GPU" in w4["workload"]
-    assert abs(w4["value"] - 8 * 1000.0 / w4["ms_per_step"]) < 0.05 * w4["value"]
+    # second field: the configuration BASELINE.json lists for N = 2 (configs[2]: VOC, global batch 4 = 2 img/GPU)
+    lc = d["listed_config"]
+    assert lc is not None and lc["comm"]["world"] == 2 and lc["baseline_config"] == "configs[2]" and lc["img_per_gpu"] == 2
+    assert "2 img/GPU" in lc["workload"] and abs(lc["value"] - 4 * 1000.0 / lc["ms_per_step"]) < 0.05 * lc["value"]
 
 
 def test_train_loop_with_external_loaders(dev, tmp_path):
