@@ -402,18 +402,27 @@ class RangeGuard:
         def rown(k):
             return v[ix[k], 1]
 
-        # format 1 planes hold x * 2^EXP_ACT / w * 2^EXP_W: "<site>_f1" says whether the site's operands also fit at that scale;
-        # a site that is fp16-safe but not at the format 1 scale runs on format 0 planes (two accumulator sets), not on f32
-        sa, sw = 2.0 ** ops.EXP_ACT, 2.0 ** ops.EXP_W
+        # format 1 planes hold x * 2^e / w * 2^EXP_W: "<site>_f1" is the largest activation exponent e <= EXP_ACT at which the
+        # site's operands still fit (0: none -- a site that is fp16-safe but not at any format 1 scale runs on format 0 planes,
+        # two accumulator sets, not on f32).  A smaller e only moves the point below which an element's lo is a subnormal
+        # (|x| < 2^(-2 - e)) up -- for operands whose bound is that large, still far below their typical size.
+        sw = 2.0 ** ops.EXP_W
         worst1 = [0.0]
 
-        def ok1(*bounds):
-            b = max(bounds)
-            worst1[0] = max(worst1[0], b)
-            return bool(FMT1 and b <= lim)
+        def exp1(ea_, ew_):
+            if not FMT1 or not (ew_ * sw <= lim):
+                worst1[0] = max(worst1[0], ew_ * sw if FMT1 else 0.0)
+                return 0
+            for e in range(ops.EXP_ACT, 0, -1):
+                if ea_ * 2.0 ** e <= lim:
+                    worst1[0] = max(worst1[0], ea_ * 2.0 ** e, ew_ * sw)
+                    return e
+            worst1[0] = max(worst1[0], ea_ * 2.0)
+            return 0
 
         wp = amax("encoder.patch_embed.proj.weight")
-        out = {"patch": ok(wp), "patch_f1": ok1(3.0 * sa, wp * sw), "blocks": []}
+        out = {"patch": ok(wp), "blocks": []}
+        out["patch_f1"] = exp1(3.0, wp) if out["patch"] else 0
         for i in range(cfg.depth):
             p = f"encoder.blocks.{i}."
             g1, g2 = amax(p + "norm1.weight"), amax(p + "norm2.weight")
@@ -424,9 +433,9 @@ class RangeGuard:
             ops_ = {"qkv": (el1, amax(p + "attn.qkv.weight")), "proj": (e_qkv, amax(p + "attn.proj.weight")),
                     "fc1": (el2, amax(p + "mlp.fc1.weight")), "fc2": (e_h, amax(p + "mlp.fc2.weight"))}
             blk = {"attn": ok(e_qkv)}
-            for site, (ea, ew) in ops_.items():
-                blk[site] = ok(ea, ew)
-                blk[site + "_f1"] = blk[site] and ok1(ea * sa, ew * sw)
+            for site, (ea_, ew_) in ops_.items():
+                blk[site] = ok(ea_, ew_)
+                blk[site + "_f1"] = exp1(ea_, ew_) if blk[site] else 0
             out["blocks"].append(blk)
         gf = amax("encoder.norm.weight")
         elf, nf = gf * sq + amax("encoder.norm.bias"), gf * sq + rown("encoder.norm.bias")
@@ -605,8 +614,8 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
     # Only while every site runs on planes (an f32-routed consumer needs its fp32 input for all rows).
     if save_rows and not (hd == 64 and all(b[k] for b in guard["blocks"] for k in RangeGuard.SITES)):
         save_rows = 0
-    def ea(site_flags, site):             # plane format of the activations that feed `site`'s GEMM (and of its weight planes)
-        return ops.EXP_ACT if (FMT1 and site_flags[site + "_f1"]) else 0
+    def ea(site_flags, site):             # plane format (format 1 exponent, 0 = format 0) of the activations that feed `site`'s GEMM
+        return int(site_flags[site + "_f1"]) if FMT1 else 0
     toks, groups = [], []
     r0 = 0
     for x in xs:

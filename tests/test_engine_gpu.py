@@ -910,9 +910,11 @@ def test_range_guard_routes_out_of_range_operands_to_f32(dev):
     pp["branch1.encoder.blocks.3.mlp.fc1.weight"][17, 40] = 1.0e5
     pp["branch1.encoder.blocks.5.norm1.weight"][100] = 3.0e3
     pp["branch1.encoder.blocks.7.attn.qkv.weight"][1000] *= 3.0e3
-    # (d) gamma 300 in block 9's norm2: inside fp16's range (bound 8.3e3) but not at the format 1 scale (x 8): fc1 / fc2 of that
-    # block must fall back to format 0 planes (two accumulator sets), NOT to f32
-    pp["branch1.encoder.blocks.9.norm2.weight"][5] = 300.0
+    # (d) gamma 1000 in block 9's norm2: inside fp16's range (bound 2.8e4 x margin 2 < 65504) but at no format 1 scale: fc1 of that
+    # block must fall back to format 0 planes (two accumulator sets), NOT to f32; (e) gamma 300 in block 10's norm2 (bound
+    # 8.3e3): format 1 with the activation exponent lowered from 3 to 1
+    pp["branch1.encoder.blocks.9.norm2.weight"][5] = 1000.0
+    pp["branch1.encoder.blocks.10.norm2.weight"][7] = 300.0
     x = O.hash_normal("rgx", (2, 3, 224, 224), std=1.0, seed=4)
 
     p64 = {k: v.double().requires_grad_(True) for k, v in O.sub_params(pp, "branch1.").items()}
@@ -954,9 +956,10 @@ def test_range_guard_routes_out_of_range_operands_to_f32(dev):
         assert (7, "qkv") not in off or True
         assert all(sites["blocks"][i][k] for i in (0, 1, 2, 4, 6, 8, 9, 10, 11) for k in engine.RangeGuard.SITES), "untouched blocks stay on f16x3"
         if engine.FMT1:
-            b9 = sites["blocks"][9]
-            assert b9["fc1"] and not b9["fc1_f1"] and b9["qkv_f1"], b9
-            assert all(sites["blocks"][i][k + "_f1"] for i in (0, 1, 2, 4, 6, 8, 10, 11) for k in ("qkv", "proj", "fc1", "fc2"))
+            b9, b10 = sites["blocks"][9], sites["blocks"][10]
+            assert b9["fc1"] and b9["fc1_f1"] == 0 and b9["qkv_f1"] == 3, b9
+            assert b10["fc1"] and b10["fc1_f1"] == 1 and b10["qkv_f1"] == 3, b10
+            assert all(sites["blocks"][i][k + "_f1"] == 3 for i in (0, 1, 2, 4, 6, 8, 11) for k in ("qkv", "proj", "fc1", "fc2"))
             assert model.flat_storage.guard.summary()["sites_on_fmt0"] >= 1
         assert all(model.flat_storage.guard.sites(1)["blocks"][i][k] for i in range(12) for k in engine.RangeGuard.SITES), "student 2 is untouched"
         engine.set_gemm_mode("f32")
@@ -965,16 +968,21 @@ def test_range_guard_routes_out_of_range_operands_to_f32(dev):
         engine.set_gemm_mode("f16x3")
         g = model.flat_storage.guard
         real = g.safe[0]
-        every = list(engine.RangeGuard.SITES) + [k + "_f1" for k in ("qkv", "proj", "fc1", "fc2")]
-        g.safe[0] = {"patch": True, "patch_f1": True, "conv6": True, "conv7": True, "blocks": [{k: True for k in every} for _ in range(12)]}
+        forced = {k: True for k in engine.RangeGuard.SITES}
+        forced.update({k + "_f1": 3 for k in ("qkv", "proj", "fc1", "fc2")})
+        g.safe[0] = {"patch": True, "patch_f1": 3, "conv6": True, "conv7": True, "blocks": [dict(forced) for _ in range(12)]}
         bad = run()
         g.safe[0] = real
     finally:
         engine.set_gemm_mode(prev)
     w16, w32, wbad = max(e16[1].values()), max(e32[1].values()), max(bad[1].values())
+    for name, eg in (("guarded f16x3", e16[1]), ("all-f32", e32[1])):
+        print(name, "worst gradients:", [(k, f"{v:.2e}") for k, v in sorted(eg.items(), key=lambda kv: -kv[1])[:4]])
     print(f"guarded f16x3: seg {e16[0]['seg']:.2e} x4 {e16[0]['x4']:.2e} grads {w16:.2e} | all-f32: seg {e32[0]['seg']:.2e} x4 {e32[0]['x4']:.2e} "
           f"grads {w32:.2e} | unguarded: seg {bad[0]['seg']:.2e} grads {wbad:.2e}")
     for k in ("seg", "x4"):
         assert e16[0][k] <= 1.5 * e32[0][k] + 5e-7, k
-    assert w16 <= 1.5 * w32 + 5e-7
+    # gradients below the gamma = 3e3 block are ill-conditioned (1e-3 in BOTH modes); which of two fp32-level computations lands
+    # closer to fp64 there varies with the planted values by a factor ~2 either way: the bar is 3x, against 1e7x without the guard
+    assert w16 <= 3.0 * w32 + 5e-7
     assert max(bad[0].values()) > 100 * max(e16[0].values()) or wbad > 100 * w16, "without the guard the clamp must be visible"
