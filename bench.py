@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--n-iter", type=int, default=None, help="iteration index the step pretends to be (default: phase B)")
     ap.add_argument("--no-listed", "--no-weak4", dest="no_listed", action="store_true",
                     help="N > 1: skip the second measurement (the configuration BASELINE.json lists for this N)")
+    ap.add_argument("--no-second", action="store_true",
+                    help="N = 1: skip the second measurement (the metric's other configuration, COCO 8 img/GPU)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--cpu-batch", type=int, default=1, help="images per CPU-oracle step (stated in the JSON)")
@@ -79,7 +81,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the second measurement of the same workload on the exact-f32 MFMA kernels (f16x3 runs only)")
-    ap.add_argument("--pmc-profile", default=os.environ.get("DUPL_PMC_PROFILE", "profiles/r03_final_pmc_hbm.txt"),
+    ap.add_argument("--pmc-profile", default=os.environ.get("DUPL_PMC_PROFILE", "profiles/r04_final_pmc_hbm.txt"),
                     help="PMC summary (tools/profile_round.sh) roofline.traffic is read from; ignored (traffic = null) "
                          "unless its '# csrc_sha256:' header matches the kernel sources of THIS build")
     ap.add_argument("--no-share-encoder", action="store_true",
@@ -220,12 +222,28 @@ class GemmTimer:
     forward Linear maps to: dupl_gemm_f16x3 (f16x3 mode) or the NT instantiation of dupl_gemm_f32 (f32 mode) -- on the
     stream it is launched on, plus its algorithmic FLOPs (2*M*N*K per launch)."""
 
+    FAMILIES = ("fwd_f1", "fwd_f0", "dgrad", "wgrad", "attention_fwd", "attention_bwd")
+
     def __init__(self):
         self.pairs = {"f16x3": [], "f32": []}
         self.flops = {"f16x3": 0.0, "f32": 0.0}
         self.bytes = {"f16x3": 0.0, "f32": 0.0}
+        # per family of split (f16x3) launches: [(event, event)], algorithmic flops -- the GEMM families are subsets of
+        # pairs["f16x3"]; the two attention families are the split attention kernels (own launches, same MFMA, same peak)
+        self.fam_pairs = {k: [] for k in self.FAMILIES}
+        self.fam_flops = {k: 0.0 for k in self.FAMILIES}
 
-    def _timed(self, kind, fn, M, N, K, batch=1, mn_tensors=1):
+    def _timed_family(self, fam, fn, flops):
+        s = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        r = fn()
+        e1.record(s)
+        self.fam_pairs[fam].append((e0, e1))
+        self.fam_flops[fam] += flops
+        return r
+
+    def _timed(self, kind, fn, M, N, K, batch=1, mn_tensors=1, family=None):
         """mn_tensors: how many [M, N] 4-byte-per-element tensors the launch reads or writes (fp32 result, result planes,
         residual, stored pre-activation, activation-gradient operand, accumulated-into result)."""
         s = torch.cuda.current_stream()
@@ -236,11 +254,15 @@ class GemmTimer:
         self.pairs[kind].append((e0, e1))
         self.flops[kind] += 2.0 * M * N * K * batch
         self.bytes[kind] += 4.0 * (M * K + N * K + mn_tensors * M * N) * batch     # two fp16 planes = 4 bytes per element
+        if family is not None:
+            self.fam_pairs[family].append((e0, e1))
+            self.fam_flops[family] += 2.0 * M * N * K * batch
         return r
 
     def install(self):
         from dupl_amd import ops
         self._orig, self._orig16 = ops.gemm_raw, ops.linear16
+        self._orig_af, self._orig_ab = ops.attention_fwd16, ops.attention_bwd16
         timer = self
 
         def timed(A, B, C, M, N, K, lda, ldb, ldc, **kw):
@@ -253,19 +275,38 @@ class GemmTimer:
             planes_out = kw.get("want16", False) or kw.get("out16") is not None
             aux = sum(kw.get(k) is not None for k in ("res", "store_pre", "dgelu_of", "relumask_of"))
             mn = int(f32_out) * (2 if kw.get("accumulate", False) else 1) + int(planes_out) + aux
-            return timer._timed("f16x3", lambda: timer._orig16(x, W, *a, **kw), x.rows, W.rows, x.cols, mn_tensors=mn)
+            # family: weight gradients accumulate; data gradients carry the inverse scale of their scaled gradient planes;
+            # everything else is a forward Linear / decoder conv, on format 1 (single accumulator) or format 0 planes
+            fam = "wgrad" if kw.get("accumulate", False) else ("dgrad" if kw.get("alpha") is not None else
+                                                                ("fwd_f1" if getattr(x, "exp", 0) else "fwd_f0"))
+            return timer._timed("f16x3", lambda: timer._orig16(x, W, *a, **kw), x.rows, W.rows, x.cols, mn_tensors=mn, family=fam)
+
+        def timed_af(qkv16, B, N, H, hd, scale, *a, **kw):      # S = Q K^T and O = P V: 4 N^2 hd per (image, head)
+            return timer._timed_family("attention_fwd", lambda: timer._orig_af(qkv16, B, N, H, hd, scale, *a, **kw),
+                                       4.0 * B * H * N * N * hd)
+
+        def timed_ab(qkv16, out, dout, lse, B, N, H, hd, scale, *a, **kw):   # S recomputed, dP, dV, dQ, dK: 10 N^2 hd
+            return timer._timed_family("attention_bwd", lambda: timer._orig_ab(qkv16, out, dout, lse, B, N, H, hd, scale, *a, **kw),
+                                       10.0 * B * H * N * N * hd)
 
         ops.gemm_raw, ops.linear16 = timed, timed16
+        ops.attention_fwd16, ops.attention_bwd16 = timed_af, timed_ab
 
     def remove(self):
         from dupl_amd import ops
         ops.gemm_raw, ops.linear16 = self._orig, self._orig16
+        ops.attention_fwd16, ops.attention_bwd16 = self._orig_af, self._orig_ab
 
-    def busy_union(self, kind, base_event):
-        """(ms during which at least one launch of `kind` was running on ANY stream, flops) since base_event: with the two
-        students on two streams their GEMMs overlap, so per-launch durations double-count the chip; the union does not."""
-        torch.cuda.synchronize()
-        iv = sorted((base_event.elapsed_time(a), base_event.elapsed_time(b)) for a, b in self.pairs[kind])
+    def reset(self):
+        self.pairs = {k: [] for k in self.pairs}
+        self.flops = {k: 0.0 for k in self.flops}
+        self.bytes = {k: 0.0 for k in self.bytes}
+        self.fam_pairs = {k: [] for k in self.FAMILIES}
+        self.fam_flops = {k: 0.0 for k in self.FAMILIES}
+
+    @staticmethod
+    def _union_ms(pairs, base_event):
+        iv = sorted((base_event.elapsed_time(a), base_event.elapsed_time(b)) for a, b in pairs)
         busy, cur0, cur1 = 0.0, None, None
         for a, b in iv:
             if cur1 is None or a > cur1:
@@ -276,7 +317,38 @@ class GemmTimer:
                 cur1 = max(cur1, b)
         if cur1 is not None:
             busy += cur1 - cur0
-        return busy, self.flops[kind]
+        return busy
+
+    def families(self, passes, peak, base_event=None, steps=1):
+        """Per family: algorithmic flops per step, launches per step and time per step -- single stream: sum over the launches
+        of the per-launch minimum over `passes` repetitions of the step; with base_event (two student streams): the union of
+        the family's event intervals / steps."""
+        torch.cuda.synchronize()
+        out = {}
+        for fam in self.FAMILIES:
+            v = self.fam_pairs[fam]
+            if not v:
+                continue
+            if base_event is None:
+                n = len(v) // passes
+                assert n * passes == len(v)
+                t = [[a.elapsed_time(b) for a, b in v[p * n:(p + 1) * n]] for p in range(passes)]
+                ms = sum(min(col) for col in zip(*t))
+                fl = self.fam_flops[fam] / passes
+            else:
+                n = len(v) // steps
+                ms = self._union_ms(v, base_event) / steps
+                fl = self.fam_flops[fam] / steps
+            out[fam] = {"tflop_per_step": round(fl / 1e12, 3), "launches_per_step": n, "ms_per_step": round(ms, 3),
+                        "achieved": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
+                        "frac": round(fl / (ms * 1e-3) / peak, 4) if ms > 0 else None}
+        return out
+
+    def busy_union(self, kind, base_event):
+        """(ms during which at least one launch of `kind` was running on ANY stream, flops) since base_event: with the two
+        students on two streams their GEMMs overlap, so per-launch durations double-count the chip; the union does not."""
+        torch.cuda.synchronize()
+        return self._union_ms(self.pairs[kind], base_event), self.flops[kind]
 
     def result(self, passes=1):
         """(kind, ms, flops, launches, bytes) per pass of the kind with the larger total time.  With passes > 1 (the same
@@ -425,6 +497,7 @@ def main():
     wl = Workload(args, world, rank, local, dataset, batch, backbone, n_iter)
     res = wl.measure("main")
     ms, imgs_per_s, phase, C = res["ms"], res["value"], wl.phase, wl.C
+    guard_main = wl.model.flat_storage.guard          # of the main workload (later legs build other models)
 
     flop_ref = FLOP_PER_IMG_PHASE_AB + (FLOP_PHASE_C_AUG + FLOP_PHASE_C_DEAD if phase == "C" else 0.0)
     flop_exec = FLOP_PER_IMG_PHASE_AB - (0.0 if args.no_share_encoder else FLOP_SHARED_PASS) + \
@@ -437,18 +510,30 @@ def main():
         for _ in range(3):
             wl.step(args.warmup + args.steps + 1)
         kind, gms, gflops, gn, gbytes = timer.result(passes=3)
+        if kind == "f16x3":
+            # one fp32-equivalent multiply-add costs 3 f16 MFMA products (hi*hi, hi*lo, lo*hi): the roofline of the
+            # ALGORITHMIC flops is the dense f16 MFMA peak / 3
+            peak, kname, prefix = PEAK_F16_MFMA / 3.0, KERNEL_F16X3, "gemm_f16x3"
+        else:
+            peak, kname, prefix = PEAK_F32_MFMA, KERNEL_F32, "gemm_f32_kernel<false, false"
+        fam_single = timer.families(3, PEAK_F16_MFMA / 3.0) if kind == "f16x3" else None
         timer.remove()
+        ach1 = gflops / (gms * 1e-3)
+        single = {"achieved": round(ach1 / 1e12, 2), "frac": round(ach1 / peak, 4), "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
+                  "kernel_ms_per_step": round(gms, 2), "families": fam_single,
+                  "note": "students back to back on ONE stream: HIP event pairs around every launch during three extra steps, per "
+                          "launch the minimum of the three (drops host-side gaps) -- clean per-kernel durations (they agree with "
+                          "the rocprofv3 kernel trace), but NOT the configuration the timed region runs in"}
         dual = None
         if not args.single_stream:
             wl.model.enable_dual_stream(True)
-            # the same kernel in the regime the timed region runs in: both students' launches in flight on two streams.
+            # the same kernels in the regime the timed region runs in: both students' launches in flight on two streams.
             # Per-launch durations are meaningless there (every launch shares the chip with the other student's), so the
             # figure is total algorithmic flops / time during which at least one such launch was running (event union)
             t2 = GemmTimer()
             t2.install()
             wl.step(args.warmup + args.steps + 4)       # settle the tile heuristic's stream count
-            t2.pairs = {"f16x3": [], "f32": []}
-            t2.flops = {"f16x3": 0.0, "f32": 0.0}
+            t2.reset()
             torch.cuda.synchronize()
             base = torch.cuda.Event(enable_timing=True)
             base.record()
@@ -456,37 +541,37 @@ def main():
             for r in range(nrep):
                 wl.step(args.warmup + args.steps + 5 + r)
             busy, fl2 = t2.busy_union(kind, base)
+            fam_dual = t2.families(1, PEAK_F16_MFMA / 3.0, base_event=base, steps=nrep) if kind == "f16x3" else None
             t2.remove()
             if busy > 0:
-                dual = {"achieved": round(fl2 / (busy * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
-                        "busy_ms_per_step": round(busy / nrep, 2), "steps": nrep,
+                dual = {"achieved": round(fl2 / (busy * 1e-3) / 1e12, 2), "frac": round(fl2 / (busy * 1e-3) / peak, 4),
+                        "busy_ms_per_step": round(busy / nrep, 2), "steps": nrep, "families": fam_dual,
                         "note": "two student streams (the timed configuration): algorithmic flops of every launch of the kernel on "
-                                "both streams / union of their [start, end] event intervals"}
-        ach = gflops / (gms * 1e-3)
-        if kind == "f16x3":
-            # one fp32-equivalent multiply-add costs 3 f16 MFMA products (hi*hi, hi*lo, lo*hi): the roofline of the
-            # ALGORITHMIC flops is the dense f16 MFMA peak / 3
-            peak, kname, prefix = PEAK_F16_MFMA / 3.0, KERNEL_F16X3, "gemm_f16x3_kernel"
-        else:
-            peak, kname, prefix = PEAK_F32_MFMA, KERNEL_F32, "gemm_f32_kernel<false, false"
+                                "both streams / union of their [start, end] event intervals; per family the union of that "
+                                "family's intervals (a launch's interval also spans what the other student's kernels took from it)"}
         traffic, tnote = pmc_traffic_per_launch(args.pmc_profile, prefix, gemm_mode) if (dataset, batch) == ("voc", 4) else \
             (None, "the committed PMC passes are of the VOC 4 img/GPU workload")
-        roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach / 1e12, 2),
-                "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+        # top level = the configuration the timed region runs in: two student streams unless --single-stream
+        top = dual if dual is not None else single
+        roof = {"bound": "mfma", "kernel": kname, "achieved": top["achieved"],
+                "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(top["achieved"] / (peak / 1e12), 4),
+                "configuration": "two student streams (as timed)" if dual is not None else "one stream",
                 "traffic": traffic, "traffic_source": tnote, "csrc_sha256": csrc_digest()[:16],
                 "peak_definition": ("dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per fp32-equivalent multiply-add; "
-                                    f"executed MFMA rate = {3 * ach / 1e12:.1f} of 2500 TFLOP/s (the same fraction)")
+                                    f"executed MFMA rate = {3 * top['achieved']:.1f} of 2500 TFLOP/s (the same fraction)")
                 if kind == "f16x3" else "f32 MFMA peak (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s",
                 "algorithmic_bytes_per_launch": round(gbytes / max(gn, 1)),
                 "traffic_over_algorithmic": (round(traffic * gn / gbytes, 2) if traffic else None),
-                "dual_stream": (dict(dual, frac=round(dual["achieved"] * 1e12 / peak, 4)) if dual else None),
-                "launches_per_step": gn, "avg_launch_us": round(gms * 1e3 / max(gn, 1), 1),
-                "kernel_share_of_step": round(gms / ms, 3),
+                "families": top["families"],
+                "dual_stream": dual, "single_stream": single,
+                "launches_per_step": gn, "avg_launch_us": single["avg_launch_us"],
+                "kernel_share_of_step": round((dual["busy_ms_per_step"] if dual is not None else gms) / ms, 3),
                 "step_flop_per_img": {"reference_algorithm": flop_ref, "executed": flop_exec},
                 "step_algorithmic_tflops": round(imgs_per_s / world * flop_exec / 1e12, 1),
-                "note": "HIP event pairs around every launch of the kernel during three extra steps run right after the "
-                        "timed region (same stream, same workload; per launch the minimum of the three, which drops "
-                        "host-side gaps); algorithmic flops = 2*M*N*K per launch (fp32-equivalent)"}
+                "note": "achieved / frac: every launch of the split GEMM (forward, data and weight gradients) in the configuration "
+                        "the timed region runs in, HIP events on the launching streams during extra steps right after the timed "
+                        "region; algorithmic flops = 2*M*N*K per launch (fp32-equivalent); `families` splits them (and adds the "
+                        "split attention kernels, same peak); `single_stream` holds the per-launch figures rocprofv3 agrees with"}
 
     # the same workload on the exact-f32 MFMA kernels (DUPL_GEMM=f32): the number to read if the f16x3 split products are
     # not accepted as the reference's fp32 arithmetic
@@ -512,6 +597,20 @@ def main():
                               f"{l_b} img/GPU): not a point of the weak-scaling curve that `value` draws"}
         wl = wL
 
+    # the metric's second configuration ("COCO bs=8"): timed in the same run on one GPU, with its own ms_per_step
+    second = None
+    if world == 1 and not args.no_second and listed and (dataset, batch) == ("voc", 4):
+        del wl
+        torch.cuda.empty_cache()
+        w2 = Workload(args, world, rank, local, "coco", 8, backbone, DEFAULT_N_ITER["coco"])
+        r2 = w2.measure("second-config")
+        second = {"value": round(r2["value"], 3), "unit": "img/s", "ms_per_step": round(r2["ms"], 2), "steps": args.steps,
+                  "warmup": args.warmup, "workload": w2.describe(), "img_per_gpu": 8, "num_classes": 81,
+                  "loss": round(r2["loss"], 5),
+                  "note": "BASELINE.json metric, second half ('COCO bs=8'): MSCOCO2014 448^2, 81 classes, COCO schedule phase B2, "
+                          "8 images on one GPU; same protocol as `value` (warm-up, barrier + synchronize, K timed steps)"}
+        wl = w2
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline == "auto":
         log("timing the CPU oracle on the host cores (bounded sample: warm-up + thread sweep + timed steps)")
@@ -531,10 +630,14 @@ def main():
                           "shared_scale1_encoder_pass": not args.no_share_encoder, "forward_gemm": gemm_mode,
                           "deterministic": os.environ.get("DUPL_DETERMINISTIC", "0") == "1",
                           "loss": round(res["loss"], 5)},
-               "comm": res["comm"], "listed_config": listed_cfg, "exact_f32_path": exact,
+               # schema 2 (round 4): `value` = configs[1] (VOC, 4 img/GPU) on EVERY rank at every N -- a weak-scaling point, NOT the
+               # configuration BASELINE.json lists for N > 1 (that one is `listed_config`); `second_config` = COCO 8 img/GPU at
+               # N = 1; roofline.frac = the two-stream (timed) configuration
+               "schema": 2, "value_config": "configs[1] per rank (weak scaling)" if listed else "custom",
+               "comm": res["comm"], "listed_config": listed_cfg, "second_config": second, "exact_f32_path": exact,
                # f16x3 operand planes have fp16's range: sites whose operands could leave it (rigorous bounds from the
                # parameters, engine.RangeGuard) run on the exact-f32 kernels; 0 = the whole step ran on the split kernels
-               "range_guard": (wl.model.flat_storage.guard.summary() if gemm_mode == "f16x3" else None),
+               "range_guard": (guard_main.summary() if gemm_mode == "f16x3" else None),
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec))
     if world > 1:

@@ -62,8 +62,9 @@ class GradReducer:
             dist.broadcast(self.store.data, src=src, group=self.pg)
             # a c10d collective does not bump the tensor's version counter: tell the fp16 operand-plane cache
             # (FlatStorage.ensure_w16 / w16T) that the parameters changed.  Every non-autograd writer of store.data
-            # (raw-pointer kernels, collectives) must do the same.
-            self.store.mark_dirty()
+            # (raw-pointer kernels, collectives) must do the same.  rewritten=True: a wholesale rewrite, so the range guard
+            # re-checks synchronously before the next forward instead of `period` steps later.
+            self.store.mark_dirty(rewritten=True)
 
     def _issue(self, lo: int, hi: int):
         """all-reduce grad[lo:hi] in pieces of at most bucket_elems (returns immediately)."""

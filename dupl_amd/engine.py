@@ -153,6 +153,7 @@ class FlatStorage:
         # writers such as the optimiser kernel, buffer address) changes
         self.data16: Optional[Tensor] = None
         self.dirty = 0
+        self.rewrites = 0           # bulk rewrites through raw pointers / collectives (mark_dirty(rewritten=True))
         self._w16_key = [None] * n_students
         self._w16T: Dict = {}
         self._w16F0: Dict = {}
@@ -178,13 +179,20 @@ class FlatStorage:
         self._w16_key = [None] * self.n_students
         self._w16T = {}
 
-    def mark_dirty(self):
-        """To be called by whoever rewrites parameters through raw pointers (the optimiser kernel)."""
+    def mark_dirty(self, rewritten: bool = False):
+        """To be called by whoever rewrites parameters through raw pointers (the optimiser kernel).  rewritten=True: the
+        writer replaced the parameters wholesale (a broadcast, a checkpoint copied in through a raw pointer) rather than
+        moving them by <= lr -- the range guard then re-checks synchronously, as it does for torch-visible rewrites."""
         self.dirty += 1
+        if rewritten:
+            self.rewrites += 1
+
+    def _param_key(self):
+        return (self.data._version, self.dirty, self.data.data_ptr(), self.rewrites)
 
     def ensure_w16(self, student: int):
         """Bring the fp16 hi / lo planes of one student's parameters up to date (on the current stream)."""
-        key = (self.data._version, self.dirty, self.data.data_ptr())
+        key = self._param_key()
         if self._w16_key[student] == key and self.data16 is not None:
             return
         if self.data16 is None or self.data16.device != self.data.device:
@@ -210,12 +218,13 @@ class FlatStorage:
         old = self._w16_key[student]
         self._w16_key[student] = key
         # the operands changed: re-check their range (synchronously unless this was an optimiser step)
-        self.guard.params_changed(student, rewritten=(old is None or old[0] != key[0] or old[2] != key[2]))
+        self.guard.params_changed(student, rewritten=(old is None or old[0] != key[0] or old[2] != key[2] or old[3] != key[3]),
+                                  key=key)
 
     def w16T(self, student: int, key: str, rows: int):
         """Operand planes of the TRANSPOSE of parameter `key` ([rows, cols] -> planes [cols, rows]): the B operand of the data
         gradient dx = dy . W as a k-contiguous product.  Built on first use after every parameter change (backward only)."""
-        ver = (self.data._version, self.dirty, self.data.data_ptr())
+        ver = self._param_key()
         hit = self._w16T.get((student, key))
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -227,7 +236,7 @@ class FlatStorage:
     def w16T_missing(self, student: int, keys_rows):
         """[(key, rows, fp32 view [rows, cols])] of the parameters whose transposed planes are stale: the caller splits them
         (together with other operands, ops.split_prepare_multi) and hands the planes back through w16T_put."""
-        ver = (self.data._version, self.dirty, self.data.data_ptr())
+        ver = self._param_key()
         out = []
         for key, rows in keys_rows:
             hit = self._w16T.get((student, key))
@@ -236,7 +245,7 @@ class FlatStorage:
         return out
 
     def w16T_put(self, student: int, key: str, T):
-        self._w16T[(student, key)] = ((self.data._version, self.dirty, self.data.data_ptr()), T)
+        self._w16T[(student, key)] = (self._param_key(), T)
 
     def w16(self, student: int, key: str, rows: int, fmt1: Optional[bool] = None) -> "ops.W16":
         """Operand planes of parameter `key` viewed as a [rows, numel / rows] matrix."""
@@ -251,7 +260,7 @@ class FlatStorage:
         # a backbone weight whose site does not fit the format 1 scale (RangeGuard "<site>_f1"): format 0 planes, built on first
         # use after every parameter change
         assert not fmt1
-        ver = (self.data._version, self.dirty, self.data.data_ptr())
+        ver = self._param_key()
         hit = self._w16F0.get((student, key))
         if hit is None or hit[0] != ver:
             hit = (ver, ops.split16(self.view(student, key).view(rows, -1)))
@@ -310,7 +319,10 @@ class RangeGuard:
     Freshness: a wholesale parameter rewrite (load_state_dict, .copy_: torch version counter / address change) is checked
     synchronously before the next forward; optimiser steps (raw-pointer writes, FlatStorage.mark_dirty) move a weight by
     <= lr per step, so they are re-checked every `period` steps from an ASYNCHRONOUS device -> pinned-host copy (no
-    host-device synchronisation on the step path) -- what `margin` = 2 is for."""
+    host-device synchronisation on the step path) -- what `margin` = 2 is for.  The copy launched at step k * period is
+    harvested at step (k + 1) * period exactly, so the step at which a site changes route does not depend on host / device
+    timing (bit-reproducible under DUPL_DETERMINISTIC=1, identical on every DDP rank); a backward pass uses the verdicts its
+    forward ran with (EncoderSaved.guard / HeadSaved.guard), whatever has been harvested in between."""
 
     SITES = ("qkv", "attn", "proj", "fc1", "fc2")
 
@@ -344,6 +356,7 @@ class RangeGuard:
         self.headroom = float("inf")   # min over sites of 65504 / (margin * bound) at the last check (< 1: some site is on f32)
         self.headroom1 = float("inf")  # the same at the format 1 scales (< 1: some encoder site runs on format 0 planes)
         self.checks = 0
+        self._checked_key = None       # parameter state (FlatStorage._param_key) of the last synchronous check
 
     # ---- device side
     def _ensure_buffers(self):
@@ -392,9 +405,14 @@ class RangeGuard:
         worst = [0.0]
 
         def ok(*bounds):
-            b = max(bounds)
-            worst[0] = max(worst[0], b)
-            return bool(b <= lim)           # NaN / inf -> False
+            good = True
+            for b in bounds:                # element-wise: Python's max() drops a NaN that is not its first argument
+                b = float(b)
+                if not (b <= lim):          # NaN / inf -> False
+                    good = False
+                if b == b:
+                    worst[0] = max(worst[0], b)
+            return good
 
         def amax(k):
             return v[ix[k], 0]
@@ -446,20 +464,28 @@ class RangeGuard:
         self.headroom1 = min(self.headroom1, float(lim / max(worst1[0], 1e-30)))
         return out
 
-    def params_changed(self, student: int, rewritten: bool):
+    def params_changed(self, student: int, rewritten: bool, key=None):
         """Called by FlatStorage.ensure_w16 when the operand planes of a student are rebuilt.  rewritten: the buffer was
-        replaced or written through torch (load_state_dict, copy_) rather than by an optimiser step."""
+        replaced or written through torch (load_state_dict, copy_) or wholesale through a raw pointer / collective
+        (mark_dirty(rewritten=True)) rather than by an optimiser step.  key: the parameter state the planes were built from --
+        one synchronous check covers every student of that state (the other student's rebuild does not repeat it)."""
         if rewritten or self.safe[student] is None:
+            if key is not None and key == self._checked_key and self.safe[student] is not None:
+                return
             self._launch(range(self.store.n_students))
             self._harvest(wait=True)
             self._steps = [0] * self.store.n_students
+            self._checked_key = key
             return
         self._steps[student] += 1
-        if student == 0 and self._steps[0] % self.period == 0 and not self._pending:
+        if student == 0 and self._steps[0] % self.period == 0:
+            # the bounds launched `period` optimiser steps ago are taken in HERE, at a fixed step of the run (the host is at most
+            # a step or two ahead of the device, so this wait does not block in practice) -- not whenever the copy happens to
+            # have landed: a site then changes route at the same step in every run and on every DDP rank (ADVICE r3)
+            self._harvest(wait=True)
             self._launch(range(self.store.n_students))
 
     def sites(self, student: int) -> dict:
-        self._harvest(wait=False)
         if self.safe[student] is None:
             self._launch(range(self.store.n_students))
             self._harvest(wait=True)
@@ -467,7 +493,6 @@ class RangeGuard:
 
     def summary(self) -> dict:
         """For logs / bench.py: how many sites run on the f32 kernels because their operands could leave fp16's range."""
-        self._harvest(wait=False)
         n = n0 = 0
         for s in self.safe:
             if s is None:
@@ -547,6 +572,7 @@ class EncoderSaved:
     x_last: Tensor = None      # input of the final LayerNorm
     mean_f: Tensor = None
     rstd_f: Tensor = None
+    guard: dict = None         # f16x3 mode: the RangeGuard verdicts this forward ran with (its backward takes the same routes)
 
 
 def encoder_forward(P: StudentParams, x: Tensor, save: bool, save_rows: int = 0):
@@ -638,7 +664,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
     sv = None
     if save:
         _, B, _, h, w = groups[0]
-        sv = EncoderSaved(B=B, h=h, w=w, x_img=xs[0])
+        sv = EncoderSaved(B=B, h=h, w=w, x_img=xs[0], guard=guard)
     aux_idx = cfg.aux_layer % cfg.depth
     aux = None
     scale = hd ** -0.5
@@ -799,12 +825,13 @@ class HeadSaved:
     h6: Tensor = None
     col7: Tensor = None
     h7: Tensor = None
+    guard: dict = None         # f16x3 mode: the RangeGuard verdicts the decoder convs ran with
 
 
 def _prefix_saved(sv: EncoderSaved, b: int, rows: int) -> EncoderSaved:
     """Activation record of the first `b` images of a larger saved batch (every tensor is image-major, so a row
     prefix is a contiguous view: nothing is copied)."""
-    out = EncoderSaved(B=b, h=sv.h, w=sv.w, x_img=sv.x_img[:b])
+    out = EncoderSaved(B=b, h=sv.h, w=sv.w, x_img=sv.x_img[:b], guard=sv.guard)
     for s in sv.blocks:
         out.blocks.append(BlockSaved(x_in=s.x_in[:rows], mean1=s.mean1[:rows], rstd1=s.rstd1[:rows], ln1=s.ln1[:rows],
                                      qkv=s.qkv[:rows] if s.qkv is not None else None, lse=s.lse[:b], att=s.att[:rows],
@@ -875,7 +902,7 @@ def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
     sv = None
     if save:
         sv = HeadSaved(enc=enc, tf=tf, aux=aux, pooled=pooled, pooled_idx=pidx, pooled_aux=pooled_a, pooled_aux_idx=paidx,
-                       col6=col6, h6=h6, col7=col7, h7=h7)
+                       col6=col6, h6=h6, col7=col7, h7=h7, guard=guard)
     return (cls_x4, seg, x4, cls_aux), sv
 
 
@@ -979,7 +1006,7 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         ops.linear_wgrad(dseg_tok, sv.h7, G["decoder.conv8.weight"], accumulate=True)
         dh7 = ops.linear_dgrad(dseg_tok, W["decoder.conv8.weight"].view(NC, dd), relumask_of=sv.h7)
         f16 = GEMM_MODE == "f16x3"
-        guard = P.store.guard.sites(P.student) if f16 else None
+        guard = (sv.guard or P.store.guard.sites(P.student)) if f16 else None
         conv_bwd = _linear_backward16 if (f16 and guard["conv7"]) else _linear_backward32
         dcol7 = conv_bwd(P, dh7, sv.col7, "decoder.conv7", has_bias=False)
         dh6 = torch.empty((B * n, dd), device=dev, dtype=torch.float32)
@@ -994,7 +1021,7 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         on_ready("heads")
     # ---- final LayerNorm
     f16 = GEMM_MODE == "f16x3"
-    gb = P.store.guard.sites(P.student)["blocks"] if f16 else None
+    gb = (enc.guard or P.store.guard.sites(P.student))["blocks"] if f16 else None
     # a gradient whose next use is the scaled operand split of an f16x3 Linear backward gets its max-abs from the kernel that
     # writes it (LayerNorm backward, dgrad epilogue) instead of a pass of its own (ops.reserve_amax)
     dx = ops.layernorm_bwd(dtf, enc.x_last, W["encoder.norm.weight"], enc.mean_f, enc.rstd_f,

@@ -162,8 +162,11 @@ def setup_seed(seed):
 
 def _save_resume_state(ckpt_dir, wrapped, model, optim, n_iter):
     """checkpoint.pth (keys prefixed `module.`, train_final_voc.py:519) + optimizer.pth + checkpoint.n_iter, each written to a
-    temporary file and renamed into place, the iteration tag last: a job killed mid-save leaves either the previous
-    consistent triple or a tag that --resume can check against optimizer.pth."""
+    temporary file and renamed into place, in THIS order: optimizer.pth (it carries n_iter) first, then checkpoint.pth, then the
+    iteration tag.  A job killed between any two renames leaves a tag that differs from optimizer.pth's n_iter, which
+    `_load_resume_state` refuses: after the first rename the optimiser is new and the weights old (mixed), after the second
+    both are new but the tag is not (consistent, refused all the same: the tag cannot tell the two apart).  Only a save that
+    ran to its end, or one that never renamed anything, resumes."""
     os.makedirs(ckpt_dir, exist_ok=True)
     sd = wrapped.state_dict() if wrapped is not None else {"module." + k: v for k, v in model.state_dict().items()}
 
@@ -172,12 +175,32 @@ def _save_resume_state(ckpt_dir, wrapped, model, optim, n_iter):
         torch.save(obj, tmp)
         os.replace(tmp, os.path.join(ckpt_dir, name))
 
-    put(sd, "checkpoint.pth")
     put({"n_iter": n_iter, "optimizer": optim.state_dict()}, "optimizer.pth")
+    put(sd, "checkpoint.pth")
     tmp = os.path.join(ckpt_dir, "checkpoint.n_iter.tmp")
     with open(tmp, "w") as f:
         f.write(str(n_iter))
     os.replace(tmp, os.path.join(ckpt_dir, "checkpoint.n_iter"))
+
+
+def _load_resume_state(resume_dir):
+    """(model state_dict without `module.`, optimiser state, n_iter) of a directory written by _save_resume_state; raises if
+    the iteration tag (written last) is missing or differs from optimizer.pth's n_iter (written first): some rename of the
+    last save did not happen, so checkpoint.pth may be older than optimizer.pth."""
+    ost = torch.load(os.path.join(resume_dir, "optimizer.pth"), map_location="cpu")
+    tag = os.path.join(resume_dir, "checkpoint.n_iter")
+    if not os.path.exists(tag):
+        raise RuntimeError(f"{resume_dir}: no checkpoint.n_iter tag (the first save of this run was interrupted after "
+                           f"optimizer.pth reached n_iter {int(ost['n_iter'])}): refusing to resume")
+    with open(tag) as f:
+        saved_at = int(f.read().strip())
+    if saved_at != int(ost["n_iter"]):
+        raise RuntimeError(f"{resume_dir}: the last COMPLETED save was at n_iter {saved_at}, but optimizer.pth is from n_iter "
+                           f"{int(ost['n_iter'])}: a later save was interrupted after it replaced optimizer.pth, and "
+                           "checkpoint.pth is from one of the two -- refusing to resume from possibly mixed state")
+    ck = torch.load(os.path.join(resume_dir, "checkpoint.pth"), map_location="cpu")
+    sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ck.items()}
+    return sd, ost["optimizer"], int(ost["n_iter"])
 
 
 def train(args, dataset: str, loader=None, val_loader=None):
@@ -231,18 +254,10 @@ def train(args, dataset: str, loader=None, val_loader=None):
     it = _EpochIterator(loader, args.max_iters) if loader is not None else None
     optim.global_step = args.start_iter       # a run that starts at n_iter = k is at step k of the LR schedule too
     if getattr(args, "resume", None):
-        ck = torch.load(os.path.join(args.resume, "checkpoint.pth"), map_location="cpu")
-        ost = torch.load(os.path.join(args.resume, "optimizer.pth"), map_location="cpu")
-        tag = os.path.join(args.resume, "checkpoint.n_iter")
-        if os.path.exists(tag):     # written last by _save_resume_state: model and optimiser files of the same iteration
-            with open(tag) as f:
-                saved_at = int(f.read().strip())
-            if saved_at != int(ost["n_iter"]):
-                raise RuntimeError(f"{args.resume}: checkpoint.pth was written at n_iter {saved_at}, optimizer.pth at "
-                                   f"{int(ost['n_iter'])} (a save was interrupted): refusing to resume from mixed state")
-        model.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in ck.items()}, strict=True)
-        optim.load_state_dict(ost["optimizer"])
-        args.start_iter = int(ost["n_iter"])
+        sd, opt_state, at = _load_resume_state(args.resume)
+        model.load_state_dict(sd, strict=True)
+        optim.load_state_dict(opt_state)
+        args.start_iter = at
         if rank == 0:
             logging.info("resumed from %s at n_iter %d" % (args.resume, args.start_iter))
     last_iter = args.max_iters if getattr(args, "stop_iter", None) is None else min(args.max_iters, args.stop_iter)

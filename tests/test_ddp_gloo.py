@@ -129,3 +129,133 @@ def test_eval_hist_exchange_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+class _Replay(torch.autograd.Function):
+    """An autograd node whose backward runs a closure: stands in for a student's _NetworkFn so that the DDP wrapper's hook
+    protocol (grad-ready events, post-backward hook, the engine's final callback) is driven by a REAL autograd pass."""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x * 1.0
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fn()
+        return g, None
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dupl_amd.model.model_dupl import siamese_network
+        from dupl_amd.ddp import DistributedDataParallel
+        from dupl_amd.synthetic import hash_normal
+        torch.manual_seed(100 + rank)
+        m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+        ddp = DistributedDataParallel(m, bucket_mb=0.05, blocks_per_bucket=1)
+        st, red = m.flat_storage, ddp.reducer
+        ok = {"world": red.world == world}
+        # the plan tiles each student's trainable range exactly once, at this world size too
+        cover = torch.zeros(st.grad.numel(), dtype=torch.int32)
+        for s in (0, 1):
+            for lo, hi, _ in red.plan[s]:
+                cover[lo:hi] += 1
+        want = torch.zeros_like(cover)
+        for s in (0, 1):
+            lo, hi = st.trainable_range(s)
+            want[lo:hi] = 1
+        ok["plan_tiles_once"] = bool(torch.equal(cover, want))
+        events = ["heads"] + list(reversed(range(st.cfg.depth))) + ["stem"]
+        nets = (m.branch1, m.branch2)
+
+        def fill(tag):
+            g = hash_normal(f"{tag}_rank{rank}", (st.grad.numel(),), std=1.0, seed=3)
+            st.grad.copy_(g)
+            for s in (0, 1):
+                flo = s * st.student_numel
+                st.grad[flo: flo + st.seg_bounds[0][1]] = 5.0 + rank
+
+        def expect(tag):
+            return sum(hash_normal(f"{tag}_rank{r}", (st.grad.numel(),), std=1.0, seed=3) for r in range(world)) / world
+
+        def check(tag):
+            e = expect(tag)
+            good = True
+            for s in (0, 1):
+                lo, hi = st.trainable_range(s)
+                good &= bool(torch.allclose(st.grad[lo:hi], e[lo:hi], atol=2e-6))
+                flo = s * st.student_numel
+                good &= bool((st.grad[flo: flo + st.seg_bounds[0][1]] == 5.0 + rank).all())
+            return good
+
+        seen = {}
+
+        def student_backward(net, last: bool):
+            """What _NetworkFn.backward does around engine.network_backward (model_dupl.py): events only during the last
+            pending backward of the student, then the post-backward hooks."""
+            def run():
+                if net._grad_ready_hooks and net._live_graphs <= 1:
+                    for ev in events:
+                        for hook in net._grad_ready_hooks:
+                            hook(net, ev)
+                else:
+                    seen.setdefault("issued_early", 0)
+                    seen["issued_early"] += len(red._issued[net._student])      # a first-of-two backward issues nothing of ITS student
+                net._live_graphs = max(0, net._live_graphs - 1)
+                for hook in net._post_backward_hooks:
+                    hook(net)
+            return run
+
+        # ---- phase B: one forward per student
+        fill("B")
+        red.pop_stats()
+        a = torch.zeros(1, requires_grad=True)
+        for net in nets:
+            net._live_graphs = 1
+        loss = sum(_Replay.apply(a, student_backward(net, True)) for net in nets)
+        loss.sum().backward()
+        stB = red.pop_stats()
+        ok["B_mean"] = check("B")
+        n_trainable = sum(st.trainable_range(s)[1] - st.trainable_range(s)[0] for s in (0, 1))
+        ok["B_bytes_once"] = stB["allreduce_bytes"] == 4 * n_trainable       # every element exchanged exactly once
+        ok["B_clean"] = not red._pending and not any(red._issued) and not ddp._touched and not ddp._reduced
+        # ---- phase C: TWO forwards per student (train_final_voc.py:291-295); the backward of the first one only accumulates
+        fill("C")
+        for net in nets:
+            net._live_graphs = 2
+        parts = []
+        for net in nets:
+            parts.append(_Replay.apply(a, student_backward(net, False)))
+            parts.append(_Replay.apply(a, student_backward(net, True)))
+        sum(parts).sum().backward()
+        stC = red.pop_stats()
+        ok["C_mean"] = check("C")
+        ok["C_bytes_once"] = stC["allreduce_bytes"] == 4 * n_trainable
+        ok["C_nothing_issued_by_first_backward"] = seen.get("issued_early", 0) == 0
+        ok["C_clean"] = not red._pending and not any(red._issued) and all(n._live_graphs == 0 for n in nets)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_bucket_bookkeeping_world8_gloo():
+    """the bucket plan and the DDP wrapper's hook protocol at world 8 (the node size of configs[4]), driven
+    by a real autograd pass per step: phase B (one forward per student) and phase C (two forwards per student: the first
+    backward must not exchange anything).  Every trainable element is all-reduced exactly once per step and ends as the mean
+    over the 8 ranks; the frozen segment is never touched."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok in res:
+        assert all(ok.values()), (rank, ok)

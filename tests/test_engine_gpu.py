@@ -480,7 +480,8 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     biases, massive-activation channels: oracle.make_student_params) -- the product stays on f16x3 wherever the range guard
     proves the planes safe, and the same bars hold.  Bars: CAM max-abs-diff < 1e-3 (north_star), identical pseudo-label
     maps, refined label maps identical except at PROVEN argmax ties (oracle decision margin < 1e-5 at every
-    mismatching pixel), loss pieces 1e-4, gradients of a spread of tensors 2e-3.  gemm_mode: the forward Linears on the
+    mismatching pixel), loss pieces 1e-4, EVERY gradient tensor (314 of them: both students, all but the frozen pos_embed / unused head) within
+    2e-4 of its max (5e-4 in exact-f32 mode).  gemm_mode: the forward Linears on the
     f16x3 split GEMM (product default) or on the exact-f32 MFMA kernel -- the same bars hold for both."""
     import random
     from dupl_amd.model.model_dupl import siamese_network
@@ -513,10 +514,10 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     torch.cuda.synchronize()
     if gemm_mode == "f16x3":
         print(f"full-size {case} range guard:", model.flat_storage.guard.summary())
-    watch = ["branch1.encoder.blocks.0.attn.qkv.weight", "branch1.encoder.blocks.11.mlp.fc2.weight",
-             "branch2.encoder.blocks.5.norm1.weight", "branch2.encoder.patch_embed.proj.weight",
-             "branch1.decoder.conv6.weight", "branch2.classifier.weight", "branch1.encoder.cls_token",
-             "branch2.encoder.blocks.9.attn.proj.bias"]
+    # EVERY parameter tensor that receives a gradient is compared: pos_embed is frozen (vit.py:243) and
+    # encoder.head is never used by forward_features
+    frozen = ("encoder.pos_embed", "encoder.head.weight", "encoder.head.bias")
+    watch = [k for k in pp if k.split(".", 1)[1] not in frozen]
     leaf = {k: v.clone().requires_grad_(k in watch) for k, v in pp.items()}
     aug = None
     if case == "voc_C":
@@ -543,12 +544,22 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     if case == "voc_C":
         print("GMM stats:", [st.cpu().numpy().round(3).tolist() for st in out["gmm_stats"]], "oracle hits", pc["gmm_hits"])
         assert [int(st[:, 1].sum().item()) for st in out["gmm_stats"]] == list(pc["gmm_hits"])
+    # per tensor: max |got - ref| / max |ref|; bar 2e-4 on the product's f16x3 path, 5e-4 on the exact-f32 kernels (whose fmaf
+    # chains round after every product: about twice the f16x3 error against fp64)
+    bar = 2e-4 if gemm_mode == "f16x3" else 5e-4
+    errs = {}
     for k in watch:
-        got = model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True).cpu()
         ref = leaf[k].grad
-        e = float((got - ref).abs().max() / ref.abs().max())
-        print(f"full-size {case} grad {k}: rel err {e:.2e}")
-        assert e < 2e-3, k
+        assert ref is not None, f"the oracle produced no gradient for {k}"
+        got = model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True).cpu()
+        errs[k] = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    order = sorted(errs, key=errs.get)
+    print(f"full-size {case} [{gemm_mode}] gradients: {len(errs)} tensors compared, median rel err {errs[order[len(order) // 2]]:.2e}, "
+          f"worst {errs[order[-1]]:.2e} ({order[-1]}), bar {bar:.0e}")
+    for k in order[-5:]:
+        print(f"full-size {case} grad {k}: rel err {errs[k]:.2e}")
+    bad = [(k, errs[k]) for k in order if not errs[k] < bar]
+    assert not bad, f"{len(bad)} gradient tensors above {bar:.0e}: {bad[:8]}"
 
 
 @pytest.mark.parametrize("b,H,W", [(1, 96, 160), (3, 128, 96), (2, 80, 80)])
@@ -953,7 +964,7 @@ def test_range_guard_routes_out_of_range_operands_to_f32(dev):
         # (a) the weight outlier: fc1 of block 3 (its input is fine, its B operand is not) and, through the output bound, fc2;
         # (b) gamma 3e3: qkv of block 5 (A operand) and everything fed by the q / k / v bound; (c) the scaled qkv row: attn + proj
         assert (3, "fc1") in off and (3, "fc2") in off and (5, "qkv") in off and (7, "attn") in off and (7, "proj") in off
-        assert (7, "qkv") not in off or True
+        assert (7, "qkv") not in off, "the scaled qkv ROW leaves the qkv GEMM's own operands in range (60 << 32 752): only its consumers move"
         assert all(sites["blocks"][i][k] for i in (0, 1, 2, 4, 6, 8, 9, 10, 11) for k in engine.RangeGuard.SITES), "untouched blocks stay on f16x3"
         if engine.FMT1:
             b9, b10 = sites["blocks"][9], sites["blocks"][10]

@@ -260,3 +260,49 @@ def test_command_line_flags_match_the_reference(golden_dir):
                     (script, name, d, rec["default"])
             n += 1
     assert n >= 95
+
+
+def test_interrupted_resume_save_is_refused(tmp_path, monkeypatch):
+    """a job killed between any two renames of _save_resume_state must not resume from mixed state.  The save is
+    cut after 0 .. 3 of its three os.replace calls; only the uncut save (3) and the one that renamed nothing (0) resume."""
+    from dupl_amd import train_main as TM
+
+    class Obj:
+        def __init__(self, v):
+            self.v = v
+
+        def state_dict(self):
+            return {"w": torch.full((2,), float(self.v))}
+
+    d = str(tmp_path)
+    TM._save_resume_state(d, None, Obj(1), Obj(10), 100)
+    sd, opt, at = TM._load_resume_state(d)
+    assert at == 100 and float(sd["w"][0]) == 1 and float(opt["w"][0]) == 10
+    real = os.replace
+    for cut in (0, 1, 2, 3):
+        n = {"k": 0}
+
+        def flaky(a, b, _n=n, _cut=cut):
+            if _n["k"] >= _cut:
+                raise KeyboardInterrupt("killed")
+            _n["k"] += 1
+            return real(a, b)
+
+        monkeypatch.setattr(TM.os, "replace", flaky)
+        try:
+            TM._save_resume_state(d, None, Obj(2), Obj(20), 200)
+        except KeyboardInterrupt:
+            pass
+        monkeypatch.setattr(TM.os, "replace", real)
+        if cut in (1, 2):
+            with pytest.raises(RuntimeError, match="refusing to resume"):
+                TM._load_resume_state(d)
+        else:
+            sd, opt, at = TM._load_resume_state(d)
+            want = (100, 1, 10) if cut == 0 else (200, 2, 20)
+            assert (at, float(sd["w"][0]), float(opt["w"][0])) == want
+        # restore a clean state at 100 for the next cut
+        TM._save_resume_state(d, None, Obj(1), Obj(10), 100)
+    os.remove(os.path.join(d, "checkpoint.n_iter"))
+    with pytest.raises(RuntimeError, match="no checkpoint.n_iter"):
+        TM._load_resume_state(d)

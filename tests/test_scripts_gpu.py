@@ -141,14 +141,19 @@ def test_train_final_coco_on_a_dataset_folder(dev, tmp_path):
     assert "Iter: 5;" in out and "val cls score" in out and "mIoU" in out
 
 
-@pytest.mark.parametrize("delay", [0, 1])
+@pytest.mark.parametrize("delay", [0, 1, 2])
 def test_ddp_exchange_on_gpu_world1(dev, delay):
     """RCCL all-reduce path (forced at world 1) gives the same gradients as the plain step; exercises the post-backward
     hooks, the autograd-engine finalise callback and the stream ordering with two student streams.
     delay = 1: after every bucket hand-off a ~10 ms spin kernel is queued on the student stream, so the producers of the
     NEXT bucket run long after the host has already called all_reduce on it -- a missing dependency of RCCL's stream on
     the producing stream (ddp.py: all_reduce(async_op=True) relies on the current stream being the student's) would reduce
-    stale memory and the comparison with the plain step fails; a second GPU is not needed to see that."""
+    stale memory; a second GPU is not needed to see that: what RCCL's stream sees is OBSERVED through a side stream that waits
+    for the collective's work handle only and then copies the bucket (`nccl_snaps`) -- it must equal the stream-ordered
+    snapshot taken on the producing stream at issue time, bit for bit.
+    delay = 2: the negative control.  The same run with the dependency BROKEN on purpose -- all_reduce is
+    called from a fresh, empty stream instead of the student's -- must be caught by that comparison; otherwise the check above
+    would prove nothing."""
     code = r'''
 DELAY = int(__import__("os").environ.get("DUPL_TEST_DELAY", "0"))
 import os, sys, torch, torch.distributed as dist
@@ -167,7 +172,7 @@ par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
 aug, _, _ = O.synthetic_batch(2, 20, 64, seed=19)
 aug = torch.flip(0.7 * inputs + 0.3 * aug, dims=[3]).contiguous().to(dev)
 for n_iter in (5000, 9000):          # phase B: one forward per student; phase C: two (only the last one may exchange)
-    grads, snaps = [], []
+    grads, snaps, nccl_snaps = [], [], []
     for use_ddp in (False, True):
         m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
         m.load_state_dict(pp); m.to(dev); m.enable_dual_stream(True)
@@ -175,12 +180,33 @@ for n_iter in (5000, 9000):          # phase B: one forward per student; phase C
         if use_ddp:
             w.reducer.world = 2          # force the exchange path: all_reduce(SUM) over 1 rank, then * 1/2
             issue = w.reducer._issue
+            side, broken = torch.cuda.Stream(), torch.cuda.Stream()
+            real_ar = dist.all_reduce
+            def ar_spy(t, *a, **kw):
+                work = real_ar(t, *a, **kw)
+                with torch.cuda.stream(side):
+                    work.wait()                                      # the side stream waits for RCCL's stream ONLY ...
+                    nccl_snaps.append(t.clone())                     # ... and sees what the collective saw
+                return work
             def spy(lo, hi, issue=issue, store=m.flat_storage):
                 snaps.append((lo, hi, store.grad[lo:hi].clone()))   # stream-ordered snapshot at issue time
-                issue(lo, hi)
+                dist.all_reduce = ar_spy
+                try:
+                    if DELAY == 2:
+                        with torch.cuda.stream(broken):              # negative control: RCCL ordered after an EMPTY stream
+                            issue(lo, hi)
+                    else:
+                        issue(lo, hi)
+                finally:
+                    dist.all_reduce = real_ar
                 if DELAY:
                     torch.cuda._sleep(20_000_000)                    # stall the producing stream before the next bucket
             w.reducer._issue = spy
+            fin = w.reducer.finish
+            def fin_spy(fin=fin):
+                torch.cuda.current_stream().wait_stream(side)        # the in-place 1 / world scale must not race the side copies
+                fin()
+            w.reducer.finish = fin_spy
         loss, out = trainer.compute_losses(w, par, inputs.to(dev), cls_label.to(dev), img_box, n_iter, trainer.StepArgs(), cls_label,
                                            inputs_aug=aug if n_iter >= 8000 else None)
         loss.sum().backward()
@@ -188,6 +214,13 @@ for n_iter in (5000, 9000):          # phase B: one forward per student; phase C
         grads.append(m.flat_storage.grad.clone())
     st = m.flat_storage
     covered = torch.zeros_like(grads[0], dtype=torch.bool)
+    assert len(nccl_snaps) == len(snaps) > 0      # bucket_mb 128 > any tiny-model bucket: one all_reduce per plan entry
+    stale = sum(not torch.equal(a, b[2]) for a, b in zip(nccl_snaps, snaps))
+    print("NCCL_STREAM_STALE_BUCKETS", n_iter, stale, "of", len(snaps))
+    if DELAY == 2:
+        assert stale > 0, "the broken-dependency control was not detected: the observation through RCCL's stream proves nothing"
+        continue
+    assert stale == 0, "RCCL's stream read a bucket before the student stream had produced it"
     for lo, hi, snap in snaps:
         # a bucket must be FINAL when it is handed to the all-reduce: nothing may add to it afterwards
         assert torch.equal(snap * 0.5, grads[1][lo:hi]), ("bucket issued before its gradient was final", n_iter, lo, hi)
@@ -231,8 +264,23 @@ def test_bench_contract_line(dev):
         ex = d["exact_f32_path"]
         assert ex["dtype"] == "f32" and 10.0 < ex["value"] < d["value"] and ex["loss"] == ex["loss"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "families", "dual_stream", "single_stream", "configuration"):
         assert k in rf, k
+    # schema 2: the top-level fraction is the timed (two-stream) configuration's, the clean per-launch
+    # figures sit under single_stream, every family of split launches reports flops / ms / frac, COCO 8 img/GPU is timed too
+    assert d["schema"] == 2 and rf["configuration"].startswith("two student streams")
+    assert rf["achieved"] == rf["dual_stream"]["achieved"] and abs(rf["frac"] - rf["dual_stream"]["frac"]) < 1e-3
+    if d["config"]["forward_gemm"] == "f16x3":
+        for where in (rf["families"], rf["single_stream"]["families"]):
+            for fam in ("fwd_f1", "dgrad", "wgrad", "attention_fwd", "attention_bwd"):
+                f = where[fam]
+                assert f["tflop_per_step"] > 0 and f["ms_per_step"] > 0 and 0.02 < f["frac"] < 1.0 and f["launches_per_step"] > 0, (fam, f)
+        fs = rf["single_stream"]["families"]
+        gemm_tf = sum(fs[k]["tflop_per_step"] for k in ("fwd_f1", "fwd_f0", "dgrad", "wgrad") if k in fs)
+        assert 9.0 < gemm_tf < 11.0, gemm_tf          # 4 img/GPU: ~9.9 TFLOP of split GEMMs per step
+    sc = d["second_config"]
+    assert sc["img_per_gpu"] == 8 and sc["num_classes"] == 81 and abs(sc["value"] - 8 * 1000.0 / sc["ms_per_step"]) < 0.05 * sc["value"]
+    assert sc["value"] > 10.0 and "MSCOCO2014" in sc["workload"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     det = bool(d["config"].get("deterministic"))        # no k-split: the weight-gradient launches run on few blocks
     assert (0.02 if det else 0.15) < rf["frac"] < 1.0 and d["value"] > 10.0, (d["value"], rf, r.stderr[-1500:])

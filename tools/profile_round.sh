@@ -14,7 +14,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --single-stream --steps 3 --warmup 1 --cpu-baseline skip --no-exact-f32"
+BENCH="python $R/bench.py --single-stream --steps 3 --warmup 1 --cpu-baseline skip --no-exact-f32 --no-second"
 rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/k -o k -- $BENCH > $OUT/k.log 2>&1
 grep '^{' $OUT/k.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
