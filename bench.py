@@ -279,7 +279,13 @@ class GemmTimer:
             # everything else is a forward Linear / decoder conv, on format 1 (single accumulator) or format 0 planes
             fam = "wgrad" if kw.get("accumulate", False) else ("dgrad" if kw.get("alpha") is not None else
                                                                 ("fwd_f1" if getattr(x, "exp", 0) else "fwd_f0"))
-            return timer._timed("f16x3", lambda: timer._orig16(x, W, *a, **kw), x.rows, W.rows, x.cols, mn_tensors=mn, family=fam)
+            # k-major operands (the backward GEMMs on the forward's planes) are stored [K, rows]; the algorithmic contraction
+            # length of a weight gradient is the token count, not its zero-padded k_pad
+            a_km, b_km = kw.get("a_kmajor", False), kw.get("b_kmajor", False)
+            M_ = x.cols if a_km else x.rows
+            N_ = W.cols if b_km else W.rows
+            K_ = getattr(x, "valid_rows", x.rows) if a_km else x.cols
+            return timer._timed("f16x3", lambda: timer._orig16(x, W, *a, **kw), M_, N_, K_, mn_tensors=mn, family=fam)
 
         def timed_af(qkv16, B, N, H, hd, scale, *a, **kw):      # S = Q K^T and O = P V: 4 N^2 hd per (image, head)
             return timer._timed_family("attention_fwd", lambda: timer._orig_af(qkv16, B, N, H, hd, scale, *a, **kw),

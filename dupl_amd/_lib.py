@@ -35,6 +35,7 @@ class GemmDesc(ctypes.Structure):
 class Gemm16Desc(ctypes.Structure):
     """Mirror of `dupl_gemm16_desc` (include/dupl_hip.h): operands as fp16 hi / lo planes."""
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("reserved0", ctypes.c_int32),
         ("A_hi", ctypes.c_void_p), ("A_lo", ctypes.c_void_p), ("B_hi", ctypes.c_void_p), ("B_lo", ctypes.c_void_p),
         ("C", ctypes.c_void_p), ("C_hi", ctypes.c_void_p), ("C_lo", ctypes.c_void_p),
         ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p), ("aux", ctypes.c_void_p),
@@ -44,7 +45,28 @@ class Gemm16Desc(ctypes.Structure):
         ("flags", ctypes.c_int32), ("c_rows", ctypes.c_int32),
         ("alpha_dev", ctypes.c_void_p), ("fmt", ctypes.c_int32), ("out_exp", ctypes.c_int32), ("post_scale", ctypes.c_float),
         ("amax_out", ctypes.c_void_p),
+        ("a_layout", ctypes.c_int32), ("b_layout", ctypes.c_int32), ("ka_valid", ctypes.c_int32), ("kb_valid", ctypes.c_int32),
+        ("tile", ctypes.c_int32), ("concurrency", ctypes.c_int32), ("persist_blocks", ctypes.c_int32), ("group", ctypes.c_int32),
     ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = ctypes.sizeof(Gemm16Desc)
+
+
+class SplitDesc(ctypes.Structure):
+    """Mirror of `dupl_split_desc` (include/dupl_hip.h)."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("ld", ctypes.c_int32), ("R", ctypes.c_int32), ("C", ctypes.c_int32),
+        ("x", ctypes.c_void_p), ("slot", ctypes.c_void_p), ("next_bits", ctypes.c_void_p),
+        ("hi", ctypes.c_void_p), ("lo", ctypes.c_void_p), ("hiT", ctypes.c_void_p), ("loT", ctypes.c_void_p),
+        ("Rp", ctypes.c_int32), ("target_exp", ctypes.c_int32), ("colsum_accum", ctypes.c_void_p),
+        ("amax_mode", ctypes.c_int32), ("fmt", ctypes.c_int32), ("rows_zero_to", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+    ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = ctypes.sizeof(SplitDesc)
 
 
 GEMM_A_MCONTIG, GEMM_B_NCONTIG, GEMM_GELU, GEMM_ACCUM = 1, 2, 4, 8
@@ -68,6 +90,8 @@ def _ctype(decl: str):
         return None
     if "dupl_gemm16_desc" in d:
         return ctypes.POINTER(Gemm16Desc)
+    if "dupl_split_desc" in d:
+        return ctypes.POINTER(SplitDesc)
     if "dupl_gemm_desc" in d:
         return ctypes.POINTER(GemmDesc)
     if "*" in d or d.startswith("dupl_stream_t"):
@@ -136,6 +160,4 @@ def lib() -> _Lib:
         _LIB = _Lib()
         if os.environ.get("DUPL_DETERMINISTIC", "0") == "1":
             _LIB.dupl_set_deterministic(1)
-        if os.environ.get("DUPL_GEMM16_TILE"):          # tuning / A-B runs: force one tile of the split GEMM (0 = heuristic)
-            _LIB.dupl_set_gemm16_tile(int(os.environ["DUPL_GEMM16_TILE"]))
     return _LIB

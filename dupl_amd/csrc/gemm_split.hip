@@ -391,7 +391,7 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
 // side buffer, 8 rows x 64 columns at a time (4 WM passes: MFMA tile i, register group g = rows 8 g .. 8 g + 7 of it).
 // Same access pattern as gemm16_epilogue_lds (b32 writes of 32 consecutive floats, b128 reads of whole 256-byte rows ->
 // float4 global accesses); in-order LDS execution within the wave orders the passes.
-template <int WM, int WN, bool ACC = false, bool SINGLE = false>
+template <int WM, int WN, bool ACC = false, bool SINGLE = false, bool ATOM = true>
 __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, f32x16 (&accM)[WM][WN],
                                                      f32x16 (&accX)[SINGLE ? 1 : WM][SINGLE ? 1 : WN],
                                                      float* __restrict__ side, const int mw, const int nw, const int lane,
@@ -430,7 +430,11 @@ __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, 
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
                         const int row = mw + i * 32 + 8 * g + r;
-                        if (row < p.M) unsafeAtomicAdd(p.C + (size_t)row * p.ldc + nw + lane, side[r * 64 + lane]);
+                        if (row < p.M) {
+                            float* cp = p.C + (size_t)row * p.ldc + nw + lane;
+                            if constexpr (ATOM) unsafeAtomicAdd(cp, side[r * 64 + lane]);
+                            else *cp += side[r * 64 + lane];      // one block owns the whole tile and all of K: fixed order
+                        }
                     }
                 }
             } else {
@@ -1094,20 +1098,379 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_pring_kernel(c
                           NWM * NWN);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Layout-general single-accumulator kernel (round 4): the persistent 3-stage ring kernel for format 1 operands whose A and / or
+// B operand may be stored K-MAJOR -- [K][rows] with the rows contiguous, i.e. the contraction index is the slow one.  That is
+// how the backward's operands lie in memory anyway:
+//   dgrad  dx[M][Kin] = dy[M][Nout] . W[Nout][Kin]        A = dy planes (k-contiguous), B = the forward's W planes, k-major
+//   wgrad  dW[Nout][Kin] += dy[M][Nout]^T . x[M][Kin]     A = dy planes, k-major;       B = the forward's x planes, k-major
+// so no transposed operand planes are built any more (split_rt's transposing outputs, the per-step W^T planes, the fp32 copies
+// of ln1 / ln2 / h1 that existed only to be transposed).
+// The MFMA fragment (lane = row l & 31, 8 consecutive k at 8 (l >> 5)) of a k-major operand is gathered by ds_read_b64_tr_b16: a
+// 16-lane group reads a [4 k][16 rows] block -- lane p supplies the address of k-row (p >> 2), rows 4 (p & 3) .. + 3 -- and
+// receives it transposed, lane p = row p, 4 consecutive k; two such reads (k + 0..3, k + 4..7) make the 8-half fragment.  The LDS
+// image of a k-major k-tile is built for that gather (on the SOURCE side of the DMA, whose LDS side is lane-linear): 512-byte
+// subtiles [8 keys][32 rows], the 8 keys being the two groups of 4 that one instruction reads, so that every instruction reads
+// one contiguous subtile.
+// Rows of a k-major operand beyond its k_valid are clamped to the last valid row (finite garbage): the OTHER operand must hold
+// zeros there (the scaled gradient planes are written zero-padded to K, dupl_split_prepare rows_zero_to).
+// SK: stream-K over (tile, k-step) as in gemm_f16x3_pring_kernel, pieces meet in fp32 atomics (ACC 1); ACC 2: C += tile by the one
+// block that owns the tile (deterministic mode); ACC 0: the full epilogue (bias / activation / aux / planes / amax).
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// phase B of the k-major kernel: NR read instructions and ND DMA pieces alternate, the rarer kind spread over the other
+constexpr bool slot_is_read(int S, int NR, int ND) {
+    int rd = 0, dd = 0;
+    for (int s = 0;; ++s) {
+        const bool r = rd < NR && (dd >= ND || rd * ND <= dd * NR);
+        if (s == S) return r;
+        if (r) ++rd; else ++dd;
+    }
+}
+constexpr int slot_index(int S, int NR, int ND) {
+    int rd = 0, dd = 0;
+    for (int s = 0;; ++s) {
+        const bool r = rd < NR && (dd >= ND || rd * ND <= dd * NR);
+        if (s == S) return r ? rd : dd;
+        if (r) ++rd; else ++dd;
+    }
+}
+
+template <int WM, int WN, int NWM, int NWN, int WPS, bool SK, int ACC, bool AKM, bool BKM, int STAGES = 3>
+__global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_km_kernel(const dupl_gemm16_desc p, const int g_gm) {
+    constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, NW = NWM * NWN;
+    constexpr int PA = BM / 16, PB = BN / 16;
+    constexpr int NP = 2 * PA + 2 * PB;
+    constexpr int STAGE = NP * 1024;
+    constexpr int PPW = NP / NW;
+    constexpr int APW = 2 * PA / NW;                       // this wave's first APW pieces belong to A, the rest to B
+    constexpr int RBA = 2 * BM, RBB = 2 * BN;              // bytes per k-row of a k-major plane image
+    constexpr int NDA = AKM ? 2 : 1, NDB = BKM ? 2 : 1;    // LDS read instructions per fragment
+    constexpr int NIA = 2 * WM * NDA, NIB = 2 * WN * NDB;  // ... per k-step and operand
+    constexpr int NRI = NIA + NIB;
+    constexpr int NMF = 3 * WM * WN;
+    constexpr int SIDE = NW * 2048;
+    static_assert(NP % NW == 0 && (2 * PA) % NW == 0, "pieces must divide over the waves, operand by operand");
+    static_assert(STAGES * STAGE + SIDE <= 160 * 1024, "LDS");
+    static_assert(1024 % RBA == 0 && 1024 % RBB == 0, "whole k-rows per DMA piece");
+    static_assert(!SK || ACC == 1, "stream-K pieces meet in atomics");
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE + SIDE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nblk = nbm * nbn;
+    const int ntf = p.K / TBK;                    // k-steps of a whole tile, >= STAGES (host)
+    int nt = ntf;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int gspan = g_gm * nbn;
+    auto lid_origin = [&](const int lid, int& m0, int& n0) __attribute__((always_inline)) {
+        const int gid = lid / gspan, gin = lid - gid * gspan;
+        const int gfirst = gid * g_gm;
+        const int gsz = min(nbm - gfirst, g_gm);
+        m0 = (gfirst + gin % gsz) * BM;
+        n0 = (gin / gsz) * BN;
+    };
+    auto tile_origin = [&](const int bid, int& m0, int& n0) __attribute__((always_inline)) {
+        const int xcd = bid & 7, idx = bid >> 3;
+        lid_origin((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx, m0, n0);
+    };
+    auto has_tile = [&](const int bid) { return (bid >> 3) < q8 + ((bid & 7) < r8 ? 1 : 0); };
+
+    // ---- DMA plan.  k-contiguous operand: as in the ring kernel (16-row x 64-byte pieces, chunk ^ ((row >> 2) & 3)), gp walks
+    // along k.  k-major operand: piece q = k-rows q RPP .. of the tile; lane -> (k-row, physical 16-byte chunk); gp holds the
+    // column address in k-row 0 of the operand, the k-row is added (clamped to k_valid - 1) at issue time.
+    const int ka_valid = p.ka_valid > 0 ? p.ka_valid : p.K, kb_valid = p.kb_valid > 0 ? p.kb_valid : p.K;
+    const char* gp[PPW];
+    int prow[PPW];
+    int kt = 0;                                   // next k-tile to fetch
+    auto plan = [&](const int m0, const int n0, const int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int g = wave + NW * i;
+            const bool isA = i < APW;
+            const int gg = isA ? g : g - 2 * PA;
+            const int PO = isA ? PA : PB;
+            const bool lo = gg >= PO;
+            const int q = lo ? gg - PO : gg;
+            const __half* plane = static_cast<const __half*>(isA ? (lo ? p.A_lo : p.A_hi) : (lo ? p.B_lo : p.B_hi));
+            const int ld = isA ? p.lda : p.ldb, r0 = isA ? m0 : n0, R = isA ? p.M : p.N;
+            const bool km = isA ? AKM : BKM;
+            if (!km) {
+                const int pr = lane >> 2;
+                const int jsrc = (lane & 3) ^ ((pr >> 2) & 3);
+                const int row = min(r0 + q * 16 + pr, R - 1);
+                gp[i] = reinterpret_cast<const char*>(plane + (size_t)row * ld + (size_t)k0 * TBK) + jsrc * 16;
+                prow[i] = 0;
+            } else {
+                // LDS image of a k-major plane: [4 key groups kk][BM / 32 row blocks][8 keys][32 rows] halfs = 512-byte subtiles;
+                // key group kk = (k >> 4) * 2 + ((k >> 2) & 1) holds keys {16 ks + 4 jj + 0..3} and {16 ks + 8 + 4 jj + 0..3} -- exactly
+                // what ONE ds_read_b64_tr_b16 of k-step ks, half jj gathers -- in subtile rows ((k >> 3) & 1) * 4 + (k & 3), so that
+                // the 64 lanes of an instruction read one contiguous 512-byte subtile (conflict-free; a [k][rows] image with
+                // a row pitch of 512 / 256 bytes is not, whatever XOR is applied to it)
+                const int NBLK = (isA ? BM : BN) / 32;
+                const int off = q * 1024 + lane * 16;                  // byte offset inside the plane image
+                const int sub = off >> 9, srow = (off >> 6) & 7, c = (off >> 4) & 3;
+                const int kk = sub / NBLK, mblk = sub - kk * NBLK;
+                const int r = (kk >> 1) * 16 + (srow >> 2) * 8 + (kk & 1) * 4 + (srow & 3);      // k-row inside the k-tile, 0 .. 31
+                const int col = min(r0 + mblk * 32 + c * 8, R - 8);      // R % 8 == 0 (host): the last whole chunk
+                gp[i] = reinterpret_cast<const char*>(plane + col);
+                prow[i] = r;
+            }
+        }
+        kt = k0;
+    };
+    auto dma_piece = [&](const int i, char* dst) __attribute__((always_inline)) {
+        const bool km = (i < APW) ? AKM : BKM;
+        if (!km) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[i],
+                                             (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
+            gp[i] += TBK * 2;
+        } else {
+            const int kv = (i < APW) ? ka_valid : kb_valid;
+            const int ld = (i < APW) ? p.lda : p.ldb;
+            const int krow = min(kt * TBK + prow[i], kv - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[i] + (size_t)krow * ld * 2),
+                                             (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        char* dst = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(i, dst);
+        ++kt;
+    };
+
+    // ---- fragment addresses (bytes inside a stage)
+    const int sw = (l31 >> 2) & 3;
+    const int a_row = (wm * (32 * WM) + l31) * 64, b_row = 2 * PA * 1024 + (wn * (32 * WN) + l31) * 64;
+    const int c0 = ((0 | hf) ^ sw) * 16, c1 = ((2 | hf) ^ sw) * 16;
+    // k-major: lane (g = lane >> 4, q = lane & 15) of the read (k-step ks, half jj) takes subtile row (g >> 1) * 4 + (q >> 2), rows
+    // 16 (g & 1) + 4 (q & 3) .. + 3 of the 32-row block wm WM + i, in subtile (ks * 2 + jj) * (BM / 32) + block: one base per lane,
+    // everything else is an immediate offset
+    const int g4 = lane >> 4, q15 = lane & 15;
+    const int kml = ((g4 >> 1) * 4 + (q15 >> 2)) * 64 + (16 * (g4 & 1) + 4 * (q15 & 3)) * 2;
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);      // LDS byte address of stage 0
+    const unsigned akm0 = lds0 + kml + wm * WM * 512, bkm0 = lds0 + 2 * PA * 1024 + kml + wn * WN * 512;
+
+    f32x16 acc[WM][WN];
+    f32x16 accX_unused[1][1];
+    // fragments as 4-half halves: [2 t], [2 t + 1] = k 0..3 / 4..7 of fragment t; t < W: hi plane, t >= W: lo plane
+    h4 f0a[4 * WM], f0b[4 * WN], f1a[4 * WM], f1b[4 * WN];
+    // The transposing reads are INLINE ASM: behind a direct-to-LDS DMA hipcc puts `s_waitcnt vmcnt(0)` in front of every
+    // ds_read_b64_tr_b16 it issues itself (the builtin carries no alias information, so every LDS-DMA in flight "may" feed it) --
+    // that drains the two-tiles-ahead DMA ring once per read (measured: 87 instead of 165 TF/s-eq).  The ring's own protocol
+    // (counted vmcnt + barrier before a stage is read, lgkmcnt(0) + barrier before it is overwritten) already orders them; what the
+    // compiler no longer does for these reads is wait for their RESULTS, so every consumer phase starts with an explicit
+    // lgkmcnt(0) (LDS operations return in order: waits the compiler computes for its own reads can only become stricter).
+    auto tr_read = [](const unsigned addr, auto offc) __attribute__((always_inline)) {
+        h4 v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(offc)::value) : "memory");
+        return v;
+    };
+    // one LDS read instruction: RI-th of the A / B operand (KS = k-step inside the tile); st = stage pointer, so = its byte offset
+    auto read_a = [&](auto ric, auto ksc, const char* st, const unsigned so, h4(&fa)[4 * WM]) __attribute__((always_inline)) {
+        constexpr int RI = decltype(ric)::value, KS = decltype(ksc)::value;
+        if constexpr (!AKM) {
+            constexpr int t = RI;
+            const h8 v = *reinterpret_cast<const h8*>(st + (t < WM ? 0 : PA * 1024) + a_row + (t % WM) * 2048 + (KS ? c1 : c0));
+            fa[2 * t] = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+            fa[2 * t + 1] = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+        } else {
+            constexpr int t = RI / 2, half = RI % 2;
+            fa[2 * t + half] = tr_read(akm0 + so, std::integral_constant<int, (t < WM ? 0 : PA * 1024) + ((KS * 2 + half) * (BM / 32) + (t % WM)) * 512>{});
+        }
+    };
+    auto read_b = [&](auto ric, auto ksc, const char* st, const unsigned so, h4(&fb)[4 * WN]) __attribute__((always_inline)) {
+        constexpr int RI = decltype(ric)::value, KS = decltype(ksc)::value;
+        if constexpr (!BKM) {
+            constexpr int t = RI;
+            const h8 v = *reinterpret_cast<const h8*>(st + (t < WN ? 0 : PB * 1024) + b_row + (t % WN) * 2048 + (KS ? c1 : c0));
+            fb[2 * t] = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+            fb[2 * t + 1] = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+        } else {
+            constexpr int t = RI / 2, half = RI % 2;
+            fb[2 * t + half] = tr_read(bkm0 + so, std::integral_constant<int, (t < WN ? 0 : PB * 1024) + ((KS * 2 + half) * (BN / 32) + (t % WN)) * 512>{});
+        }
+    };
+    // R-th read instruction of a k-step (A's first, then B's)
+    auto read_r = [&](auto rc, auto ksc, const char* st, const unsigned so, h4(&fa)[4 * WM], h4(&fb)[4 * WN]) __attribute__((always_inline)) {
+        constexpr int R = decltype(rc)::value;
+        if constexpr (R < NIA) read_a(std::integral_constant<int, R>{}, ksc, st, so, fa);
+        else read_b(std::integral_constant<int, R - NIA>{}, ksc, st, so, fb);
+    };
+    auto read_frags = [&](auto ksc, const int rbuf, h4(&fa)[4 * WM], h4(&fb)[4 * WN]) __attribute__((always_inline)) {
+        static_for<NRI>([&](auto rc) __attribute__((always_inline)) { read_r(rc, ksc, smem + rbuf * STAGE, (unsigned)(rbuf * STAGE), fa, fb); });
+    };
+    auto frag = [](const h4 lo, const h4 hi) __attribute__((always_inline)) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); };
+    // n-th MFMA of a k-step: three passes (main, hi x lo, lo x hi) over the WM x WN tiles, an accumulator is touched once per pass
+    auto mfma_n = [&](auto nc, const h8(&A)[2 * WM], const h8(&B)[2 * WN]) __attribute__((always_inline)) {
+        constexpr int n = decltype(nc)::value, pass = n / (WM * WN), idx = n % (WM * WN), i = idx / WN, j = idx % WN;
+        if constexpr (pass == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
+        else if constexpr (pass == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[WN + j], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[WM + i], B[j], acc[i][j], 0, 0, 0);
+    };
+    // A phase = the NMF MFMAs of one k-step on fragments (fa, fb), with NS load slots spread evenly between them IN THIS ORDER:
+    // the instruction stream is written out slot by slot and pinned (sched_barrier(0)), since issue-order hints cannot see the
+    // inline-asm reads
+    auto phase = [&](auto nsc, const h4(&fa)[4 * WM], const h4(&fb)[4 * WN], auto&& slot) __attribute__((always_inline)) {
+        constexpr int NS = decltype(nsc)::value;
+        h8 A[2 * WM], B[2 * WN];
+#pragma unroll
+        for (int t = 0; t < 2 * WM; ++t) A[t] = frag(fa[2 * t], fa[2 * t + 1]);
+#pragma unroll
+        for (int t = 0; t < 2 * WN; ++t) B[t] = frag(fb[2 * t], fb[2 * t + 1]);
+        if constexpr (NS == 0) {
+            static_for<NMF>([&](auto nc) __attribute__((always_inline)) { mfma_n(nc, A, B); });
+        } else {
+            static_for<NS>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int S = decltype(sc)::value, n0 = S * NMF / NS, n1 = (S + 1) * NMF / NS;
+                static_for<n1 - n0>([&](auto kc) __attribute__((always_inline)) { mfma_n(std::integral_constant<int, n0 + decltype(kc)::value>{}, A, B); });
+                slot(sc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    };
+    constexpr std::integral_constant<int, 0> KS0{};
+    constexpr std::integral_constant<int, 1> KS1{};
+    constexpr int LGKM0 = 0xC07F;        // s_waitcnt lgkmcnt(0), vmcnt / expcnt untouched
+
+    int bid = blockIdx.x;
+    int pos = 0, pend = 0;
+    int m0, n0;
+    if constexpr (SK) {
+        const int T = nblk * ntf, G = gridDim.x;
+        const int L = (bid & 7) * (G >> 3) + (bid >> 3);
+        auto cut = [&](const int l) {
+            int x = (int)((long)T * l / G);
+            const int r = x % ntf;
+            if (r && r < 3) x -= r;
+            else if (r > ntf - 3) x += ntf - r;
+            return x;
+        };
+        pos = cut(L);
+        pend = cut(L + 1);
+        if (pos >= pend) return;
+        const int lid = pos / ntf, k0 = pos - lid * ntf;
+        nt = min(pend - pos, ntf - k0);
+        lid_origin(lid, m0, n0);
+        plan(m0, n0, k0);
+    } else {
+        if (!has_tile(bid)) return;
+        tile_origin(bid, m0, n0);
+        plan(m0, n0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s) issue(s);
+    bool first = true;
+    float amx = 0.f;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(KS0, 0, f0a, f0b);
+        int rb = 0;
+        int t = 0;
+        for (; t + STAGES < nt; ++t) {
+            const int nb = rb + 1 == STAGES ? 0 : rb + 1;
+            const char* st = smem + rb * STAGE;
+            const unsigned so = (unsigned)(rb * STAGE), son = (unsigned)(nb * STAGE);
+            __builtin_amdgcn_s_waitcnt(LGKM0);                       // F0(t) has landed
+            // phase A: read F1(t) | MFMAs on F0(t)
+            phase(std::integral_constant<int, NRI>{}, f0a, f0b, [&](auto sc) __attribute__((always_inline)) { read_r(sc, KS1, st, so, f1a, f1b); });
+            __builtin_amdgcn_s_waitcnt(WAIT_LGKM0_VM((STAGES - 2) * PPW));   // F1(t) landed; my pieces of tile t+1 landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // phase B: read F0(t+1), DMA tile t+3 -> stage rb (alternating) | MFMAs on F1(t)
+            char* dst = smem + rb * STAGE + wave * 1024;
+            phase(std::integral_constant<int, NRI + PPW>{}, f1a, f1b, [&](auto sc) __attribute__((always_inline)) {
+                constexpr int S = decltype(sc)::value;
+                if constexpr (slot_is_read(S, NRI, PPW)) read_r(std::integral_constant<int, slot_index(S, NRI, PPW)>{}, KS0, smem + nb * STAGE, son, f0a, f0b);
+                else {
+                    constexpr int I = slot_index(S, NRI, PPW);
+                    dma_piece(I, dst);
+                    if constexpr (I == PPW - 1) ++kt;
+                }
+            });
+            rb = nb;
+        }
+        for (; t < nt; ++t) {
+            const int nb = rb + 1 == STAGES ? 0 : rb + 1;
+            const char* st = smem + rb * STAGE;
+            const unsigned so = (unsigned)(rb * STAGE), son = (unsigned)(nb * STAGE);
+            __builtin_amdgcn_s_waitcnt(LGKM0);
+            phase(std::integral_constant<int, NRI>{}, f0a, f0b, [&](auto sc) __attribute__((always_inline)) { read_r(sc, KS1, st, so, f1a, f1b); });
+            if (t + 1 < nt) {
+                __builtin_amdgcn_s_waitcnt(WAIT_LGKM0_VM(0));
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                phase(std::integral_constant<int, NRI>{}, f1a, f1b, [&](auto sc) __attribute__((always_inline)) { read_r(sc, KS0, smem + nb * STAGE, son, f0a, f0b); });
+            } else {
+                __builtin_amdgcn_s_waitcnt(LGKM0);
+                phase(std::integral_constant<int, 0>{}, f1a, f1b, [](auto) {});
+            }
+            rb = nb;
+        }
+        // every wave has left the k-loop -> the stages are free: start the next tile's pipeline, then write this tile out
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int mw = m0 + wm * (32 * WM), nw = n0 + wn * (32 * WN);
+        bool more;
+        if constexpr (SK) {
+            pos += nt;
+            more = pos < pend;
+            if (more) {
+                nt = min(pend - pos, ntf);
+                lid_origin(pos / ntf, m0, n0);
+                plan(m0, n0, 0);
+            }
+        } else {
+            bid += gridDim.x;
+            more = has_tile(bid);
+            if (more) {
+                tile_origin(bid, m0, n0);
+                plan(m0, n0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < STAGES; ++s) issue(s);
+        }
+        gemm16_epilogue_side<WM, WN, ACC != 0, true, ACC == 1>(p, acc, accX_unused, reinterpret_cast<float*>(smem + STAGES * STAGE) + wave * 512,
+                                                               mw, nw, lane, amx);
+        if (!more) break;
+    }
+    if (p.amax_out)
+        gemm16_amax_flush(static_cast<unsigned int*>(p.amax_out), amx, reinterpret_cast<float*>(smem + STAGES * STAGE), wave, lane,
+                          NWM * NWN);
+}
+
 }  // namespace
 
-static int g16_group_m = 8;
-static int g16_group_ring = 2;   // row tiles (256 rows) per group of the ring kernel's block order: 512-row A bands stay in an
-                                  // XCD's L2 while it sweeps the columns (2 / 3: 320, 4: 312, 8: 304, 16: 285 TF/s-eq on 15696 x 3072 x 768)
-static int g16_persist_blocks_set = 0;  // blocks of the persistent kernels (a multiple of 8: a block keeps its XCD); 0 = auto:
-                                        // one per CU alone; 192 when a second stream feeds the chip as well -- the kernel is power-bound
-                                        // (176 .. 208 blocks run a GEMM as fast as 256: fewer CUs, higher clock), and the CUs left over
-                                        // let the other student's kernels in earlier (step 61.55 -> 61.0 ms, same box; 128: 63.5)
-#define g16_persist_blocks (g16_persist_blocks_set ? g16_persist_blocks_set : (g16_concurrency >= 2 ? 192 : 256))
-static int g16_f1_big_from = 96;  // format 1: 256 x 256 tiles from this many of them
-static int g16_concurrency = 1;  // how many streams feed split GEMMs at a time (dupl_set_gemm16_concurrency)
-static int g16_tile = 0;     // 0 = heuristic; 3: 128x64 on 4 waves; 5: 128x128 on 8 waves (wave tile 64x32 in both).  Measured
-                             // and dropped: 64x64 wave tiles on 4 / 8 waves (2 waves / SIMD: -10..25 %), 256x128 on 16 waves
+// Launch tuning travels in the descriptor (dupl_gemm16_desc.tile / concurrency / persist_blocks / group; 0 = these defaults):
+// nothing about kernel selection is process-global, the library is re-entrant per call.
+constexpr int G16_GROUP_M = 8;      // 128-row tile kernels
+constexpr int G16_GROUP_RING = 2;   // row tiles (256 rows) per group of the ring kernels' block order: 512-row A bands stay in an
+                                    // XCD's L2 while it sweeps the columns (2 / 3: 320, 4: 312, 8: 304, 16: 285 TF/s-eq on 15696 x 3072 x 768)
+constexpr int G16_F1_BIG_FROM = 96; // format 1: 256 x 256 tiles from this many of them
 
 extern "C" int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, dupl_stream_t stream) {
     (void)hipGetLastError();
@@ -1134,35 +1497,22 @@ extern "C" int dupl_split_f16x2b(const float* x, void* hi, void* lo, int64_t n, 
     return dupl_launch_status();
 }
 
-extern "C" int dupl_set_gemm16_group(int32_t gm) {
-    if (gm < 1 || gm > 4096) return DUPL_ERR_ARG;
-    g16_group_m = gm;
-    g16_group_ring = gm;
-    return DUPL_OK;
-}
-
-extern "C" int dupl_set_gemm16_concurrency(int32_t n) {
-    if (n < 1 || n > 8) return DUPL_ERR_ARG;
-    g16_concurrency = n;
-    return DUPL_OK;
-}
-
-extern "C" int dupl_set_gemm16_persist_blocks(int32_t n) {
-    if (n != 0 && (n < 8 || n > 1024 || (n & 7))) return DUPL_ERR_ARG;
-    g16_persist_blocks_set = n;
-    return DUPL_OK;
-}
-
-extern "C" int dupl_set_gemm16_tile(int32_t t) {
-    if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 10 && t != 11 && t != 12 && t != 14) return DUPL_ERR_ARG;
-    g16_tile = t;
-    return DUPL_OK;
-}
-
 extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) {
     (void)hipGetLastError();
-    if (!d || !d->A_hi || !d->A_lo || !d->B_hi || !d->B_lo || d->M <= 0 || d->N <= 0 || d->K <= 0) return DUPL_ERR_ARG;
+    if (!d || d->struct_size != sizeof(dupl_gemm16_desc)) return DUPL_ERR_ARG;      // a caller built against another header
+    if (!d->A_hi || !d->A_lo || !d->B_hi || !d->B_lo || d->M <= 0 || d->N <= 0 || d->K <= 0) return DUPL_ERR_ARG;
     if ((d->K % TBK) || (d->lda % 8) || (d->ldb % 8)) return DUPL_ERR_ARG;       // whole 16-byte chunks, whole k-tiles
+    if (d->tile < 0 || d->concurrency < 0 || d->concurrency > 8 || d->group < 0 || d->group > 4096 || d->persist_blocks < 0 ||
+        d->persist_blocks > 1024 || (d->persist_blocks & 7))
+        return DUPL_ERR_ARG;
+    {
+        const int t = d->tile;
+        if (t != 0 && t != 3 && t != 5 && t != 6 && t != 7 && t != 8 && t != 10 && t != 11 && t != 12 && t != 14) return DUPL_ERR_ARG;
+    }
+    const int g16_tile = d->tile, g16_concurrency = d->concurrency > 0 ? d->concurrency : 1;
+    const int g16_persist_blocks = d->persist_blocks ? d->persist_blocks : (g16_concurrency >= 2 ? 192 : 256);
+    const int g16_group_m = d->group ? d->group : G16_GROUP_M, g16_group_ring = d->group ? d->group : G16_GROUP_RING;
+    const int g16_f1_big_from = G16_F1_BIG_FROM;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (!al16(d->A_hi) || !al16(d->A_lo) || !al16(d->B_hi) || !al16(d->B_lo)) return DUPL_ERR_ARG;
     if (!d->C && !d->C_hi) return DUPL_ERR_ARG;
@@ -1175,7 +1525,9 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
     if (accum && (!d->C || d->C_hi || d->bias || d->res || d->c_rows)) return DUPL_ERR_ARG;   // C += alpha * A B^T, nothing else
     if (d->c_rows < 0 || (d->c_rows && (d->flags & (DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK)))) return DUPL_ERR_ARG;
     if (d->amax_out && (accum || d->c_rows || (reinterpret_cast<uintptr_t>(d->amax_out) & 3))) return DUPL_ERR_ARG;
-    if (d->fmt < 0 || d->fmt > 1 || d->out_exp < 0 || d->out_exp > 15 || (d->out_exp && d->fmt != 1) || (d->fmt == 1 && (accum || d->amax_out)))
+    const bool kmajor = d->a_layout || d->b_layout;
+    if (d->fmt < 0 || d->fmt > 1 || d->out_exp < 0 || d->out_exp > 15 || (d->out_exp && d->fmt != 1) ||
+        (d->fmt == 1 && !kmajor && (accum || d->amax_out)))
         return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     // split-K for accumulating GEMMs (weight gradients: few output tiles, K = all tokens): >= ~2 blocks per CU,
@@ -1214,6 +1566,26 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         const int rounds = (tx + bmax - 1) / bmax;
         return dim3((unsigned)(8 * ((tx + rounds - 1) / rounds)));
     };
+    if (d->a_layout < 0 || d->a_layout > 1 || d->b_layout < 0 || d->b_layout > 1 || d->ka_valid < 0 || d->kb_valid < 0) return DUPL_ERR_ARG;
+    if (d->a_layout || d->b_layout) {
+        // k-major operand(s): the backward GEMMs on the forward's own planes (gemm_f16x3_km_kernel; 256 x 128, persistent)
+        if (d->fmt != 1 || d->K / TBK < 3) return DUPL_ERR_ARG;
+        if ((d->a_layout && ((d->M & 7) || d->M < 8)) || (d->b_layout && ((d->N & 7) || d->N < 8))) return DUPL_ERR_ARG;
+        if ((d->a_layout ? d->ka_valid : 0) > d->K || (d->b_layout ? d->kb_valid : 0) > d->K) return DUPL_ERR_ARG;
+        if (!d->a_layout && d->ka_valid) return DUPL_ERR_ARG;
+        if (!d->b_layout && d->kb_valid) return DUPL_ERR_ARG;
+        const int nb21 = ((d->M + 255) / 256) * ((d->N + 127) / 128);
+        const bool sk = accum && !g_dupl_deterministic && ksplit > 1;
+        if (accum) {
+            if (!(d->a_layout && d->b_layout)) return DUPL_ERR_ARG;            // the weight gradient: both operands token-major
+            if (sk) hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, true, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d, g16_group_ring);
+            else hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 2, true, true>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
+        } else {
+            if (d->a_layout || !d->b_layout) return DUPL_ERR_ARG;              // the data gradient: dy k-contiguous, W k-major
+            hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 0, false, true>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
+        }
+        return dupl_launch_status();
+    }
     if (d->fmt == 1) {
         // format 1 operands: one accumulator set.  256 x 256 on 8 waves (wave tile 128 x 64, two LDS stages of 64 KB; tile 8) where
         // the grid fills the chip, 256 x 128 (the ring kernel's tile with half the accumulators; 12) below.  One block per tile: the

@@ -49,10 +49,11 @@ __device__ __forceinline__ void scale_from_amax(unsigned int bits, int target, f
 // (optional; rows R .. Rp-1 of the transposed image are written as zeros).  scale: device float or NULL (= 1).
 // slot (scaled tensors): {scale, 1 / scale, amax bits, -} in device memory; next_bits: the amax word of the ring slot the
 // NEXT scaled tensor on this stream will use, zeroed here (stream order makes that safe) so that no memset node is needed.
+template <bool F1 = false>
 __device__ __forceinline__ void split_rt_tile(const float* __restrict__ x, const int ld, const int R, const int C, const float s,
                                               __half* __restrict__ hi, __half* __restrict__ lo, __half* __restrict__ hiT,
                                               __half* __restrict__ loT, const int Rp, float* __restrict__ colsum, const int r0,
-                                              const int c0) {
+                                              const int c0, const int Rz = 0) {
     __shared__ unsigned int tile[64][65];            // (hi | lo << 16) per element; odd stride: conflict-free both ways
     __shared__ float csum[4][64];
     const int tid = threadIdx.x;
@@ -66,11 +67,19 @@ __device__ __forceinline__ void split_rt_tile(const float* __restrict__ x, const
         if (in) v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + r) * ld + c0 + cc);
         cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
         __half h[4], l[4];
-        split_f32(v.x * s, h[0], l[0]);
-        split_f32(v.y * s, h[1], l[1]);
-        split_f32(v.z * s, h[2], l[2]);
-        split_f32(v.w * s, h[3], l[3]);
-        if (hi && in) {
+        if constexpr (F1) {
+            split_f32_u(v.x * s, h[0], l[0]);
+            split_f32_u(v.y * s, h[1], l[1]);
+            split_f32_u(v.z * s, h[2], l[2]);
+            split_f32_u(v.w * s, h[3], l[3]);
+        } else {
+            split_f32(v.x * s, h[0], l[0]);
+            split_f32(v.y * s, h[1], l[1]);
+            split_f32(v.z * s, h[2], l[2]);
+            split_f32(v.w * s, h[3], l[3]);
+        }
+        // row-major planes: rows < R, and zeros in rows R .. Rz - 1 (v = 0 there)
+        if (hi && c0 + cc < C && r0 + r < (Rz > R ? Rz : R)) {
             *reinterpret_cast<uint2*>(hi + (size_t)(r0 + r) * C + c0 + cc) = *reinterpret_cast<const uint2*>(h);
             *reinterpret_cast<uint2*>(lo + (size_t)(r0 + r) * C + c0 + cc) = *reinterpret_cast<const uint2*>(l);
         }
@@ -117,10 +126,11 @@ __device__ __forceinline__ void split_rt_tile(const float* __restrict__ x, const
     }
 }
 
+template <bool F1>
 __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__ x, int ld, int R, int C, float* __restrict__ slot,
                                                        unsigned int* __restrict__ next_bits, __half* __restrict__ hi,
                                                        __half* __restrict__ lo, __half* __restrict__ hiT, __half* __restrict__ loT,
-                                                       int Rp, int target, float* __restrict__ colsum) {
+                                                       int Rp, int target, float* __restrict__ colsum, int Rz) {
     float s = 1.f;
     if (slot) {
         float inv;
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256) void split_rt_kernel(const float* __restrict__
             if (next_bits) *next_bits = 0u;
         }
     }
-    split_rt_tile(x, ld, R, C, s, hi, lo, hiT, loT, Rp, colsum, blockIdx.y * 64, blockIdx.x * 64);
+    split_rt_tile<F1>(x, ld, R, C, s, hi, lo, hiT, loT, Rp, colsum, blockIdx.y * 64, blockIdx.x * 64, Rz);
 }
 
 // Several unscaled matrices in one launch (dupl_split_prepare_multi): block b works on tile b - first[i] of item i
@@ -175,30 +185,19 @@ extern "C" int dupl_split_prepare_multi(const dupl_split_item* items, int32_t n,
     return dupl_launch_status();
 }
 
-extern "C" int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
-                                   void* lo, void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum,
-                                   int32_t amax_mode, dupl_stream_t stream);
-
-extern "C" int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
-                                  void* hiT, void* loT, int32_t Rp, int32_t target_exp, dupl_stream_t stream) {
-    return dupl_split_prepare3(x, ld, R, C, slot, next_bits, hi, lo, hiT, loT, Rp, target_exp, nullptr, 0, stream);
-}
-
-extern "C" int dupl_split_prepare2(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
-                                   void* lo, void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum,
-                                   dupl_stream_t stream) {
-    return dupl_split_prepare3(x, ld, R, C, slot, next_bits, hi, lo, hiT, loT, Rp, target_exp, colsum_accum, 0, stream);
-}
-
-extern "C" int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi,
-                                   void* lo, void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum,
-                                   int32_t amax_mode, dupl_stream_t stream) {
+extern "C" int dupl_split_prepare(const dupl_split_desc* d, dupl_stream_t stream) {
     (void)hipGetLastError();
+    if (!d || d->struct_size != sizeof(dupl_split_desc)) return DUPL_ERR_ARG;
+    const float* x = d->x;
+    const int ld = d->ld, R = d->R, C = d->C, Rp = d->Rp, target_exp = d->target_exp, amax_mode = d->amax_mode;
+    float* slot = d->slot;
+    void *hi = d->hi, *lo = d->lo, *hiT = d->hiT, *loT = d->loT;
     if (amax_mode < 0 || amax_mode > 2 || (amax_mode && !slot)) return DUPL_ERR_ARG;
-    if (colsum_accum && g_dupl_deterministic) return DUPL_ERR_ARG;     // atomics: the caller uses dupl_colsum in that mode
+    if (d->colsum_accum && g_dupl_deterministic) return DUPL_ERR_ARG;     // atomics: the caller uses dupl_colsum in that mode
     if (!x || R <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C || (!hi && !hiT) || ((hi == nullptr) != (lo == nullptr)) ||
         ((hiT == nullptr) != (loT == nullptr)) || (hiT && (Rp < R || (Rp & 7))) || target_exp < 1 || target_exp > 15)
         return DUPL_ERR_ARG;
+    if (d->fmt < 0 || d->fmt > 1 || d->rows_zero_to < 0 || (d->rows_zero_to && (d->rows_zero_to < R || !hi))) return DUPL_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15)) return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (slot && amax_mode != 1) {
@@ -210,8 +209,14 @@ extern "C" int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_
         if (g < 1) g = 1;
         hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, s, x, n4, reinterpret_cast<unsigned int*>(slot) + 2);
     }
-    const int Rt = hiT ? Rp : R;
-    hipLaunchKernelGGL(split_rt_kernel, dim3((C + 63) / 64, (Rt + 63) / 64), dim3(256), 0, s, x, ld, R, C, slot,
-                       (unsigned int*)next_bits, (__half*)hi, (__half*)lo, (__half*)hiT, (__half*)loT, Rp, target_exp, colsum_accum);
+    int Rt = hiT ? Rp : R;
+    if (d->rows_zero_to > Rt) Rt = d->rows_zero_to;
+    const dim3 grid((C + 63) / 64, (Rt + 63) / 64);
+    if (d->fmt == 1)
+        hipLaunchKernelGGL(split_rt_kernel<true>, grid, dim3(256), 0, s, x, ld, R, C, slot, (unsigned int*)d->next_bits, (__half*)hi,
+                           (__half*)lo, (__half*)hiT, (__half*)loT, Rp, target_exp, d->colsum_accum, d->rows_zero_to);
+    else
+        hipLaunchKernelGGL(split_rt_kernel<false>, grid, dim3(256), 0, s, x, ld, R, C, slot, (unsigned int*)d->next_bits, (__half*)hi,
+                           (__half*)lo, (__half*)hiT, (__half*)loT, Rp, target_exp, d->colsum_accum, d->rows_zero_to);
     return dupl_launch_status();
 }

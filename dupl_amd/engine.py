@@ -116,6 +116,10 @@ def param_segment(key: str) -> int:
 # operand plane format of the encoder's forward GEMMs: 1 = prescaled planes with an unscaled lo (one accumulator set, 256 x 256
 # tiles: +12-15 % on the big shapes), 0 = the x 2048 lo planes everywhere (DUPL_FMT1=0; the backward always uses those)
 FMT1 = os.environ.get("DUPL_FMT1", "1") != "0"
+# backward GEMMs of the encoder's Linears on the forward's own operand planes, read K-MAJOR (dupl_gemm16_desc.a_layout / b_layout):
+# no transposed planes, no fp32 copies of ln1 / ln2 / h1, single-accumulator kernels (round 4; DUPL_KM_BWD=0 restores the
+# transposed-planes path, which sites whose planes are not format 1 take in any case)
+KM_BWD = os.environ.get("DUPL_KM_BWD", "1") != "0"
 
 
 class FlatStorage:
@@ -560,6 +564,11 @@ class BlockSaved:
     pre1: Tensor = None
     h1: Tensor = None
     qkv16: object = None      # f16x3 mode, head dim 64: the fp16 hi / lo planes of qkv (operands of the split attention backward)
+    # f16x3 mode, k-major backward (KM_BWD): the format 1 planes the forward GEMMs consumed = the B operands of the weight gradients
+    ln1_16: object = None
+    att16: object = None
+    ln2_16: object = None
+    h1_16: object = None
 
 
 @dataclass
@@ -672,8 +681,11 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         p = f"encoder.blocks.{i}."
         g = guard["blocks"][i]
         attn16 = hd == 64 and g["attn"]          # q, k, v as planes into the split attention kernel
+        # sites whose backward reads the forward's planes k-major (format 1 planes on both sides): their input needs no fp32 copy
+        km = {st_: bool(save and KM_BWD and g[st_] and ea(g, st_) > 0) for st_ in ("qkv", "proj", "fc1", "fc2")}
         ln1, ln1_16, m1, r1 = ops.layernorm_fwd16(t, W[p + "norm1.weight"], W[p + "norm1.bias"], cfg.ln_eps, save,
-                                                  want_f32=save or not g["qkv"], f32_rows=save_rows, exp=ea(g, "qkv"))
+                                                  want_f32=(save and not km["qkv"]) or not g["qkv"], f32_rows=save_rows,
+                                                  exp=ea(g, "qkv"))
         lse = None
         # q, k, v stay fp16 planes end to end where their range allows: the qkv GEMM writes them, the split attention kernel
         # reads them and writes the planes the projection GEMM consumes; fp32 copies only where the backward (save) or an
@@ -687,6 +699,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         else:
             qkv = ops.linear(ln1, W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"])
             qkv16 = ops.split16(qkv) if attn16 else None
+        ln1_keep = ln1_16 if km["qkv"] else None
         del ln1_16
         need_att32 = save or not g["proj"]
         att = torch.empty((save_rows or R, D), device=t.device, dtype=torch.float32) if (need_att32 or not attn16) else None
@@ -707,19 +720,25 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
             x_mid, _ = ops.linear16(att16, P.w16(p + "attn.proj.weight", D, bool(att16.exp)), W[p + "attn.proj.bias"], res=t)
         else:
             x_mid = ops.linear(att, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], res=t)
+        att_keep = att16 if (km["proj"] and att16 is not None and att16.exp > 0) else None
         del att16
         ln2, ln2_16, m2, r2 = ops.layernorm_fwd16(x_mid, W[p + "norm2.weight"], W[p + "norm2.bias"], cfg.ln_eps, save,
-                                                  want_f32=save or not g["fc1"], f32_rows=save_rows, exp=ea(g, "fc1"))
+                                                  want_f32=(save and not km["fc1"]) or not g["fc1"], f32_rows=save_rows,
+                                                  exp=ea(g, "fc1"))
         pre1 = torch.empty((save_rows or R, D * cfg.mlp_ratio), device=t.device, dtype=torch.float32) if save else None
         if g["fc1"]:
             # the planes of h1 in the format fc2 takes; format 1 planes can only come out of a format 1 GEMM
             e2 = ea(g, "fc2") if ln2_16.exp else 0
+            km["fc2"] = km["fc2"] and e2 > 0
             h1, h1_16 = ops.linear16(ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio, bool(ln2_16.exp)), W[p + "mlp.fc1.bias"],
-                                     gelu=True, store_pre=pre1, want_f32=save or not g["fc2"], want16=g["fc2"], c_rows=save_rows,
-                                     out_exp=e2)
+                                     gelu=True, store_pre=pre1, want_f32=(save and not km["fc2"]) or not g["fc2"], want16=g["fc2"],
+                                     c_rows=save_rows, out_exp=e2)
         else:
             h1 = ops.linear(ln2, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], gelu=True, store_pre=pre1)
             h1_16 = ops.split16(h1, exp=ea(g, "fc2")) if g["fc2"] else None
+            km["fc2"] = False          # h1 exists in fp32 anyway: its backward takes the transposed-planes path
+        ln2_keep = ln2_16 if km["fc1"] else None
+        h1_keep = h1_16 if km["fc2"] else None
         del ln2_16
         if g["fc2"]:
             x_out, _ = ops.linear16(h1_16, P.w16(p + "mlp.fc2.weight", D, bool(h1_16.exp)), W[p + "mlp.fc2.bias"], res=x_mid)
@@ -728,7 +747,9 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         del h1_16
         if save:
             sv.blocks.append(BlockSaved(x_in=t, mean1=m1, rstd1=r1, ln1=ln1, qkv=qkv, lse=lse, att=att, x_mid=x_mid,
-                                        mean2=m2, rstd2=r2, ln2=ln2, pre1=pre1, h1=h1, qkv16=qkv16_keep))
+                                        mean2=m2, rstd2=r2, ln2=ln2, pre1=pre1, h1=h1, qkv16=qkv16_keep,
+                                        ln1_16=ln1_keep, att16=att_keep, ln2_16=ln2_keep, h1_16=h1_keep))
+        del ln1_keep, att_keep, ln2_keep, h1_keep
         t = x_out
         if i == aux_idx and i != cfg.depth - 1:
             aux = t
@@ -833,11 +854,17 @@ def _prefix_saved(sv: EncoderSaved, b: int, rows: int) -> EncoderSaved:
     prefix is a contiguous view: nothing is copied)."""
     out = EncoderSaved(B=b, h=sv.h, w=sv.w, x_img=sv.x_img[:b], guard=sv.guard)
     for s in sv.blocks:
-        out.blocks.append(BlockSaved(x_in=s.x_in[:rows], mean1=s.mean1[:rows], rstd1=s.rstd1[:rows], ln1=s.ln1[:rows],
+        def pre(t_):        # fp32 copies exist for the first save_rows rows only -- or not at all (k-major backward sites)
+            return t_[:rows] if t_ is not None else None
+
+        # the kept operand planes stay WHOLE (all 2b images' rows): a weight gradient walks its contraction index in 32-row
+        # steps past `rows`, where its other operand holds zeros -- real rows there spare the kernel a clamp
+        out.blocks.append(BlockSaved(x_in=s.x_in[:rows], mean1=s.mean1[:rows], rstd1=s.rstd1[:rows], ln1=pre(s.ln1),
                                      qkv=s.qkv[:rows] if s.qkv is not None else None, lse=s.lse[:b], att=s.att[:rows],
                                      x_mid=s.x_mid[:rows],
-                                     mean2=s.mean2[:rows], rstd2=s.rstd2[:rows], ln2=s.ln2[:rows], pre1=s.pre1[:rows],
-                                     h1=s.h1[:rows], qkv16=s.qkv16.rows_slice(0, rows) if s.qkv16 is not None else None))
+                                     mean2=s.mean2[:rows], rstd2=s.rstd2[:rows], ln2=pre(s.ln2), pre1=s.pre1[:rows],
+                                     h1=pre(s.h1), qkv16=s.qkv16.rows_slice(0, rows) if s.qkv16 is not None else None,
+                                     ln1_16=s.ln1_16, att16=s.att16, ln2_16=s.ln2_16, h1_16=s.h1_16))
     out.x_last, out.mean_f, out.rstd_f = sv.x_last[:rows], sv.mean_f[:rows], sv.rstd_f[:rows]
     return out
 
@@ -919,6 +946,26 @@ def _linear_backward32(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
     return ops.linear_dgrad(dy, P.w[name + ".weight"].view(N, -1), dgelu_of=dgelu_of)
 
 
+def _linear_backward16_km(P: StudentParams, dy: Tensor, x16, name: str, dgelu_of: Optional[Tensor] = None,
+                          dx_feeds_split: bool = False) -> Tensor:
+    """Backward of y = x W^T + b on the k-major single-accumulator kernels (csrc/gemm_split.hip, gemm_f16x3_km_kernel): ONE pass
+    over dy writes its scaled format 1 planes (zero rows up to the padded token count) and the bias gradient; the weight
+    gradient reads dy and the forward's x planes k-major, the data gradient reads dy row-wise and the forward's W planes
+    k-major.  Nothing is transposed, nothing but dy is split."""
+    M, N = dy.shape
+    Kp = max(96, (M + 31) // 32 * 32)           # contraction length of the weight gradient: whole k-tiles, >= the pipeline depth
+    fuse_bias = not ops.deterministic()
+    dy16, _, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False, fmt1=True, rm_rows=Kp,
+                                       colsum_into=P.g[name + ".bias"] if fuse_bias else None)
+    gw = P.g[name + ".weight"]
+    ops.linear16(dy16, x16, out=gw.view(N, -1), accumulate=True, alpha=alpha, a_kmajor=True, b_kmajor=True, k_pad=Kp)
+    if not fuse_bias:
+        ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
+    dx, _ = ops.linear16(dy16.rows_slice(0, M), P.w16(name + ".weight", N, True), alpha=alpha, dgelu_of=dgelu_of,
+                         amax_for_next=dx_feeds_split, b_kmajor=True)
+    return dx
+
+
 def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu_of: Optional[Tensor] = None,
                        has_bias: bool = True, dx_feeds_split: bool = False, xT16=None) -> Tensor:
     """The same on the f16x3 split GEMM (fp32-equivalent).  The gradient dy is scaled by a power of two from its own
@@ -948,8 +995,9 @@ def _block_operands16(P: StudentParams, p: str, s: "BlockSaved", g: dict, D: int
     the four Linear inputs (weight gradients) and, where stale, the W^T planes (data gradients).  Between the persistent
     GEMMs -- which own every CU's LDS and registers -- each of these short kernels runs alone on the chip, so eight
     launches of ~10 us become one of ~35.  Returns {site: x^T planes}."""
-    sites = [("fc2", s.h1, "mlp.fc2", D), ("fc1", s.ln2, "mlp.fc1", Hd), ("proj", s.att, "attn.proj", D), ("qkv", s.ln1, "attn.qkv", 3 * D)]
-    sites = [t for t in sites if g[t[0]]]
+    sites = [("fc2", s.h1, "mlp.fc2", D, s.h1_16), ("fc1", s.ln2, "mlp.fc1", Hd, s.ln2_16), ("proj", s.att, "attn.proj", D, s.att16),
+             ("qkv", s.ln1, "attn.qkv", 3 * D, s.ln1_16)]
+    sites = [t[:4] for t in sites if g[t[0]] and t[4] is None]      # sites with kept planes run k-major: nothing to prepare
     if not sites:
         return {}
     items = []
@@ -1040,6 +1088,11 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         def lin_bwd(site):      # the site's backward runs where its forward ran: same operands, same range verdict
             return _linear_backward16 if (f16 and g[site]) else _linear_backward32
 
+        def lin(site, dy_, x_, x16_, nm, **kw):
+            if f16 and g[site] and x16_ is not None:          # forward planes kept: k-major backward
+                return _linear_backward16_km(P, dy_, x16_, nm, dgelu_of=kw.get("dgelu_of"), dx_feeds_split=kw.get("dx_feeds_split", False))
+            return lin_bwd(site)(P, dy_, x_, nm, **kw)
+
         def feeds(site):        # does the tensor go into a scaled split next (= is `site`'s backward an f16x3 one)?
             return {"dx_feeds_split": bool(g[site])} if f16 else {}
         att16 = f16 and s.qkv16 is not None and N <= 2048
@@ -1048,19 +1101,19 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         def pre(site):          # x^T planes prepared above (f16x3 sites only)
             return {"xT16": xT[site]} if site in xT else {}
         # MLP
-        dpre1 = lin_bwd("fc2")(P, dx, s.h1, p + "mlp.fc2", dgelu_of=s.pre1, **(feeds("fc1") if g and g["fc2"] else {}), **pre("fc2"))
-        dln2 = lin_bwd("fc1")(P, dpre1, s.ln2, p + "mlp.fc1", **pre("fc1"))
+        dpre1 = lin("fc2", dx, s.h1, s.h1_16, p + "mlp.fc2", dgelu_of=s.pre1, **(feeds("fc1") if g and g["fc2"] else {}), **pre("fc2"))
+        dln2 = lin("fc1", dpre1, s.ln2, s.ln2_16, p + "mlp.fc1", **pre("fc1"))
         del dpre1
         dx_mid = ops.layernorm_bwd(dln2, s.x_mid, W[p + "norm2.weight"], s.mean2, s.rstd2,
                                    G[p + "norm2.weight"], G[p + "norm2.bias"], dres=dx, amax_for_next=f16 and g["proj"])
         # attention
-        datt = lin_bwd("proj")(P, dx_mid, s.att, p + "attn.proj",
-                               **({"dx_feeds_split": bool(att16)} if g and g["proj"] else {}), **pre("proj"))
+        datt = lin("proj", dx_mid, s.att, s.att16, p + "attn.proj",
+                   **({"dx_feeds_split": bool(att16)} if g and g["proj"] else {}), **pre("proj"))
         if att16:
             dqkv = ops.attention_bwd16(s.qkv16, s.att, datt, s.lse, B, N, Hh, hd, scale, amax_for_next=bool(g["qkv"]))
         else:
             dqkv = ops.attention_bwd(s.qkv, s.att, datt, s.lse, B, N, Hh, hd, scale)
-        dln1 = lin_bwd("qkv")(P, dqkv, s.ln1, p + "attn.qkv", **pre("qkv"))
+        dln1 = lin("qkv", dqkv, s.ln1, s.ln1_16, p + "attn.qkv", **pre("qkv"))
         del dqkv, datt, xT
         dx = ops.layernorm_bwd(dln1, s.x_in, W[p + "norm1.weight"], s.mean1, s.rstd1,
                                G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid,

@@ -292,7 +292,7 @@ def _cu_masked_streams(dev, spec: str):
         out.append(torch.cuda.ExternalStream(h.value, device=dev))
     assert len(out) == 2
     lo, hi = (int(v) for v in spec.split(",")[0].split(":"))
-    ops.L().dupl_set_gemm16_persist_blocks(int(os.environ.get("DUPL_PERSIST_BLOCKS", (hi - lo) // 8 * 8)))
+    ops.GEMM16_TUNING["persist_blocks"] = int(os.environ.get("DUPL_PERSIST_BLOCKS", (hi - lo) // 8 * 8))
     return out
 
 
@@ -346,12 +346,11 @@ class siamese_network(nn.Module):
             self._store.streams = list(_STREAM_PAIRS[dev])
         if not on:
             self._store.streams = []
-        # the split GEMM picks its tile for the number of launches that share the chip (csrc/gemm_split.hip)
+        # the split GEMM picks its tile for the number of launches that share the chip (dupl_gemm16_desc.concurrency, a per-call
+        # field: ops.GEMM16_TUNING is this Python caller's default for it)
         from .. import ops
         if self._store.data.is_cuda:
-            ops.L().dupl_set_gemm16_concurrency(2 if (on and self._store.streams) else 1)
-            if os.environ.get("DUPL_PERSIST_BLOCKS"):
-                ops.L().dupl_set_gemm16_persist_blocks(int(os.environ["DUPL_PERSIST_BLOCKS"]))
+            ops.GEMM16_TUNING["concurrency"] = 2 if (on and self._store.streams) else 1
         return self
 
     def ms_cam_and_forward(self, inputs, scales, inputs_aug=None):

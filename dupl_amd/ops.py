@@ -69,12 +69,16 @@ class Split16:
     `planes` is one [2, rows, cols] fp16 tensor (plane 0 = hi, plane 1 = lo).
     exp = 0: format 0, x = hi + lo / 2048 (two accumulator sets in the GEMM).  exp = s > 0: format 1, the planes hold
     X = x * 2^s as hi + lo with an UNSCALED lo -- all three products share one accumulator (256 x 256 tiles); both operands
-    of a GEMM must be in the same format (csrc/common.h split_f32_u, dupl_gemm16_desc.fmt)."""
-    __slots__ = ("planes", "rows", "cols", "exp")
+    of a GEMM must be in the same format (csrc/common.h split_f32_u, dupl_gemm16_desc.fmt).
+    fmt: 1 = format 1 (implied by exp > 0; scaled gradient planes are format 1 with exp 0: their power-of-two scale travels
+    through device memory, split_prepare).  valid_rows: rows that hold data (the rest are zero padding)."""
+    __slots__ = ("planes", "rows", "cols", "exp", "fmt", "valid_rows")
 
-    def __init__(self, planes: Tensor, exp: int = 0):
+    def __init__(self, planes: Tensor, exp: int = 0, fmt: Optional[int] = None, valid_rows: Optional[int] = None):
         assert planes.dtype == torch.float16 and planes.dim() == 3 and planes.shape[0] == 2 and planes.is_contiguous()
         self.planes, self.rows, self.cols, self.exp = planes, planes.shape[1], planes.shape[2], int(exp)
+        self.fmt = int(fmt) if fmt is not None else int(exp > 0)
+        self.valid_rows = int(valid_rows) if valid_rows is not None else self.rows
 
     @property
     def hi(self) -> int:
@@ -90,11 +94,12 @@ class Split16:
 
 class Split16View:
     """Row range [r0, r1) of a Split16 (both planes), as an A operand."""
-    __slots__ = ("hi", "lo", "rows", "cols", "base", "exp")
+    __slots__ = ("hi", "lo", "rows", "cols", "base", "exp", "fmt")
 
     def __init__(self, base: Split16, r0: int, r1: int):
         self.base = base
         self.exp = base.exp
+        self.fmt = base.fmt
         self.hi = base.hi + 2 * r0 * base.cols
         self.lo = base.lo + 2 * r0 * base.cols
         self.rows, self.cols = r1 - r0, base.cols
@@ -102,10 +107,19 @@ class Split16View:
 
 class W16:
     """Raw operand planes (pointers) of a [rows, cols] matrix living in someone else's buffer (parameter planes)."""
-    __slots__ = ("hi", "lo", "rows", "cols", "exp")
+    __slots__ = ("hi", "lo", "rows", "cols", "exp", "fmt")
 
     def __init__(self, hi: int, lo: int, rows: int, cols: int, exp: int = 0):
         self.hi, self.lo, self.rows, self.cols, self.exp = hi, lo, rows, cols, int(exp)
+        self.fmt = int(exp > 0)
+
+
+# Launch tuning of the split GEMM (dupl_gemm16_desc.tile / concurrency / persist_blocks / group): per-call fields of the
+# descriptor since ABI 2 -- this module-level dict is the PYTHON caller's default for them, not library state.
+# concurrency: streams that issue split GEMMs at a time (siamese_network.enable_dual_stream sets 2); tile: DUPL_GEMM16_TILE.
+import os as _os
+GEMM16_TUNING = {"tile": int(_os.environ.get("DUPL_GEMM16_TILE", "0")), "concurrency": 1,
+                 "persist_blocks": int(_os.environ.get("DUPL_PERSIST_BLOCKS", "0")), "group": 0}
 
 
 # format 1 scales (powers of two): activations * 2^3, weights * 2^9 -- typical |x| ~ 1 and |w| ~ 0.02 both land near 8 .. 10,
@@ -191,16 +205,20 @@ def reserve_amax(device):
 
 
 def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad: int = 0, target_exp: int = 15,
-                  colsum_into: Optional[Tensor] = None):
+                  colsum_into: Optional[Tensor] = None, fmt1: bool = False, rm_rows: int = 0):
     """Backward-path operand preparation (csrc/split_prep.hip): fp32 [R, C] -> row-major planes [R, C] and / or transposed
     planes [C, Rp] (Rp = rows_pad >= R, zero-filled), optionally scaled by the power of two that brings max|x| into
-    [2^14, 2^15) (gradients).  Returns (rm Split16 | None, T Split16 | None, alpha: int device pointer of 1 / scale | None;
+    [2^14, 2^15) (gradients).  fmt1: format 1 planes (unscaled lo: the single-accumulator k-major backward GEMMs).
+    rm_rows > R: the row-major planes get rm_rows rows, the extra ones zeros (k-major A operand of a weight gradient).
+    Returns (rm Split16 | None, T Split16 | None, alpha: int device pointer of 1 / scale | None;
     valid for the next ~128 scaled calls on this stream)."""
     _chk(x)
     R, C = x.shape
     Rp = rows_pad if rows_pad else (R + 31) // 32 * 32
-    rm = split16_empty(R, C, x.device) if want_rm else None
-    T = split16_empty(C, Rp, x.device) if want_T else None
+    rm = None
+    if want_rm:
+        rm = Split16(torch.empty((2, max(R, rm_rows), C), device=x.device, dtype=torch.float16), 0, fmt=int(fmt1), valid_rows=R)
+    T = Split16(torch.empty((2, C, Rp), device=x.device, dtype=torch.float16), 0, fmt=int(fmt1)) if want_T else None
     slot = nxt = rec = None
     amax_mode = 0
     if scaled:
@@ -211,10 +229,14 @@ def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad
         slot, nxt, rec = _scale_slot(x.device)
         assert pending is None or pending.word == slot + 8
     # colsum_into: [C] fp32 accumulator that receives the column sums of x (a Linear's bias gradient) from the same pass
-    rc = L().dupl_split_prepare3(x.data_ptr(), x.stride(0), R, C, slot, nxt, rm.hi if rm else None, rm.lo if rm else None,
-                                 T.hi if T else None, T.lo if T else None, Rp, target_exp, _p(colsum_into), amax_mode,
-                                 _stream())
-    assert rc == 0, f"dupl_split_prepare3 failed ({rc})"
+    d = _lib.SplitDesc()
+    d.x, d.ld, d.R, d.C = x.data_ptr(), x.stride(0), R, C
+    d.slot, d.next_bits = slot, nxt
+    d.hi, d.lo = (rm.hi, rm.lo) if rm else (None, None)
+    d.hiT, d.loT = (T.hi, T.lo) if T else (None, None)
+    d.Rp, d.target_exp, d.colsum_accum, d.amax_mode = Rp, target_exp, _p(colsum_into), amax_mode
+    d.fmt, d.rows_zero_to = int(fmt1), (rm_rows if (rm is not None and rm_rows > R) else 0)
+    L().dupl_split_prepare(ctypes.byref(d), _stream())
     if scaled:
         for o in (rm, T):
             if o is not None:
@@ -250,15 +272,26 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
              res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None,
              want_f32: bool = True, out16: Optional[Split16] = None, want16: bool = False, device=None,
              alpha: Optional[int] = None, accumulate: bool = False, dgelu_of: Optional[Tensor] = None,
-             relumask_of: Optional[Tensor] = None, c_rows: int = 0, amax_for_next: bool = False, out_exp: int = 0):
+             relumask_of: Optional[Tensor] = None, c_rows: int = 0, amax_for_next: bool = False, out_exp: int = 0,
+             a_kmajor: bool = False, b_kmajor: bool = False, k_pad: int = 0, post_exp: int = 0):
     """y = act(alpha * x W^T + bias) (+ res) on the f16x3 split GEMM.  x: Split16 / Split16View [M, K]; W: Split16 [N, K].
     alpha: device pointer of a float (inverse scale of scaled gradient planes).  accumulate: out += alpha * x W^T (weight
     gradients; split-K).  dgelu_of / relumask_of: multiply by gelu'(pre) / (post > 0) (data gradients through an activation).
     amax_for_next: y's next use on this stream is a scaled split_prepare -- the epilogue leaves max |y| in that split's
     slot (reserve_amax) and y is tagged, so the split needs no amax pass.
+    a_kmajor / b_kmajor: the operand is stored [K, rows] (rows contiguous, dupl_gemm16_desc.a_layout / b_layout): the backward
+    GEMMs on the forward's own planes.  k_pad: the contraction length the kernel walks (a multiple of 32, >= 96; operand rows
+    beyond their own count are clamped, the other operand holds zeros there).  post_exp: the product carries 2^post_exp beyond the
+    operands' exp (scaled gradient planes carry theirs in alpha).
     Returns (y fp32 [M, N] or None, y as Split16 or None)."""
-    M, K, N = x.rows, x.cols, W.rows
-    assert W.cols == K and K % 32 == 0
+    M, Ka = (x.cols, x.rows) if a_kmajor else (x.rows, x.cols)
+    N, Kb = (W.cols, W.rows) if b_kmajor else (W.rows, W.cols)
+    if a_kmajor or b_kmajor:
+        K = k_pad if k_pad else max(Ka, Kb)
+        assert K % 32 == 0 and K >= 96 and (a_kmajor or Ka == K) and (b_kmajor or Kb == K), (Ka, Kb, K)
+    else:
+        K = Ka
+        assert Kb == K and K % 32 == 0
     if dgelu_of is not None or relumask_of is not None:
         assert store_pre is None
         store_pre = dgelu_of if dgelu_of is not None else relumask_of
@@ -271,10 +304,16 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     d = _lib.Gemm16Desc()
     # operand format: both format 0, or both format 1 (then the product carries 2^(xe + we), taken out in the epilogue)
     xe, we = getattr(x, "exp", 0), getattr(W, "exp", 0)
-    assert (xe > 0) == (we > 0), f"operand planes in different formats (exp {xe} / {we})"
-    if xe:
-        assert not accumulate and not amax_for_next
-        d.fmt, d.post_scale = 1, 2.0 ** -(xe + we)
+    xf, wf = getattr(x, "fmt", int(xe > 0)), getattr(W, "fmt", int(we > 0))
+    assert xf == wf, f"operand planes in different formats (fmt {xf} / {wf}, exp {xe} / {we})"
+    if xf:
+        assert (a_kmajor or b_kmajor) or (not accumulate and not amax_for_next)
+        d.fmt, d.post_scale = 1, 2.0 ** -(xe + we + post_exp)
+    if a_kmajor or b_kmajor:
+        assert xf == 1, "k-major operands need format 1 planes"
+        d.a_layout, d.b_layout = int(a_kmajor), int(b_kmajor)
+        d.ka_valid = min(Ka, K) if a_kmajor else 0
+        d.kb_valid = min(Kb, K) if b_kmajor else 0
     if y16 is not None:
         assert y16.exp == 0 or xe, "format 1 output planes come from format 1 GEMMs"
         d.out_exp = y16.exp
@@ -283,7 +322,7 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     d.C_hi, d.C_lo = (y16.hi, y16.lo) if y16 is not None else (None, None)
     d.bias, d.res, d.aux = _p(bias), _p(res), _p(store_pre)
     d.M, d.N, d.K = M, N, K
-    d.lda, d.ldb = K, K
+    d.lda, d.ldb = x.cols, W.cols
     d.ldc = y.stride(0) if y is not None else 0
     d.ldo = N
     d.ldr = res.stride(0) if res is not None else 0
@@ -295,6 +334,8 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
         alpha.check()
     d.alpha_dev = int(alpha) if alpha is not None else None
     d.c_rows = int(c_rows)
+    d.tile, d.concurrency = GEMM16_TUNING["tile"], GEMM16_TUNING["concurrency"]
+    d.persist_blocks, d.group = GEMM16_TUNING["persist_blocks"], GEMM16_TUNING["group"]
     tok = None
     if amax_for_next and y is not None and not accumulate and not c_rows:
         d.amax_out, tok = reserve_amax(dev)

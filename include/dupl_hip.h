@@ -22,7 +22,8 @@ extern "C" {
 
 typedef void* dupl_stream_t;
 
-/* library info: returns the ABI version (1).  Infrastructure, no reference counterpart. */
+/* library info: returns the ABI version (2: descriptors carry struct_size, tuning knobs travel in the descriptors, one entry point
+ * per operation).  Infrastructure, no reference counterpart. */
 int dupl_abi_version(void);
 /* on != 0: every accumulation that otherwise uses fp32 atomics (split-K weight gradients, LayerNorm dgamma / dbeta, bias
  * column sums, seg-loss backward scatter) runs in a fixed order, so that two identical steps give bit-identical gradients
@@ -75,8 +76,11 @@ int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
  *   transposed operand planes (dupl_split_prepare): dgrad = dy . (W^T)^T, wgrad = dy^T . (x^T)^T.
  * K % 32 == 0; lda / ldb in halfs, multiples of 8; plane pointers 16-byte aligned. */
 typedef struct dupl_gemm16_desc {
-    const void* A_hi; const void* A_lo;   /* [M][lda] fp16 */
-    const void* B_hi; const void* B_lo;   /* [N][ldb] fp16 */
+    uint32_t struct_size;                 /* sizeof(dupl_gemm16_desc) of the header the CALLER was built against: a mismatch is
+                                             refused (DUPL_ERR_ARG) instead of reading fields the caller never wrote */
+    int32_t reserved0;
+    const void* A_hi; const void* A_lo;   /* [M][lda] fp16   (a_layout 1: [K][lda], the M rows contiguous) */
+    const void* B_hi; const void* B_lo;   /* [N][ldb] fp16   (b_layout 1: [K][ldb], the N rows contiguous) */
     float* C;                             /* [M][ldc] fp32 or NULL */
     void* C_hi; void* C_lo;               /* [M][ldo] fp16 planes of the result, or both NULL */
     const float* bias;                    /* [N] or NULL */
@@ -94,39 +98,58 @@ typedef struct dupl_gemm16_desc {
                                              x * 2^s with unscaled lo (dupl_split_f16x2b: one accumulator set, 256 x 256 tiles) */
     int32_t out_exp;                      /* C_hi / C_lo: 0 = format 0; s > 0 = format 1 planes of C * 2^s */
     float post_scale;                     /* multiplied into A.B^T together with alpha (2^-(sA + sB) for format 1 operands); 0 = 1 */
-    void* amax_out;                       /* NULL, or the amax word of a scale slot (dupl_split_prepare3, amax_mode 1): the kernel
+    void* amax_out;                       /* NULL, or the amax word of a scale slot (dupl_split_prepare, amax_mode 1): the kernel
                                              raises it (atomic max on the bits) to max |C| over the M x N result, so that the
                                              split of C needs no pass of its own.  Not with DUPL_GEMM_ACCUM or c_rows. */
+    int32_t a_layout, b_layout;           /* 0 = k-contiguous ([rows][K], the Linear forward's layout); 1 = K-MAJOR ([K][rows], rows
+                                             contiguous): how the backward's operands lie in memory -- dgrad dx = dy . W reads the forward's
+                                             W planes as a k-major B, wgrad dW += dy^T . x reads dy and x planes as k-major A and B --
+                                             so no transposed planes are built.  Needs fmt 1; M (a_layout 1) / N (b_layout 1) % 8 == 0. */
+    int32_t ka_valid, kb_valid;           /* k-major operands: k-rows that exist in memory (0 = K).  Rows beyond are read as the last
+                                             valid row; the OTHER operand must hold zeros there (K itself is a multiple of 32, >= 96). */
+    /* launch tuning, per call (0 = the library's heuristic): nothing about kernel selection is process-global any more */
+    int32_t tile;                         /* block tile.  Format 0 operands: 3: 128x64 on 4 waves, 5: 128x128 on 8 waves, 6 / 7: 256x128
+                                             ring kernel on 8 / 4 waves, 10: its persistent form, 11: the stream-K form of that for
+                                             DUPL_GEMM_ACCUM.  Format 1 (one accumulator set): 8: 256x256 on 8 waves, 12: 256x128, 14:
+                                             persistent 256x128 */
+    int32_t concurrency;                  /* how many streams issue split GEMMs at the same time (2 while the two students of
+                                             siamese_network run on their own streams, model_dupl.py:157-213): tile heuristic input */
+    int32_t persist_blocks;               /* blocks of the persistent kernels, a multiple of 8 (0: 256 alone, 192 at concurrency 2) */
+    int32_t group;                        /* row tiles per group of the block -> tile order */
 } dupl_gemm16_desc;
 int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream);
 /* the operand split of the GEMM above: n fp32 values (n % 4 == 0) -> hi / lo fp16 planes (no reference counterpart) */
 int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, dupl_stream_t stream);
 /* the same into format 1 planes of x * 2^scale_exp (dupl_gemm16_desc.fmt) */
 int dupl_split_f16x2b(const float* x, void* hi, void* lo, int64_t n, int32_t scale_exp, dupl_stream_t stream);
-/* tuning knob: row-tiles per group of the block order of dupl_gemm_f16x3 */
-int dupl_set_gemm16_group(int32_t gm);
 /* operand preparation for the backward split GEMMs (csrc/split_prep.hip): x [R][ld] fp32 (C columns) -> row-major planes
  * hi / lo [R][C] and / or transposed planes hiT / loT [C][Rp] (Rp >= R, multiple of 8; rows R.. are zeros).
  * slot != NULL (gradients, far below fp16's normal range): the tensor is scaled by the power of two that brings its
- * max-abs into [2^(target_exp-1), 2^target_exp) (15 for GEMM operands); slot = 4 floats of device memory {scale, 1 / scale, amax word, -} whose amax word must be
- * ZERO on entry; pass slot + 1 as the GEMM's alpha_dev.  next_bits (optional): the amax word of the slot the next scaled
- * call on this stream will use -- it is zeroed by this call (a ring of slots then needs no memset).
+ * max-abs into [2^(target_exp-1), 2^target_exp) (15 for GEMM operands); slot = 4 floats of device memory {scale, 1 / scale,
+ * amax word, -}; pass slot + 1 as the GEMM's alpha_dev.  next_bits (optional): the amax word of the slot the next scaled call
+ * on this stream will use -- it is zeroed by this call (a ring of slots then needs no memset).
+ * amax_mode: where the amax word of `slot` comes from -- 0 = this call computes it (the word must be zero on entry); 1 = the
+ * kernel that produced x has left max |x| there already (dupl_gemm16_desc.amax_out, dupl_layernorm_bwd): no amax pass; 2 = the
+ * word may hold a stale value: it is cleared (memset node), then computed.
+ * colsum_accum != NULL: colsum_accum[c] += sum_r x[r][c] (fp32 atomics, unscaled values) -- the bias gradient of a Linear
+ * (autograd of vit.py:92-136's `+ bias`) from the pass that reads dy anyway; refused in deterministic mode (dupl_colsum there).
+ * fmt 1: the planes are written in format 1 (unscaled lo, dupl_gemm16_desc.fmt) -- the single-accumulator k-major backward GEMMs.
+ * rows_zero_to > R: the row-major planes have rows_zero_to rows and rows R .. rows_zero_to - 1 are written as zeros (the k-major
+ * A operand of a weight gradient, whose contraction index is padded to a multiple of 32).
  * No reference counterpart (the reference's autograd calls ATen GEMMs on fp32 operands). */
-int dupl_split_prepare(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
-                       void* hiT, void* loT, int32_t Rp, int32_t target_exp, dupl_stream_t stream);
-/* the same, and colsum_accum[c] += sum_r x[r][c] (fp32 atomics, unscaled values) when colsum_accum != NULL: the bias gradient of a
- * Linear (autograd of vit.py:92-136's `+ bias`) from the pass that reads dy anyway.  Refused in deterministic mode (use
- * dupl_colsum there). */
-int dupl_split_prepare2(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
-                        void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum, dupl_stream_t stream);
-/* the same with the source of the amax word of `slot` chosen by amax_mode: 0 = this call computes it (the word must be zero on
- * entry, as above); 1 = the kernel that produced x has left max |x| there already (dupl_gemm16_desc.amax_out,
- * dupl_layernorm_bwd2): no amax pass; 2 = the word may hold a stale value: it is cleared (memset node), then computed. */
-int dupl_split_prepare3(const float* x, int32_t ld, int32_t R, int32_t C, float* slot, void* next_bits, void* hi, void* lo,
-                        void* hiT, void* loT, int32_t Rp, int32_t target_exp, float* colsum_accum, int32_t amax_mode,
-                        dupl_stream_t stream);
+typedef struct dupl_split_desc {
+    uint32_t struct_size;                 /* sizeof(dupl_split_desc), checked */
+    int32_t ld, R, C;
+    const float* x;
+    float* slot; void* next_bits;
+    void* hi; void* lo; void* hiT; void* loT;
+    int32_t Rp, target_exp;
+    float* colsum_accum;
+    int32_t amax_mode, fmt, rows_zero_to, reserved0;
+} dupl_split_desc;
+int dupl_split_prepare(const dupl_split_desc* d, dupl_stream_t stream);
 /* several UNSCALED matrices (saved activations, weights: the x^T / W^T operands of one transformer block's backward) in ONE
- * launch: items[i] is the argument set of dupl_split_prepare with slot = NULL.  items: host array, n <= DUPL_SPLIT_MULTI_MAX.
+ * launch: items[i] = the x / ld / R / C / hi / lo / hiT / loT / Rp fields of dupl_split_desc with slot = NULL.  items: host array, n <= DUPL_SPLIT_MULTI_MAX.
  * The short operand-preparation kernels run chip-exclusive between the persistent GEMMs (which take every CU's LDS and
  * registers), so a launch saved is its whole duration saved. */
 #define DUPL_SPLIT_MULTI_MAX 16
@@ -135,16 +158,6 @@ typedef struct dupl_split_item {
     int32_t ld, R, C, Rp;
 } dupl_split_item;
 int dupl_split_prepare_multi(const dupl_split_item* items, int32_t n, dupl_stream_t stream);
-/* tuning knob: block tile of dupl_gemm_f16x3: 0 = heuristic.  Format 0 operands: 3: 128x64 on 4 waves, 5: 128x128 on 8 waves,
- * 6 / 7: 256x128 ring kernel on 8 / 4 waves, 10: its persistent form, 11: the stream-K form of that for DUPL_GEMM_ACCUM.
- * Format 1 operands (one accumulator set): 8: 256x256 on 8 waves, 12: 256x128, 14: persistent 256x128. */
-int dupl_set_gemm16_tile(int32_t t);
-/* tuning knob: blocks of the persistent kernels (tiles 10 / 11), a multiple of 8; 0 = auto (256 = one per CU when one stream
- * issues GEMMs, 192 under dupl_set_gemm16_concurrency(2)) */
-int dupl_set_gemm16_persist_blocks(int32_t n);
-/* hint for the tile heuristic (no reference counterpart): how many streams issue split GEMMs concurrently -- 2 while the two
- * students of siamese_network run on their own streams (model_dupl.py:157-213 runs them back to back), else 1 */
-int dupl_set_gemm16_concurrency(int32_t n);
 /* ---------------------------------------------------------------------------------------------
  * Range guard of the f16x3 operand planes (csrc/range.hip; no reference counterpart: the reference's fp32 has range 3.4e38,
  * the split format |x| <= 65504).  For n tensors of a parameter buffer (table_dev: device array of descriptors; a vector is

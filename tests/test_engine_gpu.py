@@ -558,8 +558,49 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
           f"worst {errs[order[-1]]:.2e} ({order[-1]}), bar {bar:.0e}")
     for k in order[-5:]:
         print(f"full-size {case} grad {k}: rel err {errs[k]:.2e}")
-    bad = [(k, errs[k]) for k in order if not errs[k] < bar]
+    # The LargeFOV ReLUs (conv_head.py:35,38) are DECISIONS, like the label argmax: a pre-activation at round-off level (|v| ~ 1e-6)
+    # can fall on either side of 0 in two fp32 implementations, and ONE flipped (token, channel) adds or removes one whole term of
+    # a 784 b-term row sum of dW7 / dW6 (~1 / 1568 of it at 2 images: 6e-4).  As for the label maps, a relaxed bar is only granted
+    # with proof: the product's own ReLU masks (a forward of the same student) against the oracle's, the flipped decisions counted
+    # and each required to have an oracle pre-activation below 1e-4 of the layer's largest.
+    flips = _decoder_relu_flips(model, pp, pc, inputs.to(dev)) if any(not errs[k] < bar for k in order) else {}
+    relaxed = {}
+    for br, (n6, n7, worst) in flips.items():
+        print(f"full-size {case} {br} decoder ReLU decisions that differ from the oracle's: conv6 {n6}, conv7 {n7}; largest "
+              f"|oracle pre-activation| among them {worst:.2e} of the layer maximum (bar 1e-4)")
+        assert worst < 1e-4, "a ReLU decision differs where the oracle's pre-activation is NOT at round-off level"
+        if n6 + n7:
+            relaxed[br + "decoder.conv7.weight"] = relaxed[br + "decoder.conv6.weight"] = 2e-4 + 1.5e-3 * (n6 + n7)
+    bad = [(k, errs[k]) for k in order if not errs[k] < relaxed.get(k, bar)]
     assert not bad, f"{len(bad)} gradient tensors above {bar:.0e}: {bad[:8]}"
+
+
+def _decoder_relu_flips(model, pp, pc, x_dev):
+    """{"branchK.": (flipped conv6 decisions, flipped conv7 decisions, largest |oracle pre-activation| / layer max among them)}:
+    the ReLU masks of the product's LargeFOV forward against the oracle's (conv_head.py:32-41 on the oracle's own x4)."""
+    import torch.nn.functional as F
+    from dupl_amd import engine
+    out = {}
+    for s_, net in enumerate((model.branch1, model.branch2)):
+        br = f"branch{s_ + 1}."
+        with torch.no_grad():
+            _, sv = engine.network_forward(net._P, x_dev, save=True)
+        torch.cuda.synchronize()
+        x4 = pc[f"fmap_{s_ + 1}"].float()
+        B, _, h, w = x4.shape
+        W6, W7 = pp[br + "decoder.conv6.weight"], pp[br + "decoder.conv7.weight"]
+        pre6 = F.conv2d(x4, W6, padding=5, dilation=5)
+        pre7 = F.conv2d(F.relu(pre6), W7, padding=5, dilation=5)
+        res = []
+        worst = 0.0
+        for pre, got in ((pre6, sv.h6), (pre7, sv.h7)):
+            g = got.view(B, h * w, -1).permute(0, 2, 1).reshape(B, -1, h, w).cpu() > 0
+            f = g != (pre > 0)
+            res.append(int(f.sum()))
+            if res[-1]:
+                worst = max(worst, float(pre.abs()[f].max() / pre.abs().max()))
+        out[br] = (res[0], res[1], worst)
+    return out
 
 
 @pytest.mark.parametrize("b,H,W", [(1, 96, 160), (3, 128, 96), (2, 80, 80)])

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     cdll = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(cdll, name), f"{name} declared in include/dupl_hip.h but not exported"
-    assert _lib.lib().dupl_abi_version() == 1
+    assert _lib.lib().dupl_abi_version() == 2
     # struct mirror has the same size as the C struct would (6 ptrs, 10 int32, 12 int64, float, int32)
     assert ctypes.sizeof(_lib.GemmDesc) == 6 * 8 + 10 * 4 + 12 * 8 + 8
 

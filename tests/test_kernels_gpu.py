@@ -961,7 +961,7 @@ def test_cam_fuse_band_kernel_is_bit_identical(dev, B, C, H, W, sizes):
 @pytest.mark.parametrize("M,N,K", [(3140, 768, 3072), (3140, 3072, 768), (130, 96, 288)])
 def test_producer_amax_replaces_the_amax_pass(dev, M, N, K, tile):
     """dupl_gemm16_desc.amax_out / dupl_layernorm_bwd2: the kernel that WRITES a gradient leaves max |gradient| in the scale
-    slot of the split that reads it next (ops.reserve_amax), so dupl_split_prepare3 runs without its own amax pass
+    slot of the split that reads it next (ops.reserve_amax), so dupl_split_prepare runs without its own amax pass
     (amax_mode 1).  Bars: the word equals the tensor's max-abs bit for bit; the planes and the scale are identical to those of
     the stand-alone pass; an unclaimed reservation (tensor modified / not split next) is cleared (amax_mode 2)."""
     from dupl_amd import ops
@@ -971,14 +971,14 @@ def test_producer_amax_replaces_the_amax_pass(dev, M, N, K, tile):
     pre = torch.randn(M, K, generator=g).to(dev)
     dy16, _, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False)
     _, WT16, _ = ops.split_prepare(W, scaled=False, want_rm=False, want_T=True, rows_pad=N)
-    ops.L().dupl_set_gemm16_tile(tile)
+    ops.GEMM16_TUNING["tile"] = tile
     try:
         ref, _ = ops.linear16(dy16, WT16, alpha=alpha, dgelu_of=pre)
         ring = ops._scale_ring(dev)
         assert ring[2] is None
         dx, _ = ops.linear16(dy16, WT16, alpha=alpha, dgelu_of=pre, amax_for_next=True)
     finally:
-        ops.L().dupl_set_gemm16_tile(0)
+        ops.GEMM16_TUNING["tile"] = 0
     assert torch.equal(dx, ref)
     tok = dx._dupl_amax
     assert tok is ring[2] and tok.word == ring[0].data_ptr() + 16 * ring[1] + 8
@@ -1063,12 +1063,12 @@ def test_stream_k_weight_gradient(dev, M, N, K):
     outs = {}
     try:
         for tile in (5, 11):
-            ops.L().dupl_set_gemm16_tile(tile)
+            ops.GEMM16_TUNING["tile"] = tile
             c = c0.clone()
             ops.linear16(A16, B16, out=c, accumulate=True)
             outs[tile] = c
     finally:
-        ops.L().dupl_set_gemm16_tile(0)
+        ops.GEMM16_TUNING["tile"] = 0
     sc = float(ref.abs().max())
     e5, e11 = (float((outs[t].double() - ref).abs().max()) / sc for t in (5, 11))
     print(f"wgrad {M}x{N}x{K}: tile 5 {e5:.2e} stream-K {e11:.2e}")
@@ -1142,7 +1142,7 @@ def test_gemm_f16x3_format1_is_fp32_equivalent(dev, M, N, K, tile):
     ref = x.double() @ W.double().t() + b.double()
     want = F.gelu(ref) + res.double()
     sc = float(want.abs().max())
-    ops.L().dupl_set_gemm16_tile(tile)
+    ops.GEMM16_TUNING["tile"] = tile
     try:
         pre = torch.empty(M, N, device=dev)
         y, y16 = ops.linear16(xs, Ws, b, gelu=True, res=res, store_pre=pre, want16=True, out_exp=ops.EXP_ACT)
@@ -1154,7 +1154,7 @@ def test_gemm_f16x3_format1_is_fp32_equivalent(dev, M, N, K, tile):
         xsm = x * 0.05
         ysm, _ = ops.linear16(ops.split16(xsm, exp=ops.EXP_ACT), Ws, b)
     finally:
-        ops.L().dupl_set_gemm16_tile(0)
+        ops.GEMM16_TUNING["tile"] = 0
     y32 = ops.linear(x, W, b, gelu=True, res=res)
     e16, e32 = float((y.double() - want).abs().max()) / sc, float((y32.double() - want).abs().max()) / sc
     print(f"{M}x{N}x{K} tile {tile}: format 1 {e16:.2e}  f32 {e32:.2e}")
@@ -1200,3 +1200,66 @@ def test_format1_planes_from_layernorm_and_attention(dev):
     sc = float(out.abs().max())
     assert float(((o1.planes[0].float() + o1.planes[1].float()) / 8.0 - out).abs().max()) <= 2.0 ** -21 * sc
     assert float((o0.planes[0].float() + o0.planes[1].float() / 2048.0 - out).abs().max()) <= 2.0 ** -21 * sc
+
+
+@pytest.mark.parametrize("tokens,n_out,n_in", [(3140, 768, 3072), (3140, 2304, 768), (1570, 768, 768), (130, 96, 288), (34, 288, 96),
+                                               (300, 224, 104)])
+@pytest.mark.parametrize("x_rows", ["exact", "more"])
+def test_kmajor_backward_gemms_are_fp32_equivalent(dev, tokens, n_out, n_in, x_rows):
+    """gemm_f16x3_km_kernel (dupl_gemm16_desc.a_layout / b_layout): the backward GEMMs of y = x W^T on the forward's own format 1
+    planes, read k-major through ds_read_b64_tr_b16 -- dx = dy . W (B = W planes [n_out][n_in], k-major) and dW += dy^T . x
+    (A = scaled dy planes [tokens padded][n_out], B = x planes [rows][n_in], both k-major; stream-K / atomics, and the
+    fixed-order form in deterministic mode).  Bars: error vs fp64 <= 2x the exact-f32 MFMA kernels' + 2e-7 (the same bar the
+    transposed-planes path meets); ragged tile edges, token counts that are not multiples of 32, x planes that end exactly at
+    `tokens` (the kernel clamps its reads) or continue with other rows (which must not leak into dW: dy is zero there)."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(tokens + 3 * n_out + 7 * n_in)
+    dy = (torch.randn(tokens, n_out, generator=g) * 2e-5 * (1.0 + 5.0 * (torch.rand(tokens, 1, generator=g) > 0.97))).to(dev)
+    R = tokens if x_rows == "exact" else tokens + 77
+    x_all = torch.randn(R, n_in, generator=g).to(dev)
+    x = x_all[:tokens]
+    W = (torch.randn(n_out, n_in, generator=g) * 0.03).to(dev)
+    pre = torch.randn(tokens, n_in, generator=g).to(dev)
+    x16 = ops.split16(x_all, exp=ops.EXP_ACT)
+    W16 = ops.split16(W, exp=ops.EXP_W)
+    Kp = max(96, (tokens + 31) // 32 * 32)
+    bias_g = torch.zeros(n_out, device=dev)
+    dy16, _, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False, fmt1=True, rm_rows=Kp, colsum_into=bias_g)
+    assert dy16.rows == Kp and dy16.fmt == 1 and float(dy16.planes[:, tokens:].abs().max() if Kp > tokens else 0.0) == 0.0
+    assert float((bias_g.double() - dy.double().sum(0)).abs().max()) <= 1e-5 * float(dy.double().sum(0).abs().max())
+    # ---- data gradient (with the GELU' factor and the producer amax)
+    dx, _ = ops.linear16(dy16.rows_slice(0, tokens), W16, alpha=alpha, dgelu_of=pre, b_kmajor=True)
+    cdf = 0.5 * (1 + torch.erf(pre.double() / 2 ** 0.5))
+    pdf = torch.exp(-0.5 * pre.double() ** 2) / (2 * torch.pi) ** 0.5
+    want = (dy.double() @ W.double()) * (cdf + pre.double() * pdf)
+    dx32 = ops.linear_dgrad(dy, W, dgelu_of=pre)
+    sc = float(want.abs().max())
+    e16, e32 = float((dx.double() - want).abs().max()) / sc, float((dx32.double() - want).abs().max()) / sc
+    print(f"k-major dgrad {tokens}x{n_in}x{n_out}: f16x3 {e16:.2e}  f32 {e32:.2e}")
+    assert e16 <= 2.0 * e32 + 2e-7
+    # ---- weight gradient, accumulated onto existing values: atomics (stream-K or one block per tile) and fixed order
+    c0 = (torch.randn(n_out, n_in, generator=g) * 1e-4).to(dev)
+    wantw = c0.double() + dy.double().t() @ x.double()
+    scw = float(wantw.abs().max())
+    gw32 = c0.clone()
+    ops.linear_wgrad(dy, x, gw32, accumulate=True)
+    e32w = float((gw32.double() - wantw).abs().max()) / scw
+    outs = []
+    for det in (0, 1):
+        ops.L().dupl_set_deterministic(det)
+        try:
+            gw = c0.clone()
+            ops.linear16(dy16, x16, out=gw, accumulate=True, alpha=alpha, a_kmajor=True, b_kmajor=True, k_pad=Kp)
+            outs.append(gw)
+        finally:
+            ops.L().dupl_set_deterministic(0)
+        e = float((gw.double() - wantw).abs().max()) / scw
+        print(f"k-major wgrad {n_out}x{n_in}x{tokens} det={det}: f16x3 {e:.2e}  f32 {e32w:.2e}")
+        assert e <= 2.0 * e32w + 2e-7
+    ops.L().dupl_set_deterministic(1)
+    try:
+        gw2 = c0.clone()
+        ops.linear16(dy16, x16, out=gw2, accumulate=True, alpha=alpha, a_kmajor=True, b_kmajor=True, k_pad=Kp)
+    finally:
+        ops.L().dupl_set_deterministic(0)
+    assert torch.equal(gw2, outs[1]), "the fixed-order weight gradient must be bit-reproducible"

@@ -116,7 +116,8 @@ int main(int argc, char** argv) {
     std::vector<int> tiles = {5, 6, 7};
     int iters = 20, epi = 0, probe_iters = 40000, window_ms = 0;
     bool check_only = false, two = false, dbg = false, probe = false, f1 = false;   // f1: format 1 operand planes (single accumulator)
-    std::string sel = "fwd";
+    std::string sel = "fwd", layout = "nn";
+    int group = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-t") && i + 1 < argc) tiles = parse_ints(argv[++i]);
         else if (!strcmp(argv[i], "-n") && i + 1 < argc) iters = atoi(argv[++i]);
@@ -125,12 +126,14 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "-e") && i + 1 < argc) epi = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-c")) check_only = true;
         else if (!strcmp(argv[i], "-2")) two = true;
-        else if (!strcmp(argv[i], "-g") && i + 1 < argc) dupl_set_gemm16_group(atoi(argv[++i]));
+        else if (!strcmp(argv[i], "-g") && i + 1 < argc) group = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-L") && i + 1 < argc) layout = argv[++i];   // nn (default) | nk: B k-major (dgrad) | kk: A and B k-major (wgrad, use -e 4)
         else if (!strcmp(argv[i], "-p")) probe = true;
         else if (!strcmp(argv[i], "-P") && i + 1 < argc) { probe = true; probe_iters = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "-f")) f1 = true;     // format 1 planes: A * 2^3, B * 2^9, unscaled lo; tiles 8 (256 x 256) / 12 (256 x 128)
         else if (!strcmp(argv[i], "-d")) dbg = true;   // ablation build with G16_ABL & 16: per-block s_memtime stamps through aux
     }
+    const int akm = layout.size() > 0 && layout[0] == 'k', bkm = layout.size() > 1 && layout[1] == 'k';
     std::vector<Shape> shapes;
     const Shape fwd[] = {{15696, 3072, 768}, {15696, 768, 3072}, {15696, 2304, 768}, {15696, 768, 768},
                          {6280, 3072, 768},  {6280, 768, 3072},  {6280, 2304, 768},  {6280, 768, 768},
@@ -218,8 +221,12 @@ int main(int argc, char** argv) {
         auto desc = [&](int s) {
             dupl_gemm16_desc d;
             memset(&d, 0, sizeof d);
+            d.struct_size = sizeof d;
+            d.group = group;
+            d.concurrency = two ? 2 : 1;
             d.A_hi = Ah[s]; d.A_lo = Ah[s] + nA; d.B_hi = Bh[s]; d.B_lo = Bh[s] + nB;
-            d.M = M; d.N = N; d.K = K; d.lda = K; d.ldb = K; d.ldc = N; d.ldo = N; d.ldr = N; d.ldaux = N;
+            d.M = M; d.N = N; d.K = K; d.lda = akm ? M : K; d.ldb = bkm ? N : K; d.ldc = N; d.ldo = N; d.ldr = N; d.ldaux = N;
+            d.a_layout = akm; d.b_layout = bkm;
             switch (epi) {
                 case 0: d.C = C[s]; break;
                 case 1: d.C_hi = Ch[s]; d.C_lo = Ch[s] + nC; d.bias = bias; break;
@@ -238,18 +245,19 @@ int main(int argc, char** argv) {
         {
             dupl_gemm_desc r;
             memset(&r, 0, sizeof r);
-            r.A = A[0]; r.B = B[0]; r.C = Cref; r.M = M; r.N = N; r.K = K; r.lda = K; r.ldb = K; r.ldc = N; r.ldr = N; r.ldaux = N;
+            r.A = A[0]; r.B = B[0]; r.C = Cref; r.M = M; r.N = N; r.K = K; r.lda = akm ? M : K; r.ldb = bkm ? N : K; r.ldc = N; r.ldr = N; r.ldaux = N;
             r.batch = 1; r.zdiv = 1; r.alpha = 1.f;
+            r.flags = (akm ? DUPL_GEMM_A_MCONTIG : 0) | (bkm ? DUPL_GEMM_B_NCONTIG : 0);
             if (epi == 1 || epi == 2 || epi == 3) r.bias = bias;
-            if (epi == 2) r.flags = DUPL_GEMM_GELU;
+            if (epi == 2) r.flags |= DUPL_GEMM_GELU;
             if (epi == 3) r.res = res[0];
             if (dupl_gemm_f32(&r, nullptr)) { fprintf(stderr, "reference gemm failed\n"); return 2; }
             CK(hipDeviceSynchronize());
         }
         printf("%5dx%4dx%4d:", M, N, K);
         for (int tile : tiles) {
-            if (dupl_set_gemm16_tile(tile)) { printf("  t%d n/a", tile); continue; }
             dupl_gemm16_desc d0 = desc(0);
+            d0.tile = tile;
             if (epi == 4) CK(hipMemsetAsync(C[0], 0, nC * 4, st[0]));
             int rc = dupl_gemm_f16x3(&d0, st[0]);
             if (rc) { printf("  t%d rc=%d", tile, rc); continue; }
@@ -265,6 +273,7 @@ int main(int argc, char** argv) {
             const float rel = hs[0] / (hs[1] > 0 ? hs[1] : 1.f);
             if (check_only) { printf("  t%d err %.2e", tile, rel); continue; }
             dupl_gemm16_desc d1 = two ? desc(1) : d0;
+            d1.tile = tile;
             CK(hipEventRecord(e0, st[0]));
             for (int w = 0; w < 3; ++w) {
                 dupl_gemm_f16x3(&d0, st[0]);
@@ -348,6 +357,5 @@ int main(int argc, char** argv) {
         }
         hipFree(Cref); hipFree(bias);
     }
-    dupl_set_gemm16_tile(0);
     return 0;
 }
