@@ -277,8 +277,10 @@ class GemmTimer:
             mn = int(f32_out) * (2 if kw.get("accumulate", False) else 1) + int(planes_out) + aux
             # family: weight gradients accumulate; data gradients carry the inverse scale of their scaled gradient planes;
             # everything else is a forward Linear / decoder conv, on format 1 (single accumulator) or format 0 planes
-            fam = "wgrad" if kw.get("accumulate", False) else ("dgrad" if kw.get("alpha") is not None else
-                                                                ("fwd_f1" if getattr(x, "exp", 0) else "fwd_f0"))
+            # (a stream-K data gradient accumulates into a zero-filled dx: k-major B only; a weight gradient has a k-major A too)
+            acc_, akm_ = kw.get("accumulate", False), kw.get("a_kmajor", False)
+            wg = acc_ and (akm_ or not kw.get("b_kmajor", False))
+            fam = "wgrad" if wg else ("dgrad" if kw.get("alpha") is not None else ("fwd_f1" if getattr(x, "exp", 0) else "fwd_f0"))
             # k-major operands (the backward GEMMs on the forward's planes) are stored [K, rows]; the algorithmic contraction
             # length of a weight gradient is the token count, not its zero-padded k_pad
             a_km, b_km = kw.get("a_kmajor", False), kw.get("b_kmajor", False)

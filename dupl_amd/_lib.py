@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(HERE, "libdupl_hip.so")
 class GemmDesc(ctypes.Structure):
     """Mirror of `dupl_gemm_desc` (include/dupl_hip.h)."""
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("tile_rows", ctypes.c_int32), ("tile_cols", ctypes.c_int32), ("group", ctypes.c_int32),
         ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
         ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p), ("aux", ctypes.c_void_p),
         ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
@@ -30,6 +31,10 @@ class GemmDesc(ctypes.Structure):
         ("sX0", ctypes.c_int64), ("sX1", ctypes.c_int64), ("sBias0", ctypes.c_int64), ("sBias1", ctypes.c_int64),
         ("alpha", ctypes.c_float), ("flags", ctypes.c_int32),
     ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = ctypes.sizeof(GemmDesc)
 
 
 class Gemm16Desc(ctypes.Structure):

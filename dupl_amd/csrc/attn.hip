@@ -427,12 +427,7 @@ __global__ __launch_bounds__(ANT, 2) void attn_bwd_dkv_kernel(const float* __res
 
 }  // namespace
 
-static int g_attn_remap = 1;   // XCD-aware block order (dupl_set_attention_remap)
-
-extern "C" int dupl_set_attention_remap(int32_t on) {
-    g_attn_remap = on ? 1 : 0;
-    return DUPL_OK;
-}
+constexpr int g_attn_remap = 1;   // XCD-aware block order (whole heads per XCD)
 
 extern "C" int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd,
                                   float scale, dupl_stream_t s) {

@@ -335,28 +335,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
 
 }  // namespace
 
-static int g_attn16_remap = 1;
-
+constexpr int g_attn16_remap = 1;      // XCD-aware workgroup order (whole heads per XCD)
 
 extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
                                     void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
-                                    float scale, dupl_stream_t s) {
-    return dupl_attention_fwd16b(qkv_hi, qkv_lo, vT_hi, vT_lo, out, out_hi, out_lo, lse, B, N, H, hd, Npad, scale, B, s);
-}
-
-extern "C" int dupl_attention_fwd16c(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
-                                     void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
-                                     float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s);
-extern "C" int dupl_attention_fwd16b(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
-                                     void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
-                                     float scale, int32_t B_f32, dupl_stream_t s) {
-    return dupl_attention_fwd16c(qkv_hi, qkv_lo, vT_hi, vT_lo, out, out_hi, out_lo, lse, B, N, H, hd, Npad, scale, B_f32, 0, s);
-}
-extern "C" int dupl_attention_fwd16c(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
-                                     void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
-                                     float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s) {
+                                    float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s) {
     (void)hipGetLastError();
     if (out_exp < 0 || out_exp > 15) return DUPL_ERR_ARG;
+    if (B_f32 == 0) B_f32 = B;           // 0 = the fp32 output / lse for every image
     if (B_f32 < 0 || B_f32 > B || (B_f32 < B && !out_hi)) return DUPL_ERR_ARG;
     if (!qkv_hi || !qkv_lo || !vT_hi || !vT_lo || (!out && !out_hi) || ((out_hi == nullptr) != (out_lo == nullptr)) || B <= 0 ||
         N <= 0 || H <= 0 || hd != HD || Npad < N || (Npad % KT))

@@ -67,7 +67,7 @@ __device__ __forceinline__ void split_regs(const f32x16& v, h8 (&hi)[2], h8 (&lo
 }
 
 // delta[b][h][q] = sum_d dO[q][d] * O[q][d]   (fp32 operands)
-// max |dq| / |dk| / |dv| of a wave -> the amax word of the scale slot the split of dqkv will use (dupl_split_prepare3, amax_mode 1):
+// max |dq| / |dk| / |dv| of a wave -> the amax word of the scale slot the split of dqkv will use (dupl_split_prepare, amax_mode 1):
 // one atomic per wave (non-negative floats order like their bits); the waves of the ~340 blocks retire spread over the launch
 __device__ __forceinline__ void attn_bwd_amax_flush(unsigned int* amax_out, float amx) {
     if (!amax_out) return;
@@ -420,23 +420,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dkv_kernel(const __half* __
 
 }  // namespace
 
-static int g_attnb16_remap = 1;
+constexpr int g_attnb16_remap = 1;     // XCD-aware workgroup order
 
-extern "C" int dupl_attention_bwd16b(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
-                                     const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T,
-                                     float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
-                                     void* amax_out, dupl_stream_t stream);
 extern "C" int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
                                     const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T,
                                     float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
-                                    dupl_stream_t stream) {
-    return dupl_attention_bwd16b(qkv_hi, qkv_lo, out, dout, do_hi, do_lo, do_slot, lse, delta, scratch_T, dqkv, B, N, H, hd, Npad, scale,
-                                 nullptr, stream);
-}
-extern "C" int dupl_attention_bwd16b(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
-                                     const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T,
-                                     float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
-                                     void* amax_out, dupl_stream_t stream) {
+                                    void* amax_out, dupl_stream_t stream) {
     (void)hipGetLastError();
     unsigned int* ax = static_cast<unsigned int*>(amax_out);
     if (!qkv_hi || !qkv_lo || !out || !dout || !do_hi || !do_lo || !do_slot || !lse || !delta || !scratch_T || !dqkv || B <= 0 ||

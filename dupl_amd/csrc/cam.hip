@@ -354,25 +354,17 @@ extern "C" int dupl_resize_bilinear(const float* in, float* out, int32_t B, int3
     return dupl_launch_status();
 }
 
-static int g_cam_fuse_impl = 1;     // 1: LDS-staged band kernel (W % 4 == 0), 0: per-pixel kernel (A/B tests, odd widths)
-extern "C" int dupl_set_cam_fuse_impl(int32_t impl) {
-    if (impl != 0 && impl != 1) return DUPL_ERR_ARG;
-    g_cam_fuse_impl = impl;
-    return DUPL_OK;
-}
-
-static int g_cam_band_blocks = 768;    // measured 256 .. 4096 at 448^2: C = 20: 40 / 33.3 (768) / 39 / 56 us, C = 80: 126 / 77.4 (768) / 82 us
-extern "C" int dupl_set_cam_fuse_blocks(int32_t n) {
-    if (n < 1 || n > (1 << 20)) return DUPL_ERR_ARG;
-    g_cam_band_blocks = n;
-    return DUPL_OK;
-}
-
+// impl: 0 = the library's choice (the LDS-staged band kernel where W % 4 == 0), 1 = force the per-pixel kernel (A/B tests; it is what
+// odd widths take anyway).  band_blocks: target block count of the band kernel, 0 = 768 (measured 256 .. 4096 at 448^2: C = 20:
+// 40 / 33.3 (768) / 39 / 56 us, C = 80: 126 / 77.4 (768) / 82 us).  Per-call arguments: nothing here is process-global.
 extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const int32_t* ws, int32_t nscale, int32_t row_off,
-                             int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, dupl_stream_t s) {
+                             int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, int32_t impl,
+                             int32_t band_blocks, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!lows || !hs || !ws || nscale <= 0 || nscale > 4 || !cam || !mm || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldc < C)
         return DUPL_ERR_ARG;
+    if (impl < 0 || impl > 1 || band_blocks < 0 || band_blocks > (1 << 20)) return DUPL_ERR_ARG;
+    const int g_cam_fuse_impl = impl == 1 ? 0 : 1, g_cam_band_blocks = band_blocks ? band_blocks : 768;
     CamFuseDesc d;
     for (int i = 0; i < 4; ++i) {
         d.low[i] = i < nscale ? lows[i] : nullptr;

@@ -259,32 +259,16 @@ extern "C" int dupl_set_deterministic(int32_t on) {
     return DUPL_OK;
 }
 
-static int g_group_m = 16;        // row-tiles per group of the block order (dupl_set_gemm_group)
-static int g_ncols_override = 0;  // 0 = heuristic, 64 / 128 = forced column tile of the 64-row kernels (dupl_set_gemm_ncols)
-static int g_tile_override = 0;   // 0 = heuristic, 64 / 128 = forced (tuning knob, dupl_set_gemm_tile)
-
-extern "C" int dupl_set_gemm_group(int32_t gm) {
-    if (gm < 1 || gm > 4096) return DUPL_ERR_ARG;
-    g_group_m = gm;
-    return DUPL_OK;
-}
-
-extern "C" int dupl_set_gemm_ncols(int32_t cols) {
-    if (cols != 0 && cols != 64 && cols != 128) return DUPL_ERR_ARG;
-    g_ncols_override = cols;
-    return DUPL_OK;
-}
-
-extern "C" int dupl_set_gemm_tile(int32_t rows) {
-    if (rows != 0 && rows != 64 && rows != 128) return DUPL_ERR_ARG;
-    g_tile_override = rows;
-    return DUPL_OK;
-}
-
 extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
-    if (!d || !d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->zdiv <= 0)
+    if (!d || d->struct_size != sizeof(dupl_gemm_desc)) return DUPL_ERR_ARG;       // a caller built against another header
+    if (!d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->zdiv <= 0)
         return DUPL_ERR_ARG;
+    // launch tuning travels in the descriptor (0 = heuristic): tile_rows 64 / 128, tile_cols 64 / 128, group 1 .. 4096
+    if ((d->tile_rows != 0 && d->tile_rows != 64 && d->tile_rows != 128) || (d->tile_cols != 0 && d->tile_cols != 64 && d->tile_cols != 128) ||
+        d->group < 0 || d->group > 4096)
+        return DUPL_ERR_ARG;
+    const int g_tile_override = d->tile_rows, g_ncols_override = d->tile_cols, g_group_m = d->group ? d->group : 16;
     if ((d->flags & (DUPL_GEMM_MUL_DGELU | DUPL_GEMM_MUL_RELUMASK | DUPL_GEMM_STORE_PRE)) && !d->aux) return DUPL_ERR_ARG;
     const bool amc_ = d->flags & DUPL_GEMM_A_MCONTIG, bnc_ = d->flags & DUPL_GEMM_B_NCONTIG;
     // 64-row tiles (4 resident blocks / CU) measured >= 128-row tiles on every DuPL shape (profiles/r01_gemm_tiles.txt)

@@ -195,7 +195,28 @@ __device__ __forceinline__ void gemm16_epilogue_lds(const dupl_gemm16_desc& p, f
             if (c < nv) bv[c] = p.bias[col + c];
     }
     const bool fast = vec && nv == 4;
-    for (int r = rl; r < TH; r += RPI) {
+    // Rows are handled EPU at a time: the global LOADS of a chunk (residual, aux of the gelu' / relu-mask epilogues) are issued
+    // before anything of it is computed or stored -- one load per row with its use right behind it made the whole epilogue a chain
+    // of EPU-times as many exposed memory latencies (2 waves per SIMD hide none of it): the residual epilogue cost 19 % of a
+    // 15 696 x 768 x 3 072 launch.  res / aux never alias an output of the same launch (host API: distinct tensors).
+    constexpr int EPU = 4;
+    const bool need_aux = f_dgelu | f_rmask;
+    for (int r0 = rl; r0 < TH; r0 += EPU * RPI) {
+        f32x4 rq[EPU], aq[EPU];
+        if (fast) {
+#pragma unroll
+            for (int u = 0; u < EPU; ++u) {
+                const int r = r0 + u * RPI, row = mw + r;
+                if (r < TH && row < p.M) {
+                    if (p.res) rq[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+                    if (need_aux) aq[u] = *reinterpret_cast<const f32x4*>(p.aux + (size_t)row * p.ldaux + col);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EPU; ++u) {
+        const int r = r0 + u * RPI;
+        if (r >= TH) break;
         const int row = mw + r;
         if (row >= p.M) break;
         const f32x4 t = *reinterpret_cast<const f32x4*>(tile + r * TW + cl);
@@ -220,11 +241,10 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) auxp[c] = v[c]; }
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
         }
-        if (f_dgelu | f_rmask) {
+        if (need_aux) {
             float a[4] = {0.f, 0.f, 0.f, 0.f};
             if (fast) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(auxp);
-                a[0] = q[0]; a[1] = q[1]; a[2] = q[2]; a[3] = q[3];
+                a[0] = aq[u][0]; a[1] = aq[u][1]; a[2] = aq[u][2]; a[3] = aq[u][3];
             } else
                 {
 _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) a[c] = auxp[c]; }
@@ -239,8 +259,7 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) a[c] = auxp[c]; }
         if (p.res) {
             const float* rp = p.res + (size_t)row * p.ldr + col;
             if (fast) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(rp);
-                v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+                v[0] += rq[u][0]; v[1] += rq[u][1]; v[2] += rq[u][2]; v[3] += rq[u][3];
             } else
                 {
 _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) v[c] += rp[c]; }
@@ -278,6 +297,7 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c)
                     }
                 }
         }
+        }   // rows of the chunk
     }
     }   // passes
 }
@@ -303,8 +323,10 @@ __device__ __forceinline__ Epi16 epi16_setup(const dupl_gemm16_desc& p) {
             a16(p.bias) && !(reinterpret_cast<uintptr_t>(e.Ch) & 7) && !(reinterpret_cast<uintptr_t>(e.Cl) & 7);
     return e;
 }
+// pre / pre_kind: the residual (1) / aux (2) quad of this row when the caller has loaded it already (fast lanes only), else kind 0
 __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi16& E, const int row, const int col, const int nv,
-                                           const f32x4 t, const float (&bv)[4], float& amx) {
+                                           const f32x4 t, const float (&bv)[4], float& amx, const f32x4 pre = f32x4{0.f, 0.f, 0.f, 0.f},
+                                           const int pre_kind = 0) {
     const bool fast = E.vec && nv == 4;
     float v[4] = {t[0] + bv[0], t[1] + bv[1], t[2] + bv[2], t[3] + bv[3]};
     float* auxp = p.aux + (size_t)row * p.ldaux + col;
@@ -327,7 +349,7 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
     if (E.f_dgelu | E.f_rmask) {
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         if (fast) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(auxp);
+            const f32x4 q = pre_kind == 2 ? pre : *reinterpret_cast<const f32x4*>(auxp);
             a[0] = q[0]; a[1] = q[1]; a[2] = q[2]; a[3] = q[3];
         } else {
 #pragma unroll
@@ -344,7 +366,7 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
     if (p.res) {
         const float* rp = p.res + (size_t)row * p.ldr + col;
         if (fast) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(rp);
+            const f32x4 q = pre_kind == 1 ? pre : *reinterpret_cast<const f32x4*>(rp);
             v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
         } else {
 #pragma unroll
@@ -409,10 +431,25 @@ __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, 
         for (int c = 0; c < 4; ++c)
             if (c < nv) bv[c] = p.bias[col + c];
     }
+    // (one of the two at most: the persistent kernels keep their accumulators in registers through the epilogue, 16 more would spill)
+    const bool want_aux = E.f_dgelu || E.f_rmask;
+    const bool pre_ld = !ACC && E.vec && nv == 4 && ((p.res != nullptr) != want_aux);
+    const float* pre_src = want_aux ? p.aux : p.res;
+    const int pre_ldm = want_aux ? p.ldaux : p.ldr;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            // the residual / aux quads of this pass's two rows go out BEFORE the LDS round trip of the accumulators, so that their
+            // latency overlaps it instead of standing in front of every row's arithmetic
+            f32x4 pq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            if (pre_ld) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int row = mw + i * 32 + 8 * g + rl + 4 * k;
+                    if (row < p.M) pq[k] = *reinterpret_cast<const f32x4*>(pre_src + (size_t)row * pre_ldm + col);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -443,7 +480,8 @@ __device__ __forceinline__ void gemm16_epilogue_side(const dupl_gemm16_desc& p, 
                     const int r = rl + 4 * k;
                     const f32x4 t = *reinterpret_cast<const f32x4*>(side + r * 64 + cl);
                     const int row = mw + i * 32 + 8 * g + r;
-                    if (nv > 0 && row < p.M) epi16_quad(p, E, row, col, nv, t, bv, amx);
+                    if (nv > 0 && row < p.M)
+                        epi16_quad(p, E, row, col, nv, t, bv, amx, pq[k], pre_ld ? (want_aux ? 2 : 1) : 0);
                 }
             }
         }
@@ -1546,7 +1584,7 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         // Measured on the shapes of the step (tools/gemm16_bench -w 200 with and without -2, profiles/r03_gemm16_tiles.txt),
         // sustained clocks.  The persistent 256 x 128 ring kernel (tile 10; 6 = the same, one block per tile) is one block
         // per CU: it wins wherever its grid covers a good part of the chip -- >= 64 tiles when a second stream feeds the chip
-        // as well (the two students: dupl_set_gemm16_concurrency(2)), >= 128 tiles alone.  The weight gradients go to its
+        // as well (the two students: dupl_gemm16_desc.concurrency 2), >= 128 tiles alone.  The weight gradients go to its
         // stream-K form (tile 11) when every block gets >= 10 k-steps (K = 1600, one stream: 3072 x 768 143 vs 117, 2304 x 768 116 vs 100): 3072 x 768 x 3168 alone 155 -> 205 TF/s-eq, with a
         // second stream 219 -> 238 (there only from 64 tiles on: 2304 x 768 loses 6 % to two co-resident 128 x 128 blocks of
         // both streams); the rest stay on split-K grids of 128 x 128 (tile 5, two blocks per CU) / 128 x 64 (tile 3).
@@ -1576,7 +1614,12 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         if (!d->b_layout && d->kb_valid) return DUPL_ERR_ARG;
         const int nb21 = ((d->M + 255) / 256) * ((d->N + 127) / 128);
         const bool sk = accum && !g_dupl_deterministic && ksplit > 1;
-        if (accum) {
+        if (accum && !d->a_layout) {
+            // a data gradient with a LINEAR epilogue (dx = alpha dy . W, nothing else) into a zero-filled dx: stream-K pieces meet in
+            // fp32 atomics, so that the N = 768 outputs (78 tiles of 256 x 128 at 4 images, 42 at 2) run on every CU
+            if (!d->b_layout || g_dupl_deterministic) return DUPL_ERR_ARG;      // (the caller takes the one-block-per-tile form then)
+            hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, false, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d, g16_group_ring);
+        } else if (accum) {
             if (!(d->a_layout && d->b_layout)) return DUPL_ERR_ARG;            // the weight gradient: both operands token-major
             if (sk) hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, true, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d, g16_group_ring);
             else hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 2, true, true>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);

@@ -366,25 +366,11 @@ __global__ __launch_bounds__(GT) void gmm_filter_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int dupl_gmm_noise_filter2(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch,
-                                      float* stats, int32_t B, int32_t HW, int32_t ignore_index, float min_ce,
-                                      int32_t min_count, float valid_thre, float gamma, float reg_covar, float em_tol,
-                                      int32_t em_iters, double u0, double u1, double u2, int32_t seeding,
-                                      const uint32_t* mt_raw_host, dupl_stream_t s);
-
 extern "C" int dupl_gmm_noise_filter(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch,
                                      float* stats, int32_t B, int32_t HW, int32_t ignore_index, float min_ce,
                                      int32_t min_count, float valid_thre, float gamma, float reg_covar, float em_tol,
-                                     int32_t em_iters, double u0, double u1, double u2, dupl_stream_t s) {
-    return dupl_gmm_noise_filter2(ce_map, label, xs_scratch, lab_scratch, stats, B, HW, ignore_index, min_ce, min_count, valid_thre,
-                                  gamma, reg_covar, em_tol, em_iters, u0, u1, u2, 0, nullptr, s);
-}
-
-extern "C" int dupl_gmm_noise_filter2(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch,
-                                      float* stats, int32_t B, int32_t HW, int32_t ignore_index, float min_ce,
-                                      int32_t min_count, float valid_thre, float gamma, float reg_covar, float em_tol,
-                                      int32_t em_iters, double u0, double u1, double u2, int32_t seeding,
-                                      const uint32_t* mt_raw_host, dupl_stream_t s) {
+                                     int32_t em_iters, double u0, double u1, double u2, int32_t seeding,
+                                     const uint32_t* mt_raw_host, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!ce_map || !label || !xs_scratch || !lab_scratch || !stats || B <= 0 || HW <= 0 || em_iters < 0 ||
         !(u0 >= 0.0 && u0 < 1.0) || !(u1 >= 0.0 && u1 < 1.0) || !(u2 >= 0.0 && u2 < 1.0) || (seeding != 0 && seeding != 1) ||

@@ -274,28 +274,17 @@ inline int ew_grid(long n) {
 
 }  // namespace
 
+extern "C" int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
+                                    float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
+                                    int32_t plane_exp, dupl_stream_t s);
 extern "C" int dupl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                   float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
-    return dupl_layernorm_fwd16(x, gamma, beta, y, nullptr, nullptr, mean, rstd, rows, D, eps, s);
+    return dupl_layernorm_fwd16(x, gamma, beta, y, nullptr, nullptr, mean, rstd, rows, D, eps, 0, 0, s);
 }
 
 extern "C" int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
-                                    float* mean, float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s) {
-    return dupl_layernorm_fwd16b(x, gamma, beta, y, y_hi, y_lo, mean, rstd, rows, D, eps, 0, s);
-}
-
-extern "C" int dupl_layernorm_fwd16c(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
-                                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
-                                     int32_t plane_exp, dupl_stream_t s);
-extern "C" int dupl_layernorm_fwd16b(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
-                                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
-                                     dupl_stream_t s) {
-    return dupl_layernorm_fwd16c(x, gamma, beta, y, y_hi, y_lo, mean, rstd, rows, D, eps, f32_rows, 0, s);
-}
-extern "C" int dupl_layernorm_fwd16c(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
-                                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
-                                     int32_t plane_exp, dupl_stream_t s) {
+                                    float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
+                                    int32_t plane_exp, dupl_stream_t s) {
     (void)hipGetLastError();
     if (plane_exp < 0 || plane_exp > 15) return DUPL_ERR_ARG;
     const float plane_scale = plane_exp ? ldexpf(1.f, plane_exp) : 0.f;  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
@@ -313,38 +302,24 @@ extern "C" int dupl_layernorm_fwd16c(const float* x, const float* gamma, const f
     return dupl_launch_status();
 }
 
-static int g_lnb_rows = LNB_ROWS;   // rows per wave, atomic form
-static int g_lnb_rows_p = LNB_ROWS; // rows per wave, two-stage form (measured 8 / 4 / 2 / 1: 37 / 27 / 30 / 45 us at 3140 x 768)
-extern "C" int dupl_set_lnb_rows(int32_t n) {
-    if (n < 0 || n > 64) return DUPL_ERR_ARG;
-    g_lnb_rows = n ? n : LNB_ROWS;
-    g_lnb_rows_p = n ? n : LNB_ROWS;
-    return DUPL_OK;
+// rows per wave (a block = 4 waves): measured 8 / 4 / 2 / 1: 37 / 27 / 30 / 45 us at 3140 x 768 in the two-stage form; the caller
+// may override it per call (rows_per_wave, 0 = LNB_ROWS) -- nothing here is process-global
+extern "C" int dupl_layernorm_bwd_blocks(int64_t rows, int32_t rows_per_wave) {
+    const int rpw = rows_per_wave > 0 ? rows_per_wave : LNB_ROWS;
+    return 4 * (int)((rows + 4 * rpw - 1) / (4 * rpw));
 }
-extern "C" int dupl_layernorm_bwd_blocks(int64_t rows) { return 4 * (int)((rows + 4 * g_lnb_rows_p - 1) / (4 * g_lnb_rows_p)); }
 
-extern "C" int dupl_layernorm_bwd3(const float* dy, const float* x, const float* gamma, const float* mean,
-                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                                   int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows, dupl_stream_t s);
 extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                                  int64_t rows, int32_t D, dupl_stream_t s) {
-    return dupl_layernorm_bwd3(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, nullptr, nullptr, 0, s);
-}
-extern "C" int dupl_layernorm_bwd2(const float* dy, const float* x, const float* gamma, const float* mean,
-                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                                   int64_t rows, int32_t D, void* amax_out, dupl_stream_t s) {
-    return dupl_layernorm_bwd3(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, amax_out, nullptr, 0, s);
-}
-extern "C" int dupl_layernorm_bwd3(const float* dy, const float* x, const float* gamma, const float* mean,
-                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                                   int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows, dupl_stream_t s) {
+                                  int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows,
+                                  int32_t rows_per_wave, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256)
         return DUPL_ERR_ARG;
     const bool want_dgb = dgamma || dbeta;
     const bool two_stage = partials && want_dgb;
-    const int rpw = two_stage ? g_lnb_rows_p : g_lnb_rows;
+    if (rows_per_wave < 0 || rows_per_wave > 64) return DUPL_ERR_ARG;
+    const int rpw = rows_per_wave > 0 ? rows_per_wave : LNB_ROWS;
     const int grid = (int)((rows + 4 * rpw - 1) / (4 * rpw));
     if (two_stage && partial_rows < 4 * (int64_t)grid) return DUPL_ERR_ARG;      // one partial row per wave
     // deterministic mode: the two-stage form with a single, fixed-order second stage; without a partials buffer the

@@ -120,6 +120,9 @@ FMT1 = os.environ.get("DUPL_FMT1", "1") != "0"
 # no transposed planes, no fp32 copies of ln1 / ln2 / h1, single-accumulator kernels (round 4; DUPL_KM_BWD=0 restores the
 # transposed-planes path, which sites whose planes are not format 1 take in any case)
 KM_BWD = os.environ.get("DUPL_KM_BWD", "1") != "0"
+# data gradients with a linear epilogue (fc1, qkv: their dx goes to a LayerNorm backward) as stream-K launches into a zero-filled dx
+SK_DGRAD = os.environ.get("DUPL_SK_DGRAD", "1") != "0"
+SK_DGRAD_MAX_COLS = 1024
 
 
 class FlatStorage:
@@ -961,8 +964,14 @@ def _linear_backward16_km(P: StudentParams, dy: Tensor, x16, name: str, dgelu_of
     ops.linear16(dy16, x16, out=gw.view(N, -1), accumulate=True, alpha=alpha, a_kmajor=True, b_kmajor=True, k_pad=Kp)
     if not fuse_bias:
         ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
-    dx, _ = ops.linear16(dy16.rows_slice(0, M), P.w16(name + ".weight", N, True), alpha=alpha, dgelu_of=dgelu_of,
-                         amax_for_next=dx_feeds_split, b_kmajor=True)
+    W16 = P.w16(name + ".weight", N, True)
+    if SK_DGRAD and dgelu_of is None and not dx_feeds_split and not ops.deterministic() and W16.cols <= SK_DGRAD_MAX_COLS:
+        # plain dx = alpha dy . W whose consumer reads fp32 (LayerNorm backward): stream-K into a zero-filled dx -- the narrow
+        # outputs (768 columns = 78 tiles of 256 x 128 at 4 images, 42 at 2) then occupy every CU
+        dx = ops.zeros((M, W16.cols), dy.device)
+        ops.linear16(dy16.rows_slice(0, M), W16, out=dx, accumulate=True, alpha=alpha, b_kmajor=True)
+        return dx
+    dx, _ = ops.linear16(dy16.rows_slice(0, M), W16, alpha=alpha, dgelu_of=dgelu_of, amax_for_next=dx_feeds_split, b_kmajor=True)
     return dx
 
 

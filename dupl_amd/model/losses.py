@@ -203,7 +203,7 @@ def gmm_noise_filter_(ce_map, label, ignore_index=255, gmm_valid_thre=1.0, gamma
     assert ver in ("1.0.2", "1.2+"), ver
     import ctypes
     raw = _gmm_raw_words(int(random_state))
-    rc = L().dupl_gmm_noise_filter2(ce.data_ptr(), label.data_ptr(), xs.data_ptr(), lab.data_ptr(), stats.data_ptr(), b, HW,
+    rc = L().dupl_gmm_noise_filter(ce.data_ptr(), label.data_ptr(), xs.data_ptr(), lab.data_ptr(), stats.data_ptr(), b, HW,
                                     int(ignore_index), float(min_ce), int(min_count), float(gmm_valid_thre), float(gamma),
                                     float(reg_covar), float(tol), int(max_iter), u0, u1, u2, 1 if ver == "1.0.2" else 0,
                                     ctypes.cast(raw, ctypes.c_void_p), _stream())

@@ -42,6 +42,11 @@ def _chk(t: Tensor, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+# per-call launch tuning of dupl_gemm_f32 (dupl_gemm_desc.tile_rows / tile_cols / group; 0 = the library's heuristic): the Python
+# caller's defaults, not library state
+GEMM32_TUNING = {"tile_rows": 0, "tile_cols": 0, "group": 0}
+
+
 def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, flags: int = 0,
              bias: Optional[int] = None, res: Optional[int] = None, ldr: int = 0, aux: Optional[int] = None,
              ldaux: int = 0, alpha: float = 1.0, batch: int = 1, zdiv: int = 1,
@@ -60,6 +65,7 @@ def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int,
     d.sX0, d.sX1 = sX
     d.sBias0, d.sBias1 = sBias
     d.alpha, d.flags = alpha, flags
+    d.tile_rows, d.tile_cols, d.group = GEMM32_TUNING["tile_rows"], GEMM32_TUNING["tile_cols"], GEMM32_TUNING["group"]
     L().dupl_gemm_f32(ctypes.byref(d), _stream())
 
 
@@ -191,7 +197,7 @@ class _AmaxToken:
 def reserve_amax(device):
     """For a kernel that is about to PRODUCE a tensor whose next use on this stream is a scaled split_prepare: the amax word
     of the slot that split will take, and a token.  The producer raises the word to max |tensor| (dupl_gemm16_desc.amax_out,
-    dupl_layernorm_bwd2); tag the tensor with `t._dupl_amax = token` and split_prepare skips its own amax pass.  Returns
+    dupl_layernorm_bwd); tag the tensor with `t._dupl_amax = token` and split_prepare skips its own amax pass.  Returns
     (None, None) while an earlier reservation is still open (one producer per slot).  A tagged tensor that is modified
     in place afterwards must drop the tag (`t._dupl_amax = None`); an unclaimed or stale word is cleared by the next
     scaled split on the stream (amax_mode 2)."""
@@ -308,6 +314,7 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     assert xf == wf, f"operand planes in different formats (fmt {xf} / {wf}, exp {xe} / {we})"
     if xf:
         assert (a_kmajor or b_kmajor) or (not accumulate and not amax_for_next)
+        assert not (accumulate and b_kmajor and not a_kmajor and deterministic()), "stream-K data gradients use fp32 atomics"
         d.fmt, d.post_scale = 1, 2.0 ** -(xe + we + post_exp)
     if a_kmajor or b_kmajor:
         assert xf == 1, "k-major operands need format 1 planes"
@@ -423,15 +430,18 @@ def layernorm_fwd16(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, save: bo
     if save:
         mean = torch.empty(keep, device=x.device, dtype=torch.float32)
         rstd = torch.empty(keep, device=x.device, dtype=torch.float32)
-    L().dupl_layernorm_fwd16c(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y), y16.hi, y16.lo, _p(mean), _p(rstd), rows, D,
-                              eps, int(f32_rows), int(exp), _stream())
+    L().dupl_layernorm_fwd16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y), y16.hi, y16.lo, _p(mean), _p(rstd), rows, D,
+                             eps, int(f32_rows), int(exp), _stream())
     return y, y16, mean, rstd
+
+
+LNB_ROWS_PER_WAVE = 0      # dupl_layernorm_bwd's rows_per_wave (0 = the library default; tools/op_bench.py sweeps it)
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor,
                   dres: Optional[Tensor] = None, amax_for_next: bool = False, two_stage: Optional[bool] = None) -> Tensor:
     """Returns dx = dres + LN'(dy); accumulates into dgamma / dbeta -- fp32 atomics from the main kernel, or (two_stage; the
-    default in deterministic mode) per-block partial sums + a fixed-order reduce kernel (dupl_layernorm_bwd3).
+    default in deterministic mode) per-block partial sums + a fixed-order reduce kernel (dupl_layernorm_bwd's partials).
     amax_for_next: as in linear16."""
     rows, D = x.shape
     if two_stage is None:
@@ -440,10 +450,10 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     word, tok = reserve_amax(x.device) if amax_for_next else (None, None)
     part, nb = None, 0
     if two_stage:
-        nb = L().dupl_layernorm_bwd_blocks(rows)
+        nb = L().dupl_layernorm_bwd_blocks(rows, LNB_ROWS_PER_WAVE)
         part = torch.empty((nb, 2 * D), device=x.device, dtype=torch.float32)
-    L().dupl_layernorm_bwd3(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
-                            dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, word, _p(part), nb, _stream())
+    L().dupl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
+                           dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, word, _p(part), nb, LNB_ROWS_PER_WAVE, _stream())
     if tok is not None:
         dx._dupl_amax = tok
     return dx
@@ -475,7 +485,7 @@ def attention_fwd16(qkv16, B: int, N: int, H: int, hd: int, scale: float, need_l
     if out is not None:
         assert out.shape == (bf * N, H * hd) and out.is_contiguous()
     assert getattr(qkv16, "exp", 0) == 0, "the split attention reads format 0 planes"
-    L().dupl_attention_fwd16c(qkv16.hi, qkv16.lo, vt.data_ptr(), vt.data_ptr() + 2 * vt.shape[1], _p(out),
+    L().dupl_attention_fwd16(qkv16.hi, qkv16.lo, vt.data_ptr(), vt.data_ptr() + 2 * vt.shape[1], _p(out),
                               out16.hi if out16 is not None else None, out16.lo if out16 is not None else None, _p(lse),
                               B, N, H, hd, npad, float(scale), bf, out16.exp if out16 is not None else 0, _stream())
     return lse
@@ -495,9 +505,9 @@ def attention_bwd16(qkv16, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: in
     delta = torch.empty((B, H, N), device=dev, dtype=torch.float32)
     dqkv = torch.empty((B * N, 3 * H * hd), device=dev, dtype=torch.float32)
     word, tok = reserve_amax(dev) if amax_for_next else (None, None)       # after dout's split took its slot
-    L().dupl_attention_bwd16b(qkv16.hi, qkv16.lo, out.data_ptr(), dout.data_ptr(), do16.hi, do16.lo, int(alpha) - 4, lse.data_ptr(),
-                              delta.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(), B, N, H, hd, npad, float(scale), word,
-                              _stream())
+    L().dupl_attention_bwd16(qkv16.hi, qkv16.lo, out.data_ptr(), dout.data_ptr(), do16.hi, do16.lo, int(alpha) - 4, lse.data_ptr(),
+                             delta.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(), B, N, H, hd, npad, float(scale), word,
+                             _stream())
     if tok is not None:
         dqkv._dupl_amax = tok
     return dqkv
@@ -569,7 +579,8 @@ def resize_bilinear(x: Tensor, Ho: int, Wo: int, flip_cat: bool = False, align_c
     return out
 
 
-def cam_fuse(lows: Sequence[Tensor], sizes: Sequence[tuple], B: int, C: int, H: int, W: int, row_off: int, ldc: int):
+def cam_fuse(lows: Sequence[Tensor], sizes: Sequence[tuple], B: int, C: int, H: int, W: int, row_off: int, ldc: int,
+             impl: int = 0, band_blocks: int = 0):
     """lows[i]: [2B*(row_off+hs*ws), ldc] CAM logits of scale i.  Returns (cam (B,C,H,W) un-normalised, mm [B*C,2])."""
     n = len(lows)
     ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lows])
@@ -578,7 +589,7 @@ def cam_fuse(lows: Sequence[Tensor], sizes: Sequence[tuple], B: int, C: int, H: 
     cam = torch.empty((B, C, H, W), device=lows[0].device, dtype=torch.float32)
     mm = torch.empty((B * C, 2), device=lows[0].device, dtype=torch.float32)
     L().dupl_cam_fuse(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(hs, ctypes.c_void_p), ctypes.cast(ws, ctypes.c_void_p),
-                      n, row_off, ldc, cam.data_ptr(), mm.data_ptr(), B, C, H, W, _stream())
+                      n, row_off, ldc, cam.data_ptr(), mm.data_ptr(), B, C, H, W, int(impl), int(band_blocks), _stream())
     return cam, mm
 
 

@@ -50,6 +50,10 @@ int dupl_get_deterministic(void);
 #define DUPL_GEMM_ABS 128       /* v = |v|  (PTC cosine matrix) */
 #define DUPL_GEMM_STORE_PRE 256 /* also WRITE the pre-activation (alpha*acc+bias) to aux[m][n] (training forward of fc1) */
 typedef struct dupl_gemm_desc {
+    uint32_t struct_size;  /* sizeof(dupl_gemm_desc) of the caller's header; a mismatch is refused */
+    int32_t tile_rows;     /* launch tuning, per call (0 = heuristic): row tile 64 / 128 */
+    int32_t tile_cols;     /* column tile of the 64-row kernels, 64 / 128 */
+    int32_t group;         /* row tiles per group of the block -> C-tile order inside an XCD band (0 = 16; 4096 = plain row-major) */
     const float* A; const float* B; float* C;
     const float* bias;     /* [N] or NULL, added before the activation */
     const float* res;      /* [M][ldr] or NULL, added after the activation */
@@ -169,13 +173,6 @@ typedef struct dupl_bound_desc {
     int32_t rows, cols;
 } dupl_bound_desc;
 int dupl_param_bounds(const float* base, const dupl_bound_desc* table_dev, int32_t n, float* out, dupl_stream_t stream);
-/* tuning knob (no reference counterpart): force the GEMM row-tile (64 or 128 rows; 0 = built-in heuristic) */
-int dupl_set_gemm_tile(int32_t rows);
-/* tuning knob (no reference counterpart): column tile of the 64-row GEMM kernels, 64 or 128 (0 = heuristic on the grid) */
-int dupl_set_gemm_ncols(int32_t cols);
-/* tuning knob (no reference counterpart): row-tiles per group of the block -> C-tile order inside an XCD band
- * (default 16; 4096 = plain row-major) */
-int dupl_set_gemm_group(int32_t gm);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim D (D % 4 == 0, D <= 2048), one wavefront per row.
@@ -186,33 +183,23 @@ int dupl_set_gemm_group(int32_t gm);
 int dupl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s);
 /* the same LayerNorm writing its output (also / only) as f16x3 operand planes y_hi / y_lo [rows][D] fp16 for
- * dupl_gemm_f16x3 (y may be NULL when only the planes are wanted; y_hi / y_lo both NULL = dupl_layernorm_fwd) */
+ * dupl_gemm_f16x3 (y may be NULL when only the planes are wanted; y_hi / y_lo both NULL = dupl_layernorm_fwd).
+ * f32_rows > 0: the fp32 copy y (and mean / rstd) is written for the first f32_rows rows only and has that many rows (the
+ * shared ms-CAM / training pass back-propagates only those); plane_exp > 0: the planes in format 1 (y * 2^plane_exp, unscaled
+ * lo: dupl_gemm16_desc.fmt) */
 int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
-                         float* rstd, int64_t rows, int32_t D, float eps, dupl_stream_t s);
-/* the same with the fp32 copy y (and mean / rstd) written for the first f32_rows rows only (0 = all): y then has f32_rows rows */
-int dupl_layernorm_fwd16b(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
-                          float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows, dupl_stream_t s);
-/* the same with the planes in format 1 (y * 2^plane_exp, unscaled lo: dupl_gemm16_desc.fmt) when plane_exp > 0 */
-int dupl_layernorm_fwd16c(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo, float* mean,
-                          float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows, int32_t plane_exp, dupl_stream_t s);
-/* LayerNorm backward (autograd of vit.py:157,159,323), optionally fused with the residual-stream gradient add */
+                         float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows, int32_t plane_exp, dupl_stream_t s);
+/* LayerNorm backward (autograd of vit.py:157,159,323), optionally fused with the residual-stream gradient add (dres).
+ * amax_out != NULL: max |dx| is raised into *amax_out (the amax word of a scale slot, see dupl_split_prepare amax_mode 1).
+ * partials != NULL (two-stage dgamma / dbeta): every wave writes its partial sums to partials [partial_rows][2 D] (partial_rows >=
+ * dupl_layernorm_bwd_blocks(rows, rows_per_wave)) and a second kernel adds them up -- in a fixed order under
+ * dupl_set_deterministic(1): the bit-reproducible form without a second pass over dy and x (not faster than the atomics: 27 vs
+ * 22 us at 3140 x 768); partials == NULL: one kernel, fp32 atomics.  rows_per_wave: 0 = default (4); a block = 4 waves. */
+int dupl_layernorm_bwd_blocks(int64_t rows, int32_t rows_per_wave);   /* a count, not a status */
 int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                       int64_t rows, int32_t D, dupl_stream_t s);
-/* tuning knob: rows per wave of the LayerNorm backward kernel (a block = 4 waves); 0 = default (4) */
-int dupl_set_lnb_rows(int32_t n);
-/* two-stage dgamma / dbeta: every wave writes its partial sums to partials [partial_rows][2 D] (partial_rows >=
- * dupl_layernorm_bwd_blocks(rows)) and a second kernel adds them up in a fixed order when dupl_set_deterministic(1) -- the
- * bit-reproducible form without a second pass over dy and x.  (Not faster than the atomics: 27 vs 22 us at 3140 x 768.)
- * partials == NULL: the one-kernel atomic form of dupl_layernorm_bwd2. */
-int dupl_layernorm_bwd_blocks(int64_t rows);   /* a count, not a status */
-int dupl_layernorm_bwd3(const float* dy, const float* x, const float* gamma, const float* mean,
-                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                        int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows, dupl_stream_t s);
-/* the same, and max |dx| raised into *amax_out (the amax word of a scale slot, see dupl_split_prepare3) when amax_out != NULL */
-int dupl_layernorm_bwd2(const float* dy, const float* x, const float* gamma, const float* mean,
-                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                        int64_t rows, int32_t D, void* amax_out, dupl_stream_t s);
+                       int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows, int32_t rows_per_wave,
+                       dupl_stream_t s);
 
 /* column sums: out[n] (+)= sum_m x[m][n]: the bias gradients autograd derives for nn.Linear (vit.py:92-102,115-122)
  * and the patch-embed conv (vit.py:176-183).  accumulate!=0 adds to out (atomic). */
@@ -232,25 +219,16 @@ int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int3
  * from the fp16 hi / lo planes of the qkv GEMM output ([B*N][3*H*hd] halfs each), S = q k^T and O = P v are
  * hi hi + (hi lo + lo hi) / 2048 on v_mfma_f32_32x32x16_f16 with fp32 accumulation, softmax in fp32.  vT_hi / vT_lo:
  * scratch of B*H*hd*Npad halfs each (V^T planes, written first); Npad = N rounded up to a multiple of 64.
- * out (fp32) and / or out_hi / out_lo (planes, the A operand of the projection GEMM); lse optional. */
-int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
-                         void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
-                         dupl_stream_t s);
-/* the same with the fp32 output and lse written for the first B_f32 images only (out: [B_f32*N][H*hd], lse: [B_f32][H][N]); the
- * planes for all B */
-int dupl_attention_fwd16b(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi, void* out_lo,
-                          float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, int32_t B_f32,
-                          dupl_stream_t s);
-/* the same with the output planes in format 1 (out * 2^out_exp, unscaled lo) when out_exp > 0 */
-int dupl_attention_fwd16c(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi, void* out_lo,
-                          float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s);
+ * out (fp32) and / or out_hi / out_lo (planes, the A operand of the projection GEMM); lse optional.
+ * B_f32 (0 = B): the fp32 output and lse are written for the first B_f32 images only (out: [B_f32*N][H*hd], lse: [B_f32][H][N]),
+ * the planes for all B; out_exp > 0: the output planes in format 1 (out * 2^out_exp, unscaled lo). */
+int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi, void* out_lo,
+                         float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, int32_t B_f32,
+                         int32_t out_exp, dupl_stream_t s);
 /* backward (what autograd derives for vit.py:123-135): dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N]. */
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,
                        float scale, dupl_stream_t s);
-/* tuning knob (no reference counterpart): 1 (default) = XCD-aware workgroup order of the attention kernels (whole
- * heads per XCD), 0 = plain */
-int dupl_set_attention_remap(int32_t on);
 
 /* ---------------------------------------------------------------------------------------------
  * Token plumbing (vit.py:176-184, 289-306; model_dupl.py:64-67, 88-95). */
@@ -287,13 +265,12 @@ int dupl_resize_bilinear(const float* in, float* out, int32_t B, int32_t C, int3
 /* Fused ms-CAM: lows[i] = token-major CAM logits of scale i, [2B][row_off + hs*ws][ldc] (first B images = original
  * input, last B = w-flipped input; row_off = 1 skips the cls row).
  *   cam[b][c][y][x] = sum_i relu(max(up_i(low_i[b])(y,x), up_i(low_i[B+b])(y, W-1-x)))       (cam_helper.py:173-196)
- * and mm[b*C+c] = {min, max} over the plane.  `lows`, `hs`, `ws` are HOST arrays of nscale (<= 4) entries. */
+ * and mm[b*C+c] = {min, max} over the plane.  `lows`, `hs`, `ws` are HOST arrays of nscale (<= 4) entries.
+ * impl (test / tuning, per call): 0 = the library's choice (the LDS-staged band kernel where it applies), 1 = the per-pixel kernel
+ * (same bits); band_blocks: blocks the band kernel aims at (bands = blocks / planes, at least 8 rows each), 0 = 768. */
 int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const int32_t* ws, int32_t nscale, int32_t row_off,
-                  int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, dupl_stream_t s);
-/* test / tuning knob (no reference counterpart): 1 = LDS-staged band kernel (default), 0 = per-pixel kernel; same bits */
-int dupl_set_cam_fuse_impl(int32_t impl);
-/* tuning knob: blocks the band kernel aims at (bands = blocks / planes, at least 8 rows each) */
-int dupl_set_cam_fuse_blocks(int32_t n);
+                  int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, int32_t impl,
+                  int32_t band_blocks, dupl_stream_t s);
 /* per plane, in place: cam = (cam - min) / ((max - min) + 1e-5)  == `cam + maxpool(-cam); cam /= maxpool(cam) + 1e-5`
  * (cam_helper.py:197-199).  mm [planes][2]; have_minmax = 0 recomputes it first. */
 int dupl_cam_minmax_normalise(float* cam, float* mm, int32_t planes, int32_t HW, int32_t have_minmax, dupl_stream_t s);
@@ -379,19 +356,14 @@ int dupl_seg_pseudo_label(const float* logits, const float* other_label, int32_t
  * stats [B][DUPL_GMM_STATS] = {n selected, filtered?, mean0, mean1, cov0, cov1, weight0, weight1, EM iterations,
  * Lloyd iterations, mean log-likelihood, k-means centre0, centre1, #pixels relabelled, first seed index, second}. */
 #define DUPL_GMM_STATS 16
-/* (train_final_voc.py:363-394, see the comment above) */
+/* (train_final_voc.py:363-394, see the comment above).  seeding selects the k-means++ variant: 0 = sklearn >= 1.2 (the three
+ * uniforms above), 1 = sklearn 1.0.2, the version the reference pins (requirements.txt:4): first centre = RandomState.randint(n),
+ * numpy's masked rejection on 32-bit MT19937 words, the trial uniforms from the words after it; mt_raw_host = the first 48 32-bit
+ * outputs of RandomState(seed) (a HOST array, copied into the launch; NULL with seeding 0). */
 int dupl_gmm_noise_filter(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch, float* stats,
                           int32_t B, int32_t HW, int32_t ignore_index, float min_ce, int32_t min_count,
                           float valid_thre, float gamma, float reg_covar, float em_tol, int32_t em_iters, double u0,
-                          double u1, double u2, dupl_stream_t s);
-/* the same with the k-means++ seeding selectable: seeding 0 = sklearn >= 1.2 (the three uniforms above), 1 = sklearn 1.0.2, the
- * version the reference pins (requirements.txt:4): first centre = RandomState.randint(n), numpy's masked rejection on 32-bit
- * MT19937 words, the trial uniforms from the words after it; mt_raw_host = the first 48 32-bit outputs of RandomState(seed)
- * (a HOST array, copied into the launch). */
-int dupl_gmm_noise_filter2(const float* ce_map, float* label, float* xs_scratch, uint8_t* lab_scratch, float* stats,
-                           int32_t B, int32_t HW, int32_t ignore_index, float min_ce, int32_t min_count,
-                           float valid_thre, float gamma, float reg_covar, float em_tol, int32_t em_iters, double u0,
-                           double u1, double u2, int32_t seeding, const uint32_t* mt_raw_host, dupl_stream_t s);
+                          double u1, double u2, int32_t seeding, const uint32_t* mt_raw_host, dupl_stream_t s);
 /* label[i] = value where mask[i] != 0 (noise-mask write-back, train_final_voc.py:381,393) */
 int dupl_mask_fill(float* label, const uint8_t* mask, float value, int64_t n, dupl_stream_t s);
 /* dlogits (token-major, zero first) += gscale[0] * d loss / d logits (wave-reduced atomics when H/h, W/w are multiples
@@ -462,12 +434,9 @@ int dupl_multilabel_f1_accum(const float* logits, const float* label, int32_t B,
  * vit.py:123-135.  qkv_hi / qkv_lo: planes of the qkv GEMM output saved by the forward; out / dout: fp32 attention output
  * and its gradient ([B*N][H*hd]); do_hi / do_lo + do_slot: dout as planes scaled with target_exp 4 (dupl_split_prepare;
  * do_slot = its {scale, 1/scale,..} record); lse from the forward; delta: B*H*N floats of scratch; scratch_T: 6 planes of
- * B*H*hd*Npad halfs (K^T, Q^T, dO^T); dqkv [B*N][3*H*hd] fp32 receives dq | dk | dv. */
+ * B*H*hd*Npad halfs (K^T, Q^T, dO^T); dqkv [B*N][3*H*hd] fp32 receives dq | dk | dv.  amax_out != NULL: max |dqkv| is raised into
+ * *amax_out (the amax word of a scale slot, see dupl_split_prepare amax_mode 1). */
 int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
-                         const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T, float* dqkv,
-                         int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, dupl_stream_t stream);
-/* the same, and max |dqkv| raised into *amax_out (the amax word of a scale slot, see dupl_split_prepare3) when amax_out != NULL */
-int dupl_attention_bwd16b(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
                          const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T, float* dqkv,
                          int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, void* amax_out, dupl_stream_t stream);
 

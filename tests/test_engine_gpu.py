@@ -563,24 +563,53 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     # a 784 b-term row sum of dW7 / dW6 (~1 / 1568 of it at 2 images: 6e-4).  As for the label maps, a relaxed bar is only granted
     # with proof: the product's own ReLU masks (a forward of the same student) against the oracle's, the flipped decisions counted
     # and each required to have an oracle pre-activation below 1e-4 of the layer's largest.
-    flips = _decoder_relu_flips(model, pp, pc, inputs.to(dev)) if any(not errs[k] < bar for k in order) else {}
-    relaxed = {}
+    flips, masks = _decoder_relu_flips(model, pp, pc, inputs.to(dev)) if any(not errs[k] < bar for k in order) else ({}, None)
+    nflip = 0
     for br, (n6, n7, worst) in flips.items():
         print(f"full-size {case} {br} decoder ReLU decisions that differ from the oracle's: conv6 {n6}, conv7 {n7}; largest "
               f"|oracle pre-activation| among them {worst:.2e} of the layer maximum (bar 1e-4)")
         assert worst < 1e-4, "a ReLU decision differs where the oracle's pre-activation is NOT at round-off level"
-        if n6 + n7:
-            relaxed[br + "decoder.conv7.weight"] = relaxed[br + "decoder.conv6.weight"] = 2e-4 + 1.5e-3 * (n6 + n7)
-    bad = [(k, errs[k]) for k in order if not errs[k] < relaxed.get(k, bar)]
+        nflip += n6 + n7
+    if nflip:
+        # the proof: the oracle run AGAIN with the product's ReLU decisions imposed on its LargeFOV (everything else untouched) must
+        # put every tensor back under the strict bar -- then the flipped decisions are the whole difference
+        import torch.nn.functional as F
+        used, orig = [0], F.relu
+
+        def relu_with_product_mask(x, *a, **kw):       # the oracle's LargeFOV ReLUs of the main forward, in call order
+            i = used[0]
+            if i < len(masks) and x.dim() == 4 and tuple(x.shape) == tuple(masks[i].shape):
+                used[0] += 1
+                return x * masks[i].to(x.dtype)
+            return orig(x, *a, **kw)
+
+        leaf2 = {k: v.clone().requires_grad_(k in watch) for k, v in pp.items()}
+        F.relu = relu_with_product_mask
+        try:
+            if case == "voc_C":
+                random.seed(77)
+            ref2, _ = O.train_step_losses(leaf2, inputs, cls_label, img_box, n_iter, cfg, oargs, inputs_aug=aug)
+            ref2.sum().backward()
+        finally:
+            F.relu = orig
+        assert used[0] == len(masks), "the oracle did not pass through its four LargeFOV ReLUs in the expected order"
+        for k in watch:
+            got = model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True).cpu()
+            errs[k] = float((got - leaf2[k].grad).abs().max() / leaf2[k].grad.abs().max().clamp_min(1e-30))
+        order = sorted(errs, key=errs.get)
+        print(f"full-size {case} [{gemm_mode}] gradients vs the oracle with the product's {nflip} flipped ReLU decision(s) imposed: worst "
+              f"{errs[order[-1]]:.2e} ({order[-1]}), bar {bar:.0e}")
+    bad = [(k, errs[k]) for k in order if not errs[k] < bar]
     assert not bad, f"{len(bad)} gradient tensors above {bar:.0e}: {bad[:8]}"
 
 
 def _decoder_relu_flips(model, pp, pc, x_dev):
-    """{"branchK.": (flipped conv6 decisions, flipped conv7 decisions, largest |oracle pre-activation| / layer max among them)}:
+    """({"branchK.": (flipped conv6 decisions, flipped conv7 decisions, largest |oracle pre-activation| / layer max among them)},
+    [the product's masks (B, 512, h, w) in the order the oracle applies its ReLUs: student 1 conv6, conv7, student 2 conv6, conv7]):
     the ReLU masks of the product's LargeFOV forward against the oracle's (conv_head.py:32-41 on the oracle's own x4)."""
     import torch.nn.functional as F
     from dupl_amd import engine
-    out = {}
+    out, masks = {}, []
     for s_, net in enumerate((model.branch1, model.branch2)):
         br = f"branch{s_ + 1}."
         with torch.no_grad():
@@ -595,12 +624,13 @@ def _decoder_relu_flips(model, pp, pc, x_dev):
         worst = 0.0
         for pre, got in ((pre6, sv.h6), (pre7, sv.h7)):
             g = got.view(B, h * w, -1).permute(0, 2, 1).reshape(B, -1, h, w).cpu() > 0
+            masks.append(g)
             f = g != (pre > 0)
             res.append(int(f.sum()))
             if res[-1]:
                 worst = max(worst, float(pre.abs()[f].max() / pre.abs().max()))
         out[br] = (res[0], res[1], worst)
-    return out
+    return out, masks
 
 
 @pytest.mark.parametrize("b,H,W", [(1, 96, 160), (3, 128, 96), (2, 80, 80)])

@@ -25,9 +25,9 @@ def relerr(a, b):
 def gemm_ncols(request):
     """Run a GEMM test with the column tile of the 64-row kernels forced to 64 / 128 and with the heuristic."""
     from dupl_amd import ops
-    ops.L().dupl_set_gemm_ncols(request.param)
+    ops.GEMM32_TUNING["tile_cols"] = request.param        # dupl_gemm_desc.tile_cols: a per-call field (ABI 2)
     yield request.param
-    ops.L().dupl_set_gemm_ncols(0)
+    ops.GEMM32_TUNING["tile_cols"] = 0
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (257, 131, 70), (6280 // 8, 768, 768), (50, 20, 96), (300, 2304, 768)])
@@ -527,7 +527,7 @@ def _gmm_case(kind, H, W, seed):
 @pytest.mark.parametrize("H,W", [(128, 128), (448, 448), (97, 131)])
 @pytest.mark.parametrize("skver", ["1.2+", "1.0.2"])
 def test_gmm_noise_filter_vs_sklearn(dev, H, W, skver):
-    """dupl_gmm_noise_filter2 vs the reference's sklearn call (oracle.gmm_noise_filter_ restates train_final_voc.py:
+    """dupl_gmm_noise_filter vs the reference's sklearn call (oracle.gmm_noise_filter_ restates train_final_voc.py:
     363-394): same k-means++ seeds, fitted parameters to 1e-3, relabelled pixels identical up to threshold ties -- for the
     seeding of the installed scikit-learn ("1.2+": first centre by RandomState.choice) and for that of the reference's pin
     ("1.0.2", requirements.txt:4: RandomState.randint, i.e. masked rejection on the raw MT19937 words; the sklearn side is
@@ -779,7 +779,7 @@ def test_attention_bwd16_is_fp32_equivalent(dev, B, N):
         e32 = float((d32[:, sl].double() - ref[:, sl]).abs().max()) / sc
         print(f"B{B} N{N} {name}: f16x3 {e16:.2e} f32 {e32:.2e}")
         assert e16 <= 2.0 * e32 + 5e-7, name
-    # the three kernels leave max |dqkv| for the split that reads dqkv next (dupl_attention_bwd16b; ops.reserve_amax)
+    # the three kernels leave max |dqkv| for the split that reads dqkv next (dupl_attention_bwd16; ops.reserve_amax)
     ring = ops._scale_ring(dev)
     d16b = ops.attention_bwd16(qkv16, out16, dout, lse16, B, N, H, hd, scale, amax_for_next=True)
     assert torch.equal(d16b, d16) and d16b._dupl_amax is ring[2]
@@ -947,11 +947,8 @@ def test_cam_fuse_band_kernel_is_bit_identical(dev, B, C, H, W, sizes):
     from dupl_amd import ops
     g = torch.Generator().manual_seed(B * 100 + C)
     lows = [torch.randn(2 * B * (1 + h * w), C, generator=g).to(dev) for (h, w) in sizes]
-    L = ops.L()
-    assert L.dupl_set_cam_fuse_impl(0) == 0
-    cam0, mm0 = ops.cam_fuse(lows, sizes, B, C, H, W, 1, C)
-    assert L.dupl_set_cam_fuse_impl(1) == 0
-    cam1, mm1 = ops.cam_fuse(lows, sizes, B, C, H, W, 1, C)
+    cam0, mm0 = ops.cam_fuse(lows, sizes, B, C, H, W, 1, C, impl=1)          # the per-pixel kernel
+    cam1, mm1 = ops.cam_fuse(lows, sizes, B, C, H, W, 1, C)                  # the library's choice: the band kernel
     torch.cuda.synchronize()
     assert torch.equal(cam0, cam1) and torch.equal(mm0, mm1)
     assert float(cam1.max()) > 0 and float(mm1[:, 0].min()) == 0.0
@@ -960,7 +957,7 @@ def test_cam_fuse_band_kernel_is_bit_identical(dev, B, C, H, W, sizes):
 @pytest.mark.parametrize("tile", [0, 3, 5, 6, 10])
 @pytest.mark.parametrize("M,N,K", [(3140, 768, 3072), (3140, 3072, 768), (130, 96, 288)])
 def test_producer_amax_replaces_the_amax_pass(dev, M, N, K, tile):
-    """dupl_gemm16_desc.amax_out / dupl_layernorm_bwd2: the kernel that WRITES a gradient leaves max |gradient| in the scale
+    """dupl_gemm16_desc.amax_out / dupl_layernorm_bwd: the kernel that WRITES a gradient leaves max |gradient| in the scale
     slot of the split that reads it next (ops.reserve_amax), so dupl_split_prepare runs without its own amax pass
     (amax_mode 1).  Bars: the word equals the tensor's max-abs bit for bit; the planes and the scale are identical to those of
     the stand-alone pass; an unclaimed reservation (tensor modified / not split next) is cleared (amax_mode 2)."""
@@ -1026,7 +1023,7 @@ def test_layernorm_bwd_leaves_amax_for_the_next_split(dev, rows, D):
     a16, _, _ = ops.split_prepare(dx, scaled=True, want_rm=True, want_T=False)
     b16, _, _ = ops.split_prepare(ref, scaled=True, want_rm=True, want_T=False)
     assert torch.equal(a16.planes, b16.planes) and torch.equal(a16.planes._dupl_scale[:2], b16.planes._dupl_scale[:2])
-    # two-stage dgamma / dbeta (dupl_layernorm_bwd3: per-block partials + reduce kernel): same sums, same dx; fixed order
+    # two-stage dgamma / dbeta (dupl_layernorm_bwd: per-block partials + reduce kernel): same sums, same dx; fixed order
     # (bit-reproducible) in deterministic mode
     xh = ((x - mean[:, None]) * rstd[:, None]).double()
     for det in (0, 1):
@@ -1178,7 +1175,7 @@ def test_gemm_f16x3_format1_is_fp32_equivalent(dev, M, N, K, tile):
 
 
 def test_format1_planes_from_layernorm_and_attention(dev):
-    """dupl_layernorm_fwd16c / dupl_attention_fwd16c write their output planes in format 1 on request: the same values as the
+    """dupl_layernorm_fwd16 / dupl_attention_fwd16 write their output planes in format 1 on request: the same values as the
     fp32 output, to the format's precision."""
     from dupl_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -1237,6 +1234,15 @@ def test_kmajor_backward_gemms_are_fp32_equivalent(dev, tokens, n_out, n_in, x_r
     e16, e32 = float((dx.double() - want).abs().max()) / sc, float((dx32.double() - want).abs().max()) / sc
     print(f"k-major dgrad {tokens}x{n_in}x{n_out}: f16x3 {e16:.2e}  f32 {e32:.2e}")
     assert e16 <= 2.0 * e32 + 2e-7
+    # ---- the same data gradient with a linear epilogue as a stream-K launch into a zero-filled dx (fp32 atomics)
+    dxs = ops.zeros((tokens, n_in), dev)
+    ops.linear16(dy16.rows_slice(0, tokens), W16, out=dxs, accumulate=True, alpha=alpha, b_kmajor=True)
+    wantp = dy.double() @ W.double()
+    dxp32 = ops.linear_dgrad(dy, W)
+    scp = float(wantp.abs().max())
+    es, ep32 = float((dxs.double() - wantp).abs().max()) / scp, float((dxp32.double() - wantp).abs().max()) / scp
+    print(f"k-major stream-K dgrad {tokens}x{n_in}x{n_out}: f16x3 {es:.2e}  f32 {ep32:.2e}")
+    assert es <= 2.0 * ep32 + 2e-7
     # ---- weight gradient, accumulated onto existing values: atomics (stream-K or one block per tile) and fixed order
     c0 = (torch.randn(n_out, n_in, generator=g) * 1e-4).to(dev)
     wantw = c0.double() + dy.double().t() @ x.double()

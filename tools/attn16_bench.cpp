@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
         fill_kernel<<<1024, 256>>>(qkv, nq, 7, 1.5f);
         dupl_split_f16x2(qkv, q16, q16 + nq, nq, nullptr);
         CK(hipDeviceSynchronize());
-        auto run = [&]() { return dupl_attention_fwd16(q16, q16 + nq, vt, vt + (long)B * H * hd * npad, nullptr, o16, o16 + (long)B * N * D, lse, B, N, H, hd, npad, 0.125f, st); };
+        auto run = [&]() { return dupl_attention_fwd16(q16, q16 + nq, vt, vt + (long)B * H * hd * npad, nullptr, o16, o16 + (long)B * N * D, lse, B, N, H, hd, npad, 0.125f, 0, 0, st); };
         if (run()) { fprintf(stderr, "launch failed\n"); return 2; }
         CK(hipEventRecord(e0, st)); for (int i = 0; i < 3; ++i) run(); CK(hipEventRecord(e1, st)); CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));

@@ -37,12 +37,12 @@ def main():
     dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     if "ln_bwd" in which:
         for rpw in (8, 4, 2, 1):
-            ops.L().dupl_set_lnb_rows(rpw)
+            ops.LNB_ROWS_PER_WAVE = rpw
             t = timeit(lambda: ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, dres=dres, two_stage=False))
             t2 = timeit(lambda: ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, dres=dres, two_stage=True))
             print(f"layernorm_bwd {rows}x{D} rows/wave {rpw}: atomics {t:.1f} us ({4 * rows * D * 4 / t / 1e6:.2f} TB/s), "
                   f"two-stage {t2:.1f} us ({4 * rows * D * 4 / t2 / 1e6:.2f} TB/s)")
-        ops.L().dupl_set_lnb_rows(0)
+        ops.LNB_ROWS_PER_WAVE = 0
     if "ln_fwd" in which:
         for r in (3140, 6280, 15696):
             xx = torch.randn(r, D, generator=g).to(dev)
@@ -81,10 +81,8 @@ def main():
             sizes = [(28, 28), (14, 14), (42, 42)]
             lows = [torch.randn(2 * B * (1 + h * w), C, generator=g).to(dev) for h, w in sizes]
             for nb in (384, 512, 768, 1024, 1536, 2048, 4096):
-                ops.L().dupl_set_cam_fuse_blocks(nb)
-                t = timeit(lambda: ops.cam_fuse(lows, sizes, B, C, H, W, 1, C), n=100)
+                t = timeit(lambda: ops.cam_fuse(lows, sizes, B, C, H, W, 1, C, band_blocks=nb), n=100)
                 print(f"cam_fuse C={C} band kernel, {nb} blocks aimed at: {t:.1f} us = {B * C * H * W * 4 / t / 1e6:.2f} TB/s of output (incl. the min/max init launch)")
-            ops.L().dupl_set_cam_fuse_blocks(2048)
     if "attn_bwd" in which:
         B, N, H, hd = 4, 785, 12, 64
         qkv = torch.randn(B * N, 3 * H * hd, generator=g).to(dev)
