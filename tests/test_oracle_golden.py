@@ -428,3 +428,33 @@ def test_photometric_pillow_arithmetic_restatement():
         img = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
         ref = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=r)))
         assert np.array_equal(O.pil_gaussian_blur_np(img, r), ref), (r, h, w)
+
+
+def test_gelu_phi_coefficients():
+    """csrc/common.h::gelu_phi (the GELU / GELU' of every fc1 epilogue, vit.py:88,93 nn.GELU): its nine coefficients, read from
+    the header, evaluated the way the kernel evaluates them (fp32 Horner with fused multiply-adds, exp2) against float64
+    0.5 erfc(-x / sqrt 2) -- absolute error of GELU no larger than that of the textbook fp32 formula 0.5 x (1 + erff(x / sqrt 2))
+    with a correctly rounded erff, relative error for x > -3 below 2e-6 (oracle/fit_gelu.py derives the coefficients)."""
+    import re
+    from scipy.special import erf, erfc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "dupl_amd", "csrc", "common.h")).read()
+    body = src[src.index("float gelu_phi(float x)"):src.index("float gelu_f(float x)")]
+    nums = [float(v) for v in re.findall(r"(-?\d+\.\d+(?:e-?\d+)?)f", body)]
+    clamp, coef = nums[0], nums[1:10]            # 5.65f, then q = c8; fmaf(q, u, c7) ... fmaf(q, u, c0)
+    assert clamp == 5.65 and len(coef) == 9 and nums[10] == 0.5
+    f32 = np.float32
+    x = np.concatenate([np.linspace(-12, 12, 1000001), np.random.RandomState(0).randn(500000) * 1.5]).astype(f32)
+    u = np.minimum(np.abs(x), f32(clamp)).astype(f32)
+    q = np.full_like(u, f32(coef[0]))
+    for c in coef[1:]:
+        q = (q.astype(np.float64) * u + f32(c)).astype(f32)                 # fmaf: one rounding
+    he = (f32(0.5) * np.exp2(-(q * u).astype(f32).astype(np.float64)).astype(f32)).astype(f32)
+    phi = np.where(x >= 0, (f32(1.0) - he).astype(f32), he)
+    got = (x * phi).astype(f32).astype(np.float64)
+    true = x.astype(np.float64) * 0.5 * erfc(-x.astype(np.float64) / np.sqrt(2.0))
+    ref = (f32(0.5) * x * (f32(1.0) + erf((x * f32(0.7071067811865476)).astype(np.float64)).astype(f32)).astype(f32)).astype(f32)
+    e_new, e_ref = np.abs(got - true), np.abs(ref.astype(np.float64) - true)
+    assert e_new.max() <= e_ref.max() * 1.05 and e_new.max() < 5e-7, (e_new.max(), e_ref.max())
+    m = x > -3
+    assert (e_new[m] / np.maximum(np.abs(true[m]), 1e-30)).max() < 2e-6
