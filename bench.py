@@ -263,6 +263,7 @@ class GemmTimer:
         from dupl_amd import ops
         self._orig, self._orig16 = ops.gemm_raw, ops.linear16
         self._orig_af, self._orig_ab = ops.attention_fwd16, ops.attention_bwd16
+        self._orig_wg = ops.wgrad16_group
         timer = self
 
         def timed(A, B, C, M, N, K, lda, ldb, ldc, **kw):
@@ -297,13 +298,33 @@ class GemmTimer:
             return timer._timed_family("attention_bwd", lambda: timer._orig_ab(qkv16, out, dout, lse, B, N, H, hd, scale, *a, **kw),
                                        10.0 * B * H * N * N * hd)
 
+        def timed_wg(items):        # the grouped weight gradients of a transformer block: ONE launch of the same kernel family
+            fl = by = 0.0
+            for dy16, x16, out, _ in items:
+                m_, n_, k_ = dy16.cols, x16.cols, getattr(dy16, "valid_rows", dy16.rows)
+                fl += 2.0 * m_ * n_ * k_
+                by += 4.0 * (m_ * k_ + n_ * k_ + 2 * m_ * n_)
+            s_ = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s_)
+            r = timer._orig_wg(items)
+            e1.record(s_)
+            timer.pairs["f16x3"].append((e0, e1))
+            timer.flops["f16x3"] += fl
+            timer.bytes["f16x3"] += by
+            timer.fam_pairs["wgrad"].append((e0, e1))
+            timer.fam_flops["wgrad"] += fl
+            return r
+
         ops.gemm_raw, ops.linear16 = timed, timed16
         ops.attention_fwd16, ops.attention_bwd16 = timed_af, timed_ab
+        ops.wgrad16_group = timed_wg
 
     def remove(self):
         from dupl_amd import ops
         ops.gemm_raw, ops.linear16 = self._orig, self._orig16
         ops.attention_fwd16, ops.attention_bwd16 = self._orig_af, self._orig_ab
+        ops.wgrad16_group = self._orig_wg
 
     def reset(self):
         self.pairs = {k: [] for k in self.pairs}

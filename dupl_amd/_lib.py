@@ -85,6 +85,7 @@ class SplitItem(ctypes.Structure):
 
 
 SPLIT_MULTI_MAX = 16
+GEMM16_GROUP_MAX = 8          # DUPL_GEMM16_GROUP_MAX
 
 _PROTO = re.compile(r"^\s*int\s+(dupl_\w+)\s*\(([^;{]*)\)\s*;", re.M | re.S)
 

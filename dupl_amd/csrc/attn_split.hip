@@ -225,19 +225,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
         // ---- online softmax (fp32, base-2 exponent domain: c1 = scale log2(e) folded into the score).  Register e of
         // sub-tile kt2 is key  t*64 + 32 kt2 + 16 (e >> 3) + 8 hf + (e & 7); keys >= N exist in the last tile only
         const float c1 = scale * 1.4426950408889634f, c2 = c1 * LO_INV;
-        float mx = -INFINITY;
-        // explicit register PAIRS (v_pk_mul_f32 + v_pk_fma_f32 on aligned accumulator pairs): left to itself hipcc pairs
-        // elements (1,2), (3,4), ... and pays two v_mov per packed op to re-align them
-#pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const f32x2 m2 = {sM[kt2][e], sM[kt2][e + 1]}, x2 = {sX[kt2][e], sX[kt2][e + 1]};
-                const f32x2 v2 = __builtin_elementwise_fma(x2, f32x2{c2, c2}, m2 * f32x2{c1, c1});
-                sM[kt2][e] = v2[0];
-                sM[kt2][e + 1] = v2[1];
-            }
-        if (t == nkt - 1) {            // block-uniform
+        // Round 4: the VALU block between the two MFMA phases was the long pole of a key tile (2 640 of 6 230 cycles: ~12
+        // instructions per score).  Now ~5: (i) the running maximum is taken over the MAIN products only (v_max3 on raw accumulators;
+        // the cross terms move a score by <= 2^-11 of its size, and softmax does not care which constant near the maximum is
+        // subtracted as long as numerator, denominator and lse use the same one); (ii) score scaling, cross-term fold and the
+        // subtraction of the maximum are two packed FMAs on accumulator pairs feeding exp2 directly; (iii) the hi / lo split of
+        // P is one packed convert, one packed multiply and one mixed-precision FMA per element: lo = f16(fma(f32(hi), -2048,
+        // 2048 p)) -- the same value as f16((p - hi) * 2048) (every step exact up to the final rounding), with hi read back from
+        // the register that is used as the operand, so hi and lo cannot disagree.
+        if (t == nkt - 1) {            // block-uniform: keys >= N exist in the last tile only
             const int kbase_t = t * KT + 8 * hf;
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2)
@@ -245,26 +241,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
                 for (int e = 0; e < 16; ++e)
                     if (kbase_t + 32 * kt2 + 16 * (e >> 3) + (e & 7) >= N) sM[kt2][e] = -INFINITY;
         }
+        float mx = -INFINITY;
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sM[kt2][e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c1;          // c1 > 0
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float psum = 0.f;
+        f32x2 psum2 = {0.f, 0.f};
         h8 ph[4], pl[4];
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float px = __builtin_amdgcn_exp2f(sM[kt2][e] - m_new);
-                asm volatile("" : "+v"(px));         // one materialised fp32 value for every use (see split_f32, common.h)
-                psum += px;
-                const _Float16 hh = (_Float16)px;
-                ph[2 * kt2 + (e >> 3)][e & 7] = hh;
-                pl[2 * kt2 + (e >> 3)][e & 7] = (_Float16)((px - (float)hh) * DUPL_LO_SCALE);
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 m2 = {sM[kt2][e], sM[kt2][e + 1]}, x2 = {sX[kt2][e], sX[kt2][e + 1]};
+                const f32x2 v2 = __builtin_elementwise_fma(x2, f32x2{c2, c2}, __builtin_elementwise_fma(m2, f32x2{c1, c1}, f32x2{-m_new, -m_new}));
+                const f32x2 p2 = {__builtin_amdgcn_exp2f(v2[0]), __builtin_amdgcn_exp2f(v2[1])};
+                psum2 += p2;
+                const h2v hh = __builtin_convertvector(p2, h2v);                 // v_cvt_pk_f16_f32 (round to nearest even)
+                const f32x2 q2 = p2 * f32x2{DUPL_LO_SCALE, DUPL_LO_SCALE};
+                const int idx = 2 * kt2 + (e >> 3);
+                ph[idx][e & 7] = hh[0];
+                ph[idx][(e & 7) + 1] = hh[1];
+                pl[idx][e & 7] = (_Float16)__builtin_fmaf((float)hh[0], -DUPL_LO_SCALE, q2[0]);
+                pl[idx][(e & 7) + 1] = (_Float16)__builtin_fmaf((float)hh[1], -DUPL_LO_SCALE, q2[1]);
             }
+        const float psum = psum2[0] + psum2[1];
         l_run = l_run * alpha + psum;
         // the accumulators are rescaled only when some lane's running maximum moved (wave-uniform test; alpha == 1 exactly
         // otherwise, so skipping the 64 multiplications does not change a bit)

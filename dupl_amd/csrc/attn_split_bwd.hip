@@ -55,14 +55,21 @@ __device__ __forceinline__ int pi_row(int r) {
     return (r & ~12) | ((g == 1 ? 2 : (g == 2 ? 1 : g)) << 2);
 }
 
+// hi / lo planes of 16 accumulator values, two at a time: one packed convert, one packed multiply, one FMA per element --
+// lo = f16(fma(f32(hi), -2048, 2048 x)) is the same value as f16((x - hi) * 2048) (every step before the final rounding is
+// exact), and hi is read back from the register that becomes the operand, so the two planes cannot disagree (cf. split_f32)
 __device__ __forceinline__ void split_regs(const f32x16& v, h8 (&hi)[2], h8 (&lo)[2]) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float x = v[e];
-        asm volatile("" : "+v"(x));          // one materialised fp32 value for both uses (see split_f32, common.h)
-        const _Float16 hh = (_Float16)x;
-        hi[e >> 3][e & 7] = hh;
-        lo[e >> 3][e & 7] = (_Float16)((x - (float)hh) * DUPL_LO_SCALE);
+    for (int e = 0; e < 16; e += 2) {
+        const f2v x2 = {v[e], v[e + 1]};
+        const h2v hh = __builtin_convertvector(x2, h2v);
+        const f2v q2 = x2 * f2v{DUPL_LO_SCALE, DUPL_LO_SCALE};
+        hi[e >> 3][e & 7] = hh[0];
+        hi[e >> 3][(e & 7) + 1] = hh[1];
+        lo[e >> 3][e & 7] = (_Float16)__builtin_fmaf((float)hh[0], -DUPL_LO_SCALE, q2[0]);
+        lo[e >> 3][(e & 7) + 1] = (_Float16)__builtin_fmaf((float)hh[1], -DUPL_LO_SCALE, q2[1]);
     }
 }
 

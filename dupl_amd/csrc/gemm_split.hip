@@ -1182,8 +1182,8 @@ constexpr int slot_index(int S, int NR, int ND) {
     }
 }
 
-template <int WM, int WN, int NWM, int NWN, int WPS, bool SK, int ACC, bool AKM, bool BKM, int STAGES = 3>
-__global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_km_kernel(const dupl_gemm16_desc p, const int g_gm) {
+template <int WM, int WN, int NWM, int NWN, int WPS, bool SK, int ACC, bool AKM, bool BKM, int STAGES = 3, bool ONESHOT = false>
+__device__ __forceinline__ void gemm_f16x3_km_body(const dupl_gemm16_desc& p, const int g_gm, const int bid0, const int grid) {
     constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, NW = NWM * NWN;
     constexpr int PA = BM / 16, PB = BN / 16;
     constexpr int NP = 2 * PA + 2 * PB;
@@ -1382,11 +1382,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_km_kernel(cons
     constexpr std::integral_constant<int, 1> KS1{};
     constexpr int LGKM0 = 0xC07F;        // s_waitcnt lgkmcnt(0), vmcnt / expcnt untouched
 
-    int bid = blockIdx.x;
+    int bid = bid0;
     int pos = 0, pend = 0;
     int m0, n0;
     if constexpr (SK) {
-        const int T = nblk * ntf, G = gridDim.x;
+        const int T = nblk * ntf, G = grid;
         const int L = (bid & 7) * (G >> 3) + (bid >> 3);
         auto cut = [&](const int l) {
             int x = (int)((long)T * l / G);
@@ -1480,8 +1480,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_km_kernel(cons
                 lid_origin(pos / ntf, m0, n0);
                 plan(m0, n0, 0);
             }
+        } else if constexpr (ONESHOT) {
+            more = false;                 // one tile per block (grouped launch): no next-tile state to carry through the epilogue
         } else {
-            bid += gridDim.x;
+            bid += grid;
             more = has_tile(bid);
             if (more) {
                 tile_origin(bid, m0, n0);
@@ -1499,6 +1501,33 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_km_kernel(cons
     if (p.amax_out)
         gemm16_amax_flush(static_cast<unsigned int*>(p.amax_out), amx, reinterpret_cast<float*>(smem + STAGES * STAGE), wave, lane,
                           NWM * NWN);
+}
+
+template <int WM, int WN, int NWM, int NWN, int WPS, bool SK, int ACC, bool AKM, bool BKM, int STAGES = 3>
+__global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_km_kernel(const dupl_gemm16_desc p, const int g_gm) {
+    gemm_f16x3_km_body<WM, WN, NWM, NWN, WPS, SK, ACC, AKM, BKM, STAGES>(p, g_gm, blockIdx.x, gridDim.x);
+}
+
+// Grouped weight gradients (round 4): the four dW of one transformer block -- 2304 x 768, 768 x 768, 3072 x 768, 768 x 3072, each
+// only 18 .. 72 tiles of 256 x 128 -- as ONE launch of 216 tiles: every block owns a whole tile and walks all of K (the token
+// axis: 99 k-steps at 4 images), so nothing is split, nothing meets in atomics (C += tile by the one owner: the same bits in
+// deterministic mode and out of it), the 3-stage prologue and the epilogue are paid once per 99 k-steps instead of once per
+// ~14 (stream-K pieces), and the tile count does not depend on the batch.  Problem i owns the block range [first[i],
+// first[i + 1]), a multiple of 8 blocks long so that a block's local index keeps its XCD (blockIdx % 8): the XCD-aware tile
+// order of every problem stays intact.
+struct g16_group_args {
+    dupl_gemm16_desc d[DUPL_GEMM16_GROUP_MAX];
+    int first[DUPL_GEMM16_GROUP_MAX + 1];
+    int n;
+};
+template <int WM, int WN, int NWM, int NWN, int WPS>
+__global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_km_group_kernel(const g16_group_args g, const int g_gm) {
+    int i = 0;
+#pragma unroll 1
+    while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
+    i = __builtin_amdgcn_readfirstlane(i);
+    // one tile per block: a step of the whole grid ends the persistent walk after the first tile
+    gemm_f16x3_km_body<WM, WN, NWM, NWN, WPS, false, 2, true, true, 3, true>(g.d[i], g_gm, (int)blockIdx.x - g.first[i], 1 << 28);
 }
 
 }  // namespace
@@ -1532,6 +1561,36 @@ extern "C" int dupl_split_f16x2b(const float* x, void* hi, void* lo, int64_t n, 
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(split_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4,
                        ldexpf(1.f, scale_exp));
+    return dupl_launch_status();
+}
+
+extern "C" int dupl_gemm_f16x3_group(const dupl_gemm16_desc* descs, int32_t n, dupl_stream_t stream) {
+    (void)hipGetLastError();
+    if (!descs || n < 1 || n > DUPL_GEMM16_GROUP_MAX) return DUPL_ERR_ARG;
+    g16_group_args g;
+    g.n = n;
+    int total = 0, group = 0;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    for (int i = 0; i < n; ++i) {
+        const dupl_gemm16_desc& d = descs[i];
+        if (d.struct_size != sizeof(dupl_gemm16_desc)) return DUPL_ERR_ARG;
+        if (!d.A_hi || !d.A_lo || !d.B_hi || !d.B_lo || !d.C || d.C_hi || d.C_lo || d.bias || d.res || d.c_rows || d.amax_out ||
+            d.M <= 0 || d.N <= 0 || d.K <= 0)
+            return DUPL_ERR_ARG;
+        if (d.flags != DUPL_GEMM_ACCUM || d.fmt != 1 || d.a_layout != 1 || d.b_layout != 1 || (d.K % TBK) || d.K / TBK < 3 ||
+            (d.lda % 8) || (d.ldb % 8) || (d.M & 7) || (d.N & 7) || d.ka_valid < 0 || d.kb_valid < 0 || d.ka_valid > d.K ||
+            d.kb_valid > d.K || d.group < 0 || d.group > 4096)
+            return DUPL_ERR_ARG;
+        if (!al16(d.A_hi) || !al16(d.A_lo) || !al16(d.B_hi) || !al16(d.B_lo)) return DUPL_ERR_ARG;
+        g.d[i] = d;
+        g.first[i] = total;
+        const int nblk = ((d.M + 255) / 256) * ((d.N + 127) / 128);
+        total += 8 * ((nblk + 7) / 8);          // a multiple of 8: the local block index keeps the block's XCD
+        if (d.group) group = d.group;
+    }
+    g.first[n] = total;
+    hipLaunchKernelGGL((gemm_f16x3_km_group_kernel<2, 2, 4, 2, 2>), dim3((unsigned)total), dim3(512), 0, (hipStream_t)stream, g,
+                       group ? group : G16_GROUP_RING);
     return dupl_launch_status();
 }
 

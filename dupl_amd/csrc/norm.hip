@@ -188,6 +188,142 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// The same with the wave's FOUR rows in flight at once (round 4; the default rows_per_wave = 4): all loads of the four rows (x, dy,
+// dres) are issued before anything is reduced and the eight wave reductions run interleaved, instead of four dependent
+// load -> reduce -> store chains per wave (~200 blocks of 4 waves leave nothing else on a CU to hide them: 28.8 us at 3140 x 768
+// = 1.3 TB/s).  Same arithmetic per row, same accumulation order of dgamma / dbeta over the rows.
+template <int LN_MAXC>
+__global__ __launch_bounds__(256) void layernorm_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, long rows, int D,
+                                                             unsigned int* __restrict__ amax_out, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][D] + the block's max |dx| (bits)
+    constexpr int R = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = D >> 2;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * R;
+    // ---- every global load of the wave's four rows, up front
+    float4 xv[R][LN_MAXC], dv[R][LN_MAXC], rv[R][LN_MAXC];
+    float mu[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long row = row0 + r;
+        const bool ok = row < rows;
+        mu[r] = ok ? mean[row] : 0.f;
+        rs[r] = ok ? rstd[row] : 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const bool in = ok && c < nch;
+            xv[r][i] = in ? reinterpret_cast<const float4*>(x + row * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[r][i] = in ? reinterpret_cast<const float4*>(dy + row * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rv[r][i] = (in && dres) ? reinterpret_cast<const float4*>(dres + row * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    float4 gam[LN_MAXC], dg[LN_MAXC], db[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        gam[i] = c < nch ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (!part) {
+        for (int t = threadIdx.x; t < 2 * D + 1; t += blockDim.x) lds[t] = 0.f;
+        __syncthreads();
+    }
+    // ---- xhat, g = dy gamma, the row sums; dgamma / dbeta accumulate over the rows in row order (as the one-row-at-a-time kernel)
+    float s1[R], s2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s1[r] = 0.f;
+        s2[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            float4& xh = xv[r][i];
+            float4& d = dv[r][i];
+            xh.x = (xh.x - mu[r]) * rs[r]; xh.y = (xh.y - mu[r]) * rs[r]; xh.z = (xh.z - mu[r]) * rs[r]; xh.w = (xh.w - mu[r]) * rs[r];
+            dg[i].x += d.x * xh.x; dg[i].y += d.y * xh.y; dg[i].z += d.z * xh.z; dg[i].w += d.w * xh.w;
+            db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+            d.x *= gam[i].x; d.y *= gam[i].y; d.z *= gam[i].z; d.w *= gam[i].w;            // d is g from here on
+            s1[r] += (d.x + d.y) + (d.z + d.w);
+            s2[r] += (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            s1[r] += __shfl_xor(s1[r], o, 64);
+            s2[r] += __shfl_xor(s2[r], o, 64);
+        }
+    float amx = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long row = row0 + r;
+        if (row >= rows) break;
+        const float m1 = s1[r] / (float)D, m2 = s2[r] / (float)D;
+        float4* dxr = reinterpret_cast<float4*>(dx + row * D);
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const float4 g = dv[r][i], xh = xv[r][i];
+                float4 o;
+                o.x = rs[r] * (g.x - m1 - xh.x * m2);
+                o.y = rs[r] * (g.y - m1 - xh.y * m2);
+                o.z = rs[r] * (g.z - m1 - xh.z * m2);
+                o.w = rs[r] * (g.w - m1 - xh.w * m2);
+                if (dres) { o.x += rv[r][i].x; o.y += rv[r][i].y; o.z += rv[r][i].z; o.w += rv[r][i].w; }
+                amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                dxr[c] = o;
+            }
+        }
+    }
+    if (part) {
+        float4* pg = reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 4 + wave) * 2 * D);
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                pg[c] = dg[i];
+                pg[nch + c] = db[i];
+            }
+        }
+        if (amax_out) {
+            amx = wave_max(amx);
+            if (lane == 0 && amx > 0.f) atomicMax(amax_out, __float_as_uint(amx));
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            atomicAdd(&lds[4 * c + 0], dg[i].x); atomicAdd(&lds[4 * c + 1], dg[i].y);
+            atomicAdd(&lds[4 * c + 2], dg[i].z); atomicAdd(&lds[4 * c + 3], dg[i].w);
+            atomicAdd(&lds[D + 4 * c + 0], db[i].x); atomicAdd(&lds[D + 4 * c + 1], db[i].y);
+            atomicAdd(&lds[D + 4 * c + 2], db[i].z); atomicAdd(&lds[D + 4 * c + 3], db[i].w);
+        }
+    }
+    if (amax_out) {
+        amx = wave_max(amx);
+        if (lane == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(lds + 2 * D), __float_as_uint(amx));
+    }
+    __syncthreads();
+    if (amax_out && threadIdx.x == 0) {
+        const unsigned int b = *reinterpret_cast<const unsigned int*>(lds + 2 * D);
+        if (b) atomicMax(amax_out, b);
+    }
+    for (int t = threadIdx.x; t < D; t += blockDim.x) {
+        if (dgamma) atomicAdd(&dgamma[t], lds[t]);
+        if (dbeta) atomicAdd(&dbeta[t], lds[D + t]);
+    }
+}
+
 // second stage of the two-stage dgamma / dbeta reduction: part [nblk][2 D] (one row per wave of the main kernel) -> dgamma[c] += sum_b part[b][c], dbeta likewise.
 // block = 64 columns x 4 block-groups; gridDim.y > 1 splits the blocks further (atomics); gridDim.y == 1: fixed order, plain +=
 __global__ __launch_bounds__(256) void ln_dgb_reduce_kernel(const float* __restrict__ part, int nblk, int D,
@@ -330,11 +466,20 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
 #define LN_BWD(MC) hipLaunchKernelGGL(layernorm_bwd_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
                                       dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D, (unsigned int*)amax_out, rpw, \
                                       two_stage ? partials : nullptr)
-    if (D <= 256) LN_BWD(1);
+#define LN_BWD4(MC) hipLaunchKernelGGL(layernorm_bwd4_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
+                                       dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D, (unsigned int*)amax_out,        \
+                                       two_stage ? partials : nullptr)
+    // four rows per wave (the default): the variant that keeps all four in flight; wide rows (D > 1024: 8 float4 per lane and row)
+    // would not fit its registers and take the row-at-a-time kernel, like every other rows_per_wave
+    if (rpw == 4 && D <= 256) LN_BWD4(1);
+    else if (rpw == 4 && D <= 768) LN_BWD4(3);
+    else if (rpw == 4 && D <= 1024) LN_BWD4(4);
+    else if (D <= 256) LN_BWD(1);
     else if (D <= 768) LN_BWD(3);
     else if (D <= 1024) LN_BWD(4);
     else LN_BWD(8);
 #undef LN_BWD
+#undef LN_BWD4
     if (two_stage) {
         int gy = g_dupl_deterministic ? 1 : (grid + 63) / 64;
         if (gy > 16) gy = 16;

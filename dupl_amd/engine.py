@@ -122,6 +122,8 @@ FMT1 = os.environ.get("DUPL_FMT1", "1") != "0"
 KM_BWD = os.environ.get("DUPL_KM_BWD", "1") != "0"
 # data gradients with a linear epilogue (fc1, qkv: their dx goes to a LayerNorm backward) as stream-K launches into a zero-filled dx
 SK_DGRAD = os.environ.get("DUPL_SK_DGRAD", "1") != "0"
+# the weight gradients of a transformer block as one grouped launch (whole tiles, no atomics); 0: one stream-K launch each
+WGRAD_GROUP = os.environ.get("DUPL_WGRAD_GROUP", "1") != "0"
 SK_DGRAD_MAX_COLS = 1024
 
 
@@ -950,7 +952,7 @@ def _linear_backward32(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
 
 
 def _linear_backward16_km(P: StudentParams, dy: Tensor, x16, name: str, dgelu_of: Optional[Tensor] = None,
-                          dx_feeds_split: bool = False) -> Tensor:
+                          dx_feeds_split: bool = False, wgrads: Optional[list] = None) -> Tensor:
     """Backward of y = x W^T + b on the k-major single-accumulator kernels (csrc/gemm_split.hip, gemm_f16x3_km_kernel): ONE pass
     over dy writes its scaled format 1 planes (zero rows up to the padded token count) and the bias gradient; the weight
     gradient reads dy and the forward's x planes k-major, the data gradient reads dy row-wise and the forward's W planes
@@ -961,7 +963,11 @@ def _linear_backward16_km(P: StudentParams, dy: Tensor, x16, name: str, dgelu_of
     dy16, _, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False, fmt1=True, rm_rows=Kp,
                                        colsum_into=P.g[name + ".bias"] if fuse_bias else None)
     gw = P.g[name + ".weight"]
-    ops.linear16(dy16, x16, out=gw.view(N, -1), accumulate=True, alpha=alpha, a_kmajor=True, b_kmajor=True, k_pad=Kp)
+    if wgrads is not None:
+        # the weight gradient joins the block's grouped launch (network_backward: ops.wgrad16_group); dy16 stays alive until then
+        wgrads.append((dy16, x16, gw.view(N, -1), alpha))
+    else:
+        ops.linear16(dy16, x16, out=gw.view(N, -1), accumulate=True, alpha=alpha, a_kmajor=True, b_kmajor=True, k_pad=Kp)
     if not fuse_bias:
         ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
     W16 = P.w16(name + ".weight", N, True)
@@ -1097,9 +1103,14 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         def lin_bwd(site):      # the site's backward runs where its forward ran: same operands, same range verdict
             return _linear_backward16 if (f16 and g[site]) else _linear_backward32
 
+        # the block's weight gradients (18 .. 72 tiles of 256 x 128 each) are collected and leave as ONE launch after its data
+        # gradients: whole tiles over the whole token axis, no split-K, no atomics (ops.wgrad16_group)
+        wg = [] if WGRAD_GROUP else None
+
         def lin(site, dy_, x_, x16_, nm, **kw):
             if f16 and g[site] and x16_ is not None:          # forward planes kept: k-major backward
-                return _linear_backward16_km(P, dy_, x16_, nm, dgelu_of=kw.get("dgelu_of"), dx_feeds_split=kw.get("dx_feeds_split", False))
+                return _linear_backward16_km(P, dy_, x16_, nm, dgelu_of=kw.get("dgelu_of"), dx_feeds_split=kw.get("dx_feeds_split", False),
+                                             wgrads=wg)
             return lin_bwd(site)(P, dy_, x_, nm, **kw)
 
         def feeds(site):        # does the tensor go into a scaled split next (= is `site`'s backward an f16x3 one)?
@@ -1127,6 +1138,9 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         dx = ops.layernorm_bwd(dln1, s.x_in, W[p + "norm1.weight"], s.mean1, s.rstd1,
                                G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid,
                                amax_for_next=f16 and i > 0 and gb[i - 1]["fc2"])
+        if wg:
+            ops.wgrad16_group(wg)
+        del wg
         enc.blocks[i] = None  # release activations as we go
         if on_ready is not None:
             on_ready(i)

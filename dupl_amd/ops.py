@@ -354,6 +354,35 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     return y, y16
 
 
+def wgrad16_group(items):
+    """Several weight gradients dW_i += alpha_i dy_i^T x_i in ONE launch (dupl_gemm_f16x3_group: a whole 256 x 128 tile per block over
+    the whole token axis, no split-K, no atomics -- the same bits in deterministic mode).  items: [(dy16 Split16 [Kp, n_out] scaled
+    format 1 planes with zero rows up to Kp, x16 Split16 / view [rows, n_in] format 1 planes, out fp32 [n_out, n_in], alpha)]."""
+    descs = []
+    for dy16, x16, out, alpha in items:
+        assert dy16.fmt == 1 and getattr(x16, "fmt", 0) == 1, "grouped weight gradients read format 1 planes k-major"
+        Kp = dy16.rows
+        assert Kp % 32 == 0 and Kp >= 96 and out.is_contiguous() and out.shape == (dy16.cols, x16.cols)
+        if isinstance(alpha, _Alpha):
+            alpha.check()
+        d = _lib.Gemm16Desc()
+        d.A_hi, d.A_lo, d.B_hi, d.B_lo = dy16.hi, dy16.lo, x16.hi, x16.lo
+        d.C = out.data_ptr()
+        d.M, d.N, d.K = dy16.cols, x16.cols, Kp
+        d.lda, d.ldb, d.ldc, d.ldo = dy16.cols, x16.cols, out.stride(0), x16.cols
+        d.flags = _lib.GEMM_ACCUM
+        d.alpha_dev = int(alpha) if alpha is not None else None
+        d.fmt, d.post_scale = 1, 2.0 ** -(getattr(dy16, "exp", 0) + getattr(x16, "exp", 0))
+        d.a_layout, d.b_layout = 1, 1
+        d.ka_valid, d.kb_valid = Kp, min(x16.rows, Kp)
+        d.group = GEMM16_TUNING["group"]
+        descs.append(d)
+    for i in range(0, len(descs), _lib.GEMM16_GROUP_MAX):
+        chunk = descs[i:i + _lib.GEMM16_GROUP_MAX]
+        arr = (_lib.Gemm16Desc * len(chunk))(*chunk)
+        L().dupl_gemm_f16x3_group(arr, len(chunk), _stream())
+
+
 def linear(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, gelu: bool = False, relu: bool = False,
            res: Optional[Tensor] = None, out: Optional[Tensor] = None, store_pre: Optional[Tensor] = None) -> Tensor:
     """y[M,N] = act(x[M,K] @ W[N,K]^T + bias) + res     (nn.Linear / 1x1 conv forward).

@@ -122,6 +122,12 @@ typedef struct dupl_gemm16_desc {
     int32_t group;                        /* row tiles per group of the block -> tile order */
 } dupl_gemm16_desc;
 int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream);
+/* n (<= DUPL_GEMM16_GROUP_MAX) independent weight gradients C_i += alpha_i A_i^T . B_i (every descriptor: fmt 1, a_layout = b_layout = 1,
+ * flags = DUPL_GEMM_ACCUM) as ONE launch, a whole 256 x 128 tile per block over all of K: the four dW of a transformer block
+ * (autograd of vit.py:92-136: 18 .. 72 tiles each) fill the chip together, nothing is split along K and nothing meets in atomics --
+ * bit-reproducible with and without dupl_set_deterministic.  descs: HOST array (copied into the launch). */
+#define DUPL_GEMM16_GROUP_MAX 8
+int dupl_gemm_f16x3_group(const dupl_gemm16_desc* descs, int32_t n, dupl_stream_t stream);
 /* the operand split of the GEMM above: n fp32 values (n % 4 == 0) -> hi / lo fp16 planes (no reference counterpart) */
 int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, dupl_stream_t stream);
 /* the same into format 1 planes of x * 2^scale_exp (dupl_gemm16_desc.fmt) */

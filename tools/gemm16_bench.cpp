@@ -245,6 +245,7 @@ int main(int argc, char** argv) {
         {
             dupl_gemm_desc r;
             memset(&r, 0, sizeof r);
+            r.struct_size = sizeof r;
             r.A = A[0]; r.B = B[0]; r.C = Cref; r.M = M; r.N = N; r.K = K; r.lda = akm ? M : K; r.ldb = bkm ? N : K; r.ldc = N; r.ldr = N; r.ldaux = N;
             r.batch = 1; r.zdiv = 1; r.alpha = 1.f;
             r.flags = (akm ? DUPL_GEMM_A_MCONTIG : 0) | (bkm ? DUPL_GEMM_B_NCONTIG : 0);
