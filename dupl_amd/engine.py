@@ -124,6 +124,7 @@ KM_BWD = os.environ.get("DUPL_KM_BWD", "1") != "0"
 SK_DGRAD = os.environ.get("DUPL_SK_DGRAD", "1") != "0"
 # the weight gradients of a transformer block as one grouped launch (whole tiles, no atomics); 0: one stream-K launch each
 WGRAD_GROUP = os.environ.get("DUPL_WGRAD_GROUP", "1") != "0"
+
 SK_DGRAD_MAX_COLS = 1024
 
 
@@ -1139,6 +1140,8 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
                                G[p + "norm1.weight"], G[p + "norm1.bias"], dres=dx_mid,
                                amax_for_next=f16 and i > 0 and gb[i - 1]["fc2"])
         if wg:
+            # (measured and dropped: this launch on a side stream of its student, to share the chip with the narrow data-gradient
+            # launches of the next block -- 55.2 vs 54.4 ms at 4 img/GPU, 33.8 vs 32.6 at 2, same box: DESIGN 6)
             ops.wgrad16_group(wg)
         del wg
         enc.blocks[i] = None  # release activations as we go
