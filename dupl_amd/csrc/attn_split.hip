@@ -8,11 +8,14 @@
 // For the f16 MFMA a lane's B fragment is 8 consecutive reduction slots; the accumulator gives lane half hf the MFMA rows
 // {0-3, 8-11} / {4-7, 12-15} of each 16-row group, so the K rows are fed in the permuted order pi (4-row groups 1 and 2
 // swapped): then registers e = 8s .. 8s+7 of a lane ARE keys 16s + 8 hf + 0..7 -- the fragment, without any permute.
-// V is consumed as V^T [d][key] (key-contiguous), produced by vt_planes_kernel from the qkv planes, so both K and V^T
-// tiles are [64 rows][64 halfs = 128 bytes] images filled by direct-to-LDS DMA (8 rows per wave instruction) with the
-// bank swizzle chunk ^ ((row >> 1) & 7) applied on the source side, and every fragment read is one ds_read_b128.
+// K tiles are [64 keys][64 halfs = 128 bytes] images filled by direct-to-LDS DMA (8 rows per wave instruction) with the bank
+// swizzle chunk ^ ((row >> 1) & 7) applied on the source side; a fragment read is one ds_read_b128.  V is the k-major operand
+// of the second product (A = V^T [d][key], memory holds [key][d]): its DMA lays the tile out as 512-byte subtiles
+// [8 keys][32 d] (the layout of gemm_split.hip's k-major operands) and ds_read_b64_tr_b16 gathers the fragments, so no
+// transposed copy of V is ever written (rounds 2-3 ran a vt_planes kernel per call: 0.7 ms / step).
 // Block = 4 waves x 32 queries, 64 keys per iteration, two LDS stages (64 KB, 2 blocks / CU), one barrier per key tile.
 #include "common.h"
+#include <type_traits>
 #include "../../include/dupl_hip.h"
 
 #ifndef ATT_PRIO
@@ -25,11 +28,19 @@
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
 constexpr float LO_INV = 1.f / DUPL_LO_SCALE;
 constexpr int HD = 64, KT = 64;
 constexpr int PLANE = KT * 128;          // one [64][128 B] image
-constexpr int STAGE = 4 * PLANE;         // K_hi | K_lo | VT_hi | VT_lo
+constexpr int STAGE = 4 * PLANE;         // K_hi | K_lo | V_hi | V_lo
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
@@ -49,49 +60,10 @@ __device__ __forceinline__ void xcd_remap3(int remap, int& bx, int& by, int& bz)
     bz = w / (gx * gy);
 }
 
-// V^T planes: vT[(b*H + h)*64 + d][key], key < Npad (a multiple of 64), zero for key >= N.  One block per (64-key tile, h, b).
-__global__ __launch_bounds__(256) void vt_planes_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
-                                                        __half* __restrict__ vT_hi, __half* __restrict__ vT_lo, int N, int H,
-                                                        int Npad) {
-    __shared__ __half tile[2][64][66];
-    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const int D = H * HD, ld = 3 * D;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-        const __half* src = (pl == 0 ? qkv_hi : qkv_lo) + (size_t)b * N * ld + 2 * D + h * HD;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i;              // 512 chunks of 8 halfs: key = c / 8, d0 = (c % 8) * 8
-            const int key = c >> 3, d0 = (c & 7) << 3;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (k0 + key < N) v = *reinterpret_cast<const uint4*>(src + (size_t)(k0 + key) * ld + d0);
-            const __half* hv = reinterpret_cast<const __half*>(&v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) tile[pl][key][d0 + j] = hv[j];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-        __half* dst = (pl == 0 ? vT_hi : vT_lo) + ((size_t)(b * H + h) * HD) * Npad + k0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i;              // d = c / 8, keys (c % 8) * 8 .. + 7
-            const int d = c >> 3, kk = (c & 7) << 3;
-            __half o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = tile[pl][kk + j][d];
-            *reinterpret_cast<uint4*>(dst + (size_t)d * Npad + kk) = *reinterpret_cast<const uint4*>(o);
-        }
-    }
-}
-
 __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
-                                                            const __half* __restrict__ vT_hi, const __half* __restrict__ vT_lo,
                                                             float* __restrict__ out, __half* __restrict__ out_hi,
                                                             __half* __restrict__ out_lo, float* __restrict__ lse, int N, int H,
-                                                            int Npad, float scale, int remap, int B_f32, float out_scale) {
+                                                            float scale, int remap, int B_f32, float out_scale) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     int bx, h, b;
@@ -117,16 +89,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
     const char* kbase[2];      // K planes at this (b, h): row 0, column chunk 0
     kbase[0] = reinterpret_cast<const char*>(qkv_hi + (size_t)b * N * ld + D + h * HD);
     kbase[1] = reinterpret_cast<const char*>(qkv_lo + (size_t)b * N * ld + D + h * HD);
-    const char* vp[4];         // V^T pieces i = 4 .. 7: per-lane pointer at key tile 0
-    int krow[2], kch[2];
+    const char* vbase[2];      // V planes at this (b, h)
+    vbase[0] = kbase[0] + D * 2;
+    vbase[1] = kbase[1] + D * 2;
+    int krow[2], kch[2], vrow[2], vch;
+    // V piece q = wave + 4 j (1 KB = subtiles 2 q, 2 q + 1 = key group q, d blocks 0 / 1): lane -> subtile row (lane >> 2) & 7,
+    // 16-byte chunk lane & 3 of d block lane >> 5; key group q holds keys 16 (q >> 1) + 4 (q & 1) + {0..3, 8..11} in rows 0 .. 7
+    vch = ((lane >> 5) * 32 + (lane & 3) * 8) * 2;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = 8 * (wave + 4 * j) + prow;                 // tile row of this lane in pieces with (i & 1) == j
         const int c = pch ^ ((r >> 1) & 7);                      // source chunk (swizzle on the source side)
         krow[j] = r;
         kch[j] = c * 16;
-        vp[j] = reinterpret_cast<const char*>(vT_hi + ((size_t)(b * H + h) * HD + r) * Npad) + c * 16;
-        vp[2 + j] = reinterpret_cast<const char*>(vT_lo + ((size_t)(b * H + h) * HD + r) * Npad) + c * 16;
+        const int q = wave + 4 * j, srow = (lane >> 2) & 7;
+        vrow[j] = (q >> 1) * 16 + (srow >> 2) * 8 + (q & 1) * 4 + (srow & 3);
     }
     auto issue = [&](int t, int buf) __attribute__((always_inline)) {
         char* dst = smem + buf * STAGE + wave * 1024;
@@ -135,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
             const int j = i & 1;
             const char* src;
             if (i < 4) src = kbase[i >> 1] + (size_t)min(t * KT + krow[j], N - 1) * (ld * 2) + kch[j];
-            else src = vp[(i >= 6 ? 2 : 0) + j] + (size_t)t * (KT * 2);
+            else src = vbase[(i - 4) >> 1] + (size_t)min(t * KT + vrow[j], N - 1) * (ld * 2) + vch;     // rows past N: P = 0 there
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
         }
@@ -146,8 +123,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
     const int g4 = (l31 >> 2) & 3;
     const int krow_a = (l31 & ~12) | ((g4 == 1 ? 2 : (g4 == 2 ? 1 : g4)) << 2);
     const int k_off = krow_a * 128, k_sw = (krow_a >> 1) & 7;
-    // V^T (A operand of O^T): MFMA row l31 <- d = 32 dt + l31; chunk (2 sigma + hf) ^ ((row >> 1) & 7)
-    const int v_off = l31 * 128, v_sw = (l31 >> 1) & 7;
+    // V (k-major A operand of O^T): lane (g = lane >> 4, q = lane & 15) of the read (key step sg, half jj, d block dd) takes subtile
+    // row (g >> 1) * 4 + (q >> 2), d 16 (g & 1) + 4 (q & 3) .. + 3 of subtile (sg * 2 + jj) * 2 + dd; the reads are inline asm (a
+    // builtin read behind an LDS-DMA makes hipcc drain vmcnt first, gemm_split.hip) with explicit lgkmcnt waits at the consumers
+    const int vg = lane >> 4, vq = lane & 15;
+    const unsigned v_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + 2 * PLANE +
+                           ((vg >> 1) * 4 + (vq >> 2)) * 64 + (16 * (vg & 1) + 4 * (vq & 3)) * 2;
 
     f32x16 oM[2], oX[2];
 #pragma unroll
@@ -212,16 +193,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
         if (ATT_ABL & 16) { asm volatile("" ::"v"(sM[0]), "v"(sM[1]), "v"(sX[0]), "v"(sX[1])); }
         ATT_STAMP(1)
         // the first V^T fragments are fetched now: their LDS latency hides under the softmax arithmetic
-        h8 vh[2][2], vl[2][2];               // [set][d half]
-        auto v_read = [&](const int sg, h8(&fh)[2], h8(&fl)[2]) __attribute__((always_inline)) {
-            const int ch = ((2 * sg + hf) ^ v_sw) * 16;
-#pragma unroll
-            for (int dd = 0; dd < 2; ++dd) {
-                fh[dd] = *reinterpret_cast<const h8*>(st + 2 * PLANE + dd * 4096 + v_off + ch);
-                fl[dd] = *reinterpret_cast<const h8*>(st + 3 * PLANE + dd * 4096 + v_off + ch);
-            }
+        h4 vf[2][8];                         // [set][(plane * 2 + d block) * 2 + half]
+        const unsigned v_st = v_lds + (t & 1) * STAGE;
+        auto tr_read = [](const unsigned addr, auto offc) __attribute__((always_inline)) {
+            h4 v;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(offc)::value) : "memory");
+            return v;
         };
-        v_read(0, vh[0], vl[0]);
+        auto v_read = [&](auto sgc, h4(&f)[8]) __attribute__((always_inline)) {
+            constexpr int SG = decltype(sgc)::value;
+            static_for<8>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value, pl = i >> 2, dd = (i >> 1) & 1, jj = i & 1;
+                f[i] = tr_read(v_st, std::integral_constant<int, pl * PLANE + ((SG * 2 + jj) * 2 + dd) * 512>{});
+            });
+        };
+        v_read(std::integral_constant<int, 0>{}, vf[0]);
         // ---- online softmax (fp32, base-2 exponent domain: c1 = scale log2(e) folded into the score).  Register e of
         // sub-tile kt2 is key  t*64 + 32 kt2 + 16 (e >> 3) + 8 hf + (e & 7); keys >= N exist in the last tile only
         const float c1 = scale * 1.4426950408889634f, c2 = c1 * LO_INV;
@@ -283,19 +269,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
         ATT_STAMP(2)
         // ---- O^T += V^T P^T, same read-ahead and accumulator rotation
         __builtin_amdgcn_s_setprio(ATT_PRIO);
-#pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-            const int cur = sg & 1;
-            if (sg + 1 < 4) v_read(sg + 1, vh[cur ^ 1], vl[cur ^ 1]);
+        static_for<4>([&](auto sgc) __attribute__((always_inline)) {
+            constexpr int sg = decltype(sgc)::value, cur = sg & 1;
+            if constexpr (sg + 1 < 4) {
+                v_read(std::integral_constant<int, sg + 1>{}, vf[cur ^ 1]);
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // LDS returns in order: the 8 reads of step sg have landed
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
-            oM[0] = MFMA16(vh[cur][0], ph[sg], oM[0]);
-            oM[1] = MFMA16(vh[cur][1], ph[sg], oM[1]);
-            oX[0] = MFMA16(vh[cur][0], pl[sg], oX[0]);
-            oX[1] = MFMA16(vh[cur][1], pl[sg], oX[1]);
-            oX[0] = MFMA16(vl[cur][0], ph[sg], oX[0]);
-            oX[1] = MFMA16(vl[cur][1], ph[sg], oX[1]);
+            const h4(&f)[8] = vf[cur];
+            const h8 vh0 = __builtin_shufflevector(f[0], f[1], 0, 1, 2, 3, 4, 5, 6, 7), vh1 = __builtin_shufflevector(f[2], f[3], 0, 1, 2, 3, 4, 5, 6, 7);
+            const h8 vl0 = __builtin_shufflevector(f[4], f[5], 0, 1, 2, 3, 4, 5, 6, 7), vl1 = __builtin_shufflevector(f[6], f[7], 0, 1, 2, 3, 4, 5, 6, 7);
+            oM[0] = MFMA16(vh0, ph[sg], oM[0]);
+            oM[1] = MFMA16(vh1, ph[sg], oM[1]);
+            oX[0] = MFMA16(vh0, pl[sg], oX[0]);
+            oX[1] = MFMA16(vh1, pl[sg], oX[1]);
+            oX[0] = MFMA16(vl0, ph[sg], oX[0]);
+            oX[1] = MFMA16(vl1, ph[sg], oX[1]);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
         __builtin_amdgcn_s_setprio(0);
         if (ATT_ABL & 16) { asm volatile("" ::"v"(oM[0]), "v"(oM[1]), "v"(oX[0]), "v"(oX[1])); }
         ATT_STAMP(3)
@@ -341,22 +334,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
 
 constexpr int g_attn16_remap = 1;      // XCD-aware workgroup order (whole heads per XCD)
 
-extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi,
-                                    void* out_lo, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad,
-                                    float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s) {
+extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, float* out, void* out_hi, void* out_lo, float* lse,
+                                    int32_t B, int32_t N, int32_t H, int32_t hd, float scale, int32_t B_f32, int32_t out_exp,
+                                    dupl_stream_t s) {
     (void)hipGetLastError();
     if (out_exp < 0 || out_exp > 15) return DUPL_ERR_ARG;
     if (B_f32 == 0) B_f32 = B;           // 0 = the fp32 output / lse for every image
     if (B_f32 < 0 || B_f32 > B || (B_f32 < B && !out_hi)) return DUPL_ERR_ARG;
-    if (!qkv_hi || !qkv_lo || !vT_hi || !vT_lo || (!out && !out_hi) || ((out_hi == nullptr) != (out_lo == nullptr)) || B <= 0 ||
-        N <= 0 || H <= 0 || hd != HD || Npad < N || (Npad % KT))
+    if (!qkv_hi || !qkv_lo || (!out && !out_hi) || ((out_hi == nullptr) != (out_lo == nullptr)) || B <= 0 || N <= 0 || H <= 0 ||
+        hd != HD)
         return DUPL_ERR_ARG;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (!al16(qkv_hi) || !al16(qkv_lo) || !al16(vT_hi) || !al16(vT_lo)) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(vt_planes_kernel, dim3(Npad / KT, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
-                       (const __half*)qkv_lo, (__half*)vT_hi, (__half*)vT_lo, N, H, Npad);
+    if (!al16(qkv_hi) || !al16(qkv_lo)) return DUPL_ERR_ARG;
     hipLaunchKernelGGL(attn_fwd16_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
-                       (const __half*)qkv_lo, (const __half*)vT_hi, (const __half*)vT_lo, out, (__half*)out_hi, (__half*)out_lo, lse,
-                       N, H, Npad, scale, g_attn16_remap, B_f32, out_exp ? ldexpf(1.f, out_exp) : 0.f);
+                       (const __half*)qkv_lo, out, (__half*)out_hi, (__half*)out_lo, lse, N, H, scale, g_attn16_remap, B_f32,
+                       out_exp ? ldexpf(1.f, out_exp) : 0.f);
     return dupl_launch_status();
 }

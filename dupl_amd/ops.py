@@ -507,16 +507,14 @@ def attention_fwd16(qkv16, B: int, N: int, H: int, hd: int, scale: float, need_l
     receiving the planes of the output.  Returns lse (B, H, N) or None."""
     assert hd == 64 and qkv16.rows == B * N and qkv16.cols == 3 * H * hd and (out is not None or out16 is not None)
     dev = out.device if out is not None else (out16.planes.device if isinstance(out16, Split16) else out16.base.planes.device)
-    npad = (N + 63) // 64 * 64
-    vt = torch.empty((2, B * H * hd * npad), device=dev, dtype=torch.float16)
     bf = b_f32 or B          # fp32 out / lse for the first bf images only (the planes for all B)
     lse = torch.empty((bf, H, N), device=dev, dtype=torch.float32) if need_lse else None
     if out is not None:
         assert out.shape == (bf * N, H * hd) and out.is_contiguous()
     assert getattr(qkv16, "exp", 0) == 0, "the split attention reads format 0 planes"
-    L().dupl_attention_fwd16(qkv16.hi, qkv16.lo, vt.data_ptr(), vt.data_ptr() + 2 * vt.shape[1], _p(out),
-                              out16.hi if out16 is not None else None, out16.lo if out16 is not None else None, _p(lse),
-                              B, N, H, hd, npad, float(scale), bf, out16.exp if out16 is not None else 0, _stream())
+    L().dupl_attention_fwd16(qkv16.hi, qkv16.lo, _p(out), out16.hi if out16 is not None else None,
+                              out16.lo if out16 is not None else None, _p(lse), B, N, H, hd, float(scale), bf,
+                              out16.exp if out16 is not None else 0, _stream())
     return lse
 
 

@@ -223,14 +223,13 @@ int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int3
                        int32_t hd, float scale, dupl_stream_t s);
 /* The same attention forward as fp32-equivalent f16x3 split products (csrc/attn_split.hip; head dim 64): q, k, v are read
  * from the fp16 hi / lo planes of the qkv GEMM output ([B*N][3*H*hd] halfs each), S = q k^T and O = P v are
- * hi hi + (hi lo + lo hi) / 2048 on v_mfma_f32_32x32x16_f16 with fp32 accumulation, softmax in fp32.  vT_hi / vT_lo:
- * scratch of B*H*hd*Npad halfs each (V^T planes, written first); Npad = N rounded up to a multiple of 64.
+ * hi hi + (hi lo + lo hi) / 2048 on v_mfma_f32_32x32x16_f16 with fp32 accumulation, softmax in fp32.  V is read in place
+ * (k-major operand, transposing LDS reads): no scratch.
  * out (fp32) and / or out_hi / out_lo (planes, the A operand of the projection GEMM); lse optional.
  * B_f32 (0 = B): the fp32 output and lse are written for the first B_f32 images only (out: [B_f32*N][H*hd], lse: [B_f32][H][N]),
  * the planes for all B; out_exp > 0: the output planes in format 1 (out * 2^out_exp, unscaled lo). */
-int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, void* vT_hi, void* vT_lo, float* out, void* out_hi, void* out_lo,
-                         float* lse, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, int32_t B_f32,
-                         int32_t out_exp, dupl_stream_t s);
+int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, float* out, void* out_hi, void* out_lo, float* lse, int32_t B,
+                         int32_t N, int32_t H, int32_t hd, float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s);
 /* backward (what autograd derives for vit.py:123-135): dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N]. */
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,

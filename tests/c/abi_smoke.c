@@ -128,18 +128,17 @@ int main(void) {
         if (!(worst16[0] < 2e-6 && worst16[1] < 2e-6 && worst16[2] < 2e-6)) return 7;
     }
     {   /* attention forward on the planes of a qkv matrix: B = 1, H = 2, N = 50, head dim 64 */
-        const int Bq = 1, H = 2, Nq = 50, hd = 64, D = H * hd, Np = 64;
+        const int Bq = 1, H = 2, Nq = 50, hd = 64, D = H * hd;
         const size_t nq = (size_t)Bq * Nq * 3 * D;
         float *hq = malloc(sizeof(float) * nq), *ho = malloc(sizeof(float) * Bq * Nq * D);
         for (size_t i = 0; i < nq; ++i) hq[i] = 2.0f * frand(&seed);
         float *dq, *dout;
-        void *pq, *pvt;
+        void *pq;
         CHECK(hipMalloc((void**)&dq, sizeof(float) * nq)); CHECK(hipMalloc((void**)&dout, sizeof(float) * Bq * Nq * D));
-        CHECK(hipMalloc(&pq, 4 * nq)); CHECK(hipMalloc(&pvt, 4 * (size_t)Bq * H * hd * Np));
+        CHECK(hipMalloc(&pq, 4 * nq));
         CHECK(hipMemcpy(dq, hq, sizeof(float) * nq, hipMemcpyHostToDevice));
         OK(dupl_split_f16x2(dq, pq, (char*)pq + 2 * nq, (int64_t)nq, st));
-        OK(dupl_attention_fwd16(pq, (char*)pq + 2 * nq, pvt, (char*)pvt + 2 * (size_t)Bq * H * hd * Np, dout, NULL, NULL, NULL, Bq, Nq, H, hd,
-                                Np, 0.125f, 0, 0, st));
+        OK(dupl_attention_fwd16(pq, (char*)pq + 2 * nq, dout, NULL, NULL, NULL, Bq, Nq, H, hd, 0.125f, 0, 0, st));
         CHECK(hipStreamSynchronize(st));
         CHECK(hipMemcpy(ho, dout, sizeof(float) * Bq * Nq * D, hipMemcpyDeviceToHost));
         double worst_at = 0.0;

@@ -27,15 +27,15 @@ int main(int argc, char** argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& c : cases) {
-        const int B = c[0], N = c[1], npad = (N + 63) / 64 * 64;
+        const int B = c[0], N = c[1];
         const long nq = (long)B * N * 3 * D;
-        float* qkv; __half *q16, *vt, *o16; float *out, *lse;
-        CK(hipMalloc(&qkv, nq * 4)); CK(hipMalloc(&q16, nq * 4)); CK(hipMalloc(&vt, (long)B * H * hd * npad * 4));
+        float* qkv; __half *q16, *o16; float *out, *lse;
+        CK(hipMalloc(&qkv, nq * 4)); CK(hipMalloc(&q16, nq * 4));
         CK(hipMalloc(&o16, (long)B * N * D * 4)); CK(hipMalloc(&out, (long)B * N * D * 4)); CK(hipMalloc(&lse, (long)B * H * N * 4 + (1 << 20)));
         fill_kernel<<<1024, 256>>>(qkv, nq, 7, 1.5f);
         dupl_split_f16x2(qkv, q16, q16 + nq, nq, nullptr);
         CK(hipDeviceSynchronize());
-        auto run = [&]() { return dupl_attention_fwd16(q16, q16 + nq, vt, vt + (long)B * H * hd * npad, nullptr, o16, o16 + (long)B * N * D, lse, B, N, H, hd, npad, 0.125f, 0, 0, st); };
+        auto run = [&]() { return dupl_attention_fwd16(q16, q16 + nq, nullptr, o16, o16 + (long)B * N * D, lse, B, N, H, hd, 0.125f, 0, 0, st); };
         if (run()) { fprintf(stderr, "launch failed\n"); return 2; }
         CK(hipEventRecord(e0, st)); for (int i = 0; i < 3; ++i) run(); CK(hipEventRecord(e1, st)); CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0, st)); for (int i = 0; i < iters; ++i) run(); CK(hipEventRecord(e1, st)); CK(hipDeviceSynchronize());
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / iters, fl = 4.0 * B * H * (double)N * N * hd;
-        printf("B=%d N=%4d: %7.1f us (incl. vt_planes)  %5.0f TF/s-eq", B, N, us, fl / us / 1e6);
+        printf("B=%d N=%4d: %7.1f us  %5.0f TF/s-eq", B, N, us, fl / us / 1e6);
         if (dbg) {
             const int nblk = ((N + 127) / 128) * H * B;
             std::vector<long long> h((size_t)nblk * 4);
@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
             printf("  [cycles per key tile, wave 0: wait+barrier %.0f, QK %.0f, softmax %.0f, PV %.0f]", p[0] / nt, p[1] / nt, p[2] / nt, p[3] / nt);
         }
         printf("\n");
-        hipFree(qkv); hipFree(q16); hipFree(vt); hipFree(o16); hipFree(out); hipFree(lse);
+        hipFree(qkv); hipFree(q16); hipFree(o16); hipFree(out); hipFree(lse);
     }
     return 0;
 }
