@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
                                                             __half* __restrict__ out_lo, float* __restrict__ lse, int N, int H,
                                                             float scale, int remap, int B_f32, float out_scale) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // scalar: the LDS destination of a DMA piece goes through M0
     int bx, h, b;
     xcd_remap3(remap, bx, h, b);
     const int q0 = bx * 128 + wave * 32;
@@ -92,10 +93,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
     const char* vbase[2];      // V planes at this (b, h)
     vbase[0] = kbase[0] + D * 2;
     vbase[1] = kbase[1] + D * 2;
-    int krow[2], kch[2], vrow[2], vch;
+    int krow[2], kch[2], vrow[2];
     // V piece q = wave + 4 j (1 KB = subtiles 2 q, 2 q + 1 = key group q, d blocks 0 / 1): lane -> subtile row (lane >> 2) & 7,
     // 16-byte chunk lane & 3 of d block lane >> 5; key group q holds keys 16 (q >> 1) + 4 (q & 1) + {0..3, 8..11} in rows 0 .. 7
-    vch = ((lane >> 5) * 32 + (lane & 3) * 8) * 2;
+    const int vch = ((lane >> 5) * 32 + (lane & 3) * 8) * 2;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = 8 * (wave + 4 * j) + prow;                 // tile row of this lane in pieces with (i & 1) == j
@@ -105,16 +106,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
         const int q = wave + 4 * j, srow = (lane >> 2) & 7;
         vrow[j] = (q >> 1) * 16 + (srow >> 2) * 8 + (q & 1) * 4 + (srow & 3);
     }
+    // a piece's source = (uniform) plane base of tile t + a 32-bit per-lane offset (the planes of one call are far below 4 GB): the
+    // DMA takes the base in scalar registers, 4 vector registers hold the offsets.  A whole tile (all 64 keys < N) uses the
+    // precomputed offsets, the partial last tile clamps its rows to N - 1 (K rows past N are masked to -inf scores, V rows past N
+    // meet P = 0).
+    const size_t tstride = (size_t)KT * ld * 2;
+    unsigned koff[2], voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        koff[j] = (unsigned)krow[j] * (unsigned)(ld * 2) + kch[j];
+        voff[j] = (unsigned)vrow[j] * (unsigned)(ld * 2) + vch;
+    }
+    auto dma16 = [](const char* ubase, const unsigned off, char* dst) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ubase + off),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
     auto issue = [&](int t, int buf) __attribute__((always_inline)) {
         char* dst = smem + buf * STAGE + wave * 1024;
+        const size_t o = t * tstride;
+        if (t * KT + KT <= N) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int j = i & 1;
-            const char* src;
-            if (i < 4) src = kbase[i >> 1] + (size_t)min(t * KT + krow[j], N - 1) * (ld * 2) + kch[j];
-            else src = vbase[(i - 4) >> 1] + (size_t)min(t * KT + vrow[j], N - 1) * (ld * 2) + vch;     // rows past N: P = 0 there
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+            for (int i = 0; i < 4; ++i) dma16(kbase[i >> 1] + o, koff[i & 1], dst + i * 4096);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma16(vbase[i >> 1] + o, voff[i & 1], dst + (4 + i) * 4096);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dma16(kbase[i >> 1] + o, (unsigned)(min(t * KT + krow[i & 1], N - 1) - t * KT) * (unsigned)(ld * 2) + kch[i & 1], dst + i * 4096);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dma16(vbase[i >> 1] + o, (unsigned)(min(t * KT + vrow[i & 1], N - 1) - t * KT) * (unsigned)(ld * 2) + vch, dst + (4 + i) * 4096);
         }
     };
 
@@ -232,9 +253,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sM[kt2][e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c1;          // c1 > 0
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        {
+            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+            const u2v sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c1;          // c1 > 0; both lane halves of a query
+        }
+        // Lazy running maximum: it follows the tile maximum only when some query of the wave would otherwise see a probability above
+        // 2^8 (wave-uniform decision).  exp2(s - m) with a stale m is the same softmax -- numerator, denominator and lse use the one
+        // constant -- and P <= 256 keeps the fp16 hi / lo split as accurate as P <= 1; what it saves is the rescaling of the 64
+        // accumulators, which otherwise runs whenever any of 32 maxima moves at all (most tiles).
+        const float m_cand = fmaxf(m_run, mx);
+        const bool move = __builtin_amdgcn_ballot_w64(m_cand - m_run > 8.f) != 0;       // -inf start: inf > 8
+        const float m_new = move ? m_cand : m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                     // exactly 1 when the maximum stays
         f32x2 psum2 = {0.f, 0.f};
         h8 ph[4], pl[4];
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -256,9 +287,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
             }
         const float psum = psum2[0] + psum2[1];
         l_run = l_run * alpha + psum;
-        // the accumulators are rescaled only when some lane's running maximum moved (wave-uniform test; alpha == 1 exactly
-        // otherwise, so skipping the 64 multiplications does not change a bit)
-        if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {
+        if (move) {
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll

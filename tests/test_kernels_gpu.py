@@ -1274,13 +1274,13 @@ def test_kmajor_backward_gemms_are_fp32_equivalent(dev, tokens, n_out, n_in, x_r
 @pytest.mark.parametrize("tokens,D", [(3140, 768), (1570, 768), (34, 96)])
 def test_grouped_weight_gradients(dev, tokens, D):
     """dupl_gemm_f16x3_group: the four weight gradients of a transformer block (qkv 3D x D, proj D x D, fc1 4D x D, fc2 D x 4D) as ONE
-    launch of whole 256 x 128 tiles -- no split-K, no atomics.  Bars: each dW within 3x the exact-f32 kernel's error + 2e-7 of the
-    float64 result (accumulated onto existing values) -- 3x, not the 2x of the split forms: ONE fp32 accumulator chain runs over
-    all tokens here (~200 MFMA accumulations per output; measured 1.2-1.4e-6 of the tensor's max at 3 140 tokens), whereas the
-    exact-f32 kernel it is compared with splits K over blocks in this mode (4.5e-7 - 9e-7) and the stream-K form of this kernel sums
-    ~14-step pieces (5e-7); unsplit, the exact-f32 kernel has the same chain and the same error (deterministic mode: 1.1e-6 -
-    1.9e-6, test_kmajor_backward_gemms_are_fp32_equivalent).  Two runs are bit-identical WITHOUT deterministic mode (nothing in
-    the launch depends on scheduling), and identical to the run in deterministic mode."""
+    launch of whole 256 x 128 tiles -- no split-K, no atomics.  Bars: each dW no further than the exact-f32 kernel's error + 2e-7 from the
+    float64 result (accumulated onto existing values), the exact-f32 kernel run in DETERMINISTIC mode: unsplit, it has the same
+    single fp32 accumulator chain over all tokens as this kernel (~200 MFMA accumulations per output; at 3 140 tokens it measures
+    2.1e-6 - 3.4e-6 of the tensor's max, this kernel 1.2e-6 - 1.6e-6) and its result does not depend on scheduling -- its split-K / atomic form sums shorter
+    pieces in an order that changes from run to run (3.1e-7 - 9e-7), which made a bar built on it flaky.  Two runs are
+    bit-identical WITHOUT deterministic mode (nothing in the launch depends on scheduling), and identical to the run in
+    deterministic mode."""
     from dupl_amd import ops
     g = torch.Generator().manual_seed(tokens + D)
     shapes = [(3 * D, D), (D, D), (4 * D, D), (D, 4 * D)]
@@ -1298,7 +1298,11 @@ def test_grouped_weight_gradients(dev, tokens, D):
         c0s.append(c0)
         refs.append(c0.double() + dy.double().t() @ x[:tokens].double())
         c32 = c0.clone()
-        ops.linear_wgrad(dy, x[:tokens], c32, accumulate=True)
+        ops.L().dupl_set_deterministic(1)
+        try:
+            ops.linear_wgrad(dy, x[:tokens], c32, accumulate=True)
+        finally:
+            ops.L().dupl_set_deterministic(0)
         f32s.append(c32)
     outs = []
     for rep in range(3):
@@ -1315,5 +1319,5 @@ def test_grouped_weight_gradients(dev, tokens, D):
         e16 = float((outs[0][i].double() - ref).abs().max()) / sc
         e32 = float((f32s[i].double() - ref).abs().max()) / sc
         print(f"grouped wgrad {tuple(ref.shape)} x {tokens}: f16x3 {e16:.2e}  f32 {e32:.2e}")
-        assert e16 <= 3.0 * e32 + 2e-7
+        assert e16 <= e32 + 2e-7
         assert torch.equal(outs[0][i], outs[1][i]) and torch.equal(outs[0][i], outs[2][i]), "the grouped launch must be bit-reproducible"
