@@ -6,6 +6,7 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool AGPR>
 __global__ __launch_bounds__(512, 1) void k(float* out, long long* cyc, int iters, int mode, int valu_kind) {
     __shared__ char big[100 * 1024];
     big[threadIdx.x] = 0;
@@ -18,13 +19,21 @@ __global__ __launch_bounds__(512, 1) void k(float* out, long long* cyc, int iter
         for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f); }
         f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
         t0 = clock64();
-        for (int i = 0; i < iters; ++i) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c3, 0, 0, 0);
+        if (AGPR) {
+            // accumulators in the AGPR file ("a" constraint): does the other wave's arithmetic get its VGPR bandwidth back?
+            for (int i = 0; i < iters; ++i) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n v_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n"
+                             "v_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n"
+                             "v_mfma_f32_32x32x16_f16 %2, %5, %4, %2\n v_mfma_f32_32x32x16_f16 %3, %5, %4, %3\n"
+                             : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : "v"(a), "v"(b));
+            }
+        } else {
+            for (int i = 0; i < iters; ++i) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n v_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n"
+                             "v_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n"
+                             "v_mfma_f32_32x32x16_f16 %2, %5, %4, %2\n v_mfma_f32_32x32x16_f16 %3, %5, %4, %3\n"
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));
+            }
         }
         t1 = clock64();
         float s = 0.f;
@@ -61,17 +70,18 @@ __global__ __launch_bounds__(512, 1) void k(float* out, long long* cyc, int iter
 int main() {
     float* out; long long* cyc; hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8 * 8);
     const int iters = 2000;
+    for (int ag = 0; ag < 2; ++ag)
     for (int vk = 0; vk < 3; ++vk)
         for (int mode = 1; mode <= 3; ++mode) {
             hipMemset(cyc, 0, 256 * 8 * 8);
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            k<<<256, 512>>>(out, cyc, iters, mode, vk);
-            hipEventRecord(e0); k<<<256, 512>>>(out, cyc, iters, mode, vk); hipEventRecord(e1); hipDeviceSynchronize();
+            if (ag) k<true><<<256, 512>>>(out, cyc, iters, mode, vk); else k<false><<<256, 512>>>(out, cyc, iters, mode, vk);
+            hipEventRecord(e0); if (ag) k<true><<<256, 512>>>(out, cyc, iters, mode, vk); else k<false><<<256, 512>>>(out, cyc, iters, mode, vk); hipEventRecord(e1); hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
             long long h[256 * 8]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
             double m = 0, v = 0;
             for (int b = 0; b < 256; ++b) for (int w = 0; w < 8; ++w) (w < 4 ? m : v) += (double)h[b * 8 + w];
-            printf("valu kind %d mode %d: kernel %.1f us; MFMA wave: %.1f ticks / MFMA; VALU wave: %.1f ticks / iteration\n", vk, mode, ms * 1e3, m / (256 * 4) / iters / 6, v / (256 * 4) / iters);
+            printf("acc in %s, valu kind %d mode %d: kernel %.1f us; MFMA wave: %.1f ticks / MFMA; VALU wave: %.1f ticks / iteration\n", ag ? "AGPR" : "VGPR", vk, mode, ms * 1e3, m / (256 * 4) / iters / 6, v / (256 * 4) / iters);
         }
     return 0;
 }
