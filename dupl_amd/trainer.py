@@ -123,14 +123,17 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
         else:
             high = per_image_high_thres(cls_label_host, n_iter, args, device=inputs.device)
             to_label = cam_helper.cam_to_label_dynamic_cls
-        labels = []
-        for ca in (cams_aux_1, cams_aux_2):
+        # per student on its own stream (round 4): the label / PTC / refinement kernels are small (a PAR iteration is 46 us on a
+        # fraction of the chip), so the two students' chains overlap almost completely instead of queueing on one stream
+        def aux_label_and_ptc(ca, fmap):
             r = ops.resize_bilinear(ca, fh, fw)
             _, pl = to_label(r, cls_label=cls_label, img_box=img_box, ignore_mid=True, bkg_thre=args.bkg_thre,
                              high_thre=high, low_thre=args.low_thre, ignore_index=args.ignore_index)
-            labels.append(pl)
-        ptc_loss = LS.get_masked_ptc_loss_from_label(fmap_1, labels[0], args.ignore_index) + \
-            LS.get_masked_ptc_loss_from_label(fmap_2, labels[1], args.ignore_index)
+            return pl, LS.get_masked_ptc_loss_from_label(fmap, pl, args.ignore_index)
+        (l1, p1), (l2, p2) = core.per_student(lambda: aux_label_and_ptc(cams_aux_1, fmap_1),
+                                              lambda: aux_label_and_ptc(cams_aux_2, fmap_2))
+        labels = [l1, l2]
+        ptc_loss = p1 + p2
         out["pseudo_label_aux_1"], out["pseudo_label_aux_2"] = labels
     if phase_a:
         seg_loss = torch.ones(1, device=inputs.device)
@@ -139,38 +142,45 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
         # PRESENT classes (label == 1), for which that product is the identity, so the (b,C,H,W) multiply is skipped
         if coco and n_iter <= args.coco_switch_iter:
             # train_final_coco.py:312-322: scalar high threshold on the AUX CAMs
-            r1 = cam_helper.refine_cams_with_bkg_v2(par, inputs_denorm, cams=cams_aux_1, cls_labels=cls_label_host,
-                                                    high_thre=args.high_thre, low_thre=args.low_thre,
-                                                    ignore_index=args.ignore_index, img_box=img_box)
-            r2 = cam_helper.refine_cams_with_bkg_v2(par, inputs_denorm, cams=cams_aux_2, cls_labels=cls_label_host,
-                                                    high_thre=args.high_thre, low_thre=args.low_thre,
-                                                    ignore_index=args.ignore_index, img_box=img_box)
+            def refine(cams_aux_k):
+                return cam_helper.refine_cams_with_bkg_v2(par, inputs_denorm, cams=cams_aux_k, cls_labels=cls_label_host,
+                                                          high_thre=args.high_thre, low_thre=args.low_thre,
+                                                          ignore_index=args.ignore_index, img_box=img_box)
+            ref_in = (cams_aux_1, cams_aux_2)
         else:
             hmap = high.view(b, 1, 1, 1).expand(b, 1, h, w).contiguous()
-            r1 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_1, cls_labels=cls_label_host,
-                                                           high_thre_map=hmap, low_thre=args.low_thre,
-                                                           ignore_index=args.ignore_index, img_box=img_box)
-            r2 = cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_2, cls_labels=cls_label_host,
-                                                           high_thre_map=hmap, low_thre=args.low_thre,
-                                                           ignore_index=args.ignore_index, img_box=img_box)
-        if phase_c:
-            # GMM label-noise filter on the detached per-pixel CE of each student w.r.t. ITS OWN labels (:360-394)
-            # one workgroup per image fits sklearn's 2-component mixture on the device (csrc/gmm.hip): no host round trip
-            stats = []
-            for segs_k, r_k in ((segs_1, r1), (segs_2, r2)):
+            def refine(cams_k):
+                return cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_k, cls_labels=cls_label_host,
+                                                                 high_thre_map=hmap, low_thre=args.low_thre,
+                                                                 ignore_index=args.ignore_index, img_box=img_box)
+            ref_in = (cams_1, cams_2)
+
+        def refine_and_filter(cams_k, segs_k):
+            r_k = refine(cams_k)
+            st = None
+            if phase_c:
+                # GMM label-noise filter on the detached per-pixel CE of each student w.r.t. ITS OWN labels (:360-394)
+                # one workgroup per image fits sklearn's 2-component mixture on the device (csrc/gmm.hip): no host round trip
                 ce = LS.seg_ce_map(segs_k, r_k, (h, w), args.ignore_index)
-                stats.append(LS.gmm_noise_filter_(ce, r_k, args.ignore_index, args.gmm_valid_thre, args.gamma))
-            out["gmm_stats"] = stats      # (b, 16) per student; column 1 = image was filtered
+                st = LS.gmm_noise_filter_(ce, r_k, args.ignore_index, args.gmm_valid_thre, args.gamma)
+            return r_k, st
+        (r1, st1), (r2, st2) = core.per_student(lambda: refine_and_filter(ref_in[0], segs_1),
+                                                lambda: refine_and_filter(ref_in[1], segs_2))
+        if phase_c:
+            out["gmm_stats"] = [st1, st2]      # (b, 16) per student; column 1 = image was filtered
         # cross supervision: student 1 learns from student 2's labels and vice versa (train_final_voc.py:351-352)
-        seg_loss = LS.get_seg_loss_lowres(segs_1, r2, (h, w), args.ignore_index) + \
-            LS.get_seg_loss_lowres(segs_2, r1, (h, w), args.ignore_index)
+        sl1, sl2 = core.per_student(lambda: LS.get_seg_loss_lowres(segs_1, r2, (h, w), args.ignore_index),
+                                    lambda: LS.get_seg_loss_lowres(segs_2, r1, (h, w), args.ignore_index))
+        seg_loss = sl1 + sl2
         out["refined_1"], out["refined_2"] = r1, r2
         if phase_c:
             # consistency regularisation on the 0.75x strong-aug branch (:407-436)
-            ps1, n1 = LS.seg_pseudo_label(segs_1, r2, (h, w), args.ignore_index, 0.9)
-            ps2, n2 = LS.seg_pseudo_label(segs_2, r1, (h, w), args.ignore_index, 0.9)
-            reg_loss = LS.get_reg_loss(res["branch1_aug"], ps1, (h, w), args.ignore_index) + \
-                LS.get_reg_loss(res["branch2_aug"], ps2, (h, w), args.ignore_index)
+            def pseudo_and_reg(segs_k, r_other, aug_k):
+                ps, n = LS.seg_pseudo_label(segs_k, r_other, (h, w), args.ignore_index, 0.9)
+                return ps, n, LS.get_reg_loss(aug_k, ps, (h, w), args.ignore_index)
+            (ps1, n1, g1), (ps2, n2, g2) = core.per_student(lambda: pseudo_and_reg(segs_1, r2, res["branch1_aug"]),
+                                                            lambda: pseudo_and_reg(segs_2, r1, res["branch2_aug"]))
+            reg_loss = g1 + g2
             out.update(pseudo_seg_1=ps1, pseudo_seg_2=ps2, n_uncertain=(n1, n2), reg_loss=reg_loss)
     sim = LS.sim_loss(fmap_1, fmap_2)
     if coco:    # hard-coded weights, train_final_coco.py:441-448
