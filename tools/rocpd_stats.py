@@ -79,8 +79,60 @@ def timeline(path, tail_frac=0.5):
         print(f"{k:18s} {v / 1e6:9.2f} ms {100.0 * v / tot:6.1f} %")
 
 
+def light_time(path, tail_frac=0.5, top=25):
+    """Where the time WITHOUT an MFMA-heavy kernel in flight goes: per light kernel name the time it ran while no heavy kernel
+    did (split evenly among the light kernels in flight), and the idle time charged to the kernel that ended the gap.
+    python tools/rocpd_stats.py --light x.db"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {namecol}, start, end from kernels order by start").fetchall()
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    lo = t1 - (t1 - t0) * tail_frac
+    ev = []
+    for i, (n, s, e) in enumerate(rows):
+        if e <= lo:
+            continue
+        ev.append((max(s, lo), 1, i))
+        ev.append((e, -1, i))
+    ev.sort()
+    live = set()
+    heavy = 0
+    light_by, idle_by = {}, {}
+    prev = lo
+    for t, d, i in ev:
+        dt = t - prev
+        if dt > 0 and heavy == 0:
+            if live:
+                for j in live:
+                    k = short(rows[j][0])
+                    light_by[k] = light_by.get(k, 0) + dt / len(live)
+            elif d > 0:
+                k = short(rows[i][0])
+                idle_by[k] = idle_by.get(k, 0) + dt
+        prev = t
+        h = 1 if HEAVY.search(rows[i][0]) else 0
+        if d > 0:
+            live.add(i)
+        else:
+            live.discard(i)
+        heavy += d * h
+    tot = t1 - lo
+    print(f"# time without an MFMA-heavy kernel in flight, last {tail_frac:.0%} of {path} ({tot / 1e6:.1f} ms)")
+    print(f"# light kernels running alone: {sum(light_by.values()) / 1e6:.2f} ms; idle: {sum(idle_by.values()) / 1e6:.2f} ms")
+    print("## light kernels (time while no heavy kernel was in flight)")
+    for k, v in sorted(light_by.items(), key=lambda kv: -kv[1])[:top]:
+        print(f"{k:70s} {v / 1e6:8.3f} ms")
+    print("## idle gaps, by the kernel that ended them")
+    for k, v in sorted(idle_by.items(), key=lambda kv: -kv[1])[:top]:
+        print(f"{k:70s} {v / 1e6:8.3f} ms")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--timeline":
+    if sys.argv[1] == "--light":
+        light_time(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.5)
+    elif sys.argv[1] == "--timeline":
         timeline(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.5)
     else:
         main(sys.argv[1])
