@@ -193,12 +193,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // load -> reduce -> store chains per wave (~200 blocks of 4 waves leave nothing else on a CU to hide them: 28.8 us at 3140 x 768
 // = 1.3 TB/s).  Same arithmetic per row, same accumulation order of dgamma / dbeta over the rows.
 template <int LN_MAXC>
-__global__ __launch_bounds__(256) void layernorm_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void layernorm_bwd4_kernel(const float* dy, const float* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ dres,
                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, long rows, int D,
-                                                             unsigned int* __restrict__ amax_out, float* __restrict__ part) {
+                                                             unsigned int* __restrict__ amax_out, float* __restrict__ part,
+                                                             float* dy_clear) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][D] + the block's max |dx| (bits)
     constexpr int R = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -220,6 +221,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd4_kernel(const float* __rest
             xv[r][i] = in ? reinterpret_cast<const float4*>(x + row * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             dv[r][i] = in ? reinterpret_cast<const float4*>(dy + row * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             rv[r][i] = (in && dres) ? reinterpret_cast<const float4*>(dres + row * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // dy_clear (== dy): the rows just read are handed back as zeros -- dy is the accumulation target of a stream-K data gradient,
+    // which wants it zero-filled for its next use (one buffer per stream serves every block; no fill launch in between)
+    if (dy_clear) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long row = row0 + r;
+#pragma unroll
+            for (int i = 0; i < LN_MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (row < rows && c < nch) reinterpret_cast<float4*>(dy_clear + row * D)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
@@ -448,13 +462,14 @@ extern "C" int dupl_layernorm_bwd_blocks(int64_t rows, int32_t rows_per_wave) {
 extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                                   int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows,
-                                  int32_t rows_per_wave, dupl_stream_t s) {
+                                  int32_t rows_per_wave, float* dy_clear, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256)
         return DUPL_ERR_ARG;
     const bool want_dgb = dgamma || dbeta;
     const bool two_stage = partials && want_dgb;
     if (rows_per_wave < 0 || rows_per_wave > 64) return DUPL_ERR_ARG;
+    if (dy_clear && dy_clear != dy) return DUPL_ERR_ARG;          // NULL, or dy itself: "hand dy back zero-filled"
     const int rpw = rows_per_wave > 0 ? rows_per_wave : LNB_ROWS;
     const int grid = (int)((rows + 4 * rpw - 1) / (4 * rpw));
     if (two_stage && partial_rows < 4 * (int64_t)grid) return DUPL_ERR_ARG;      // one partial row per wave
@@ -468,9 +483,12 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
                                       two_stage ? partials : nullptr)
 #define LN_BWD4(MC) hipLaunchKernelGGL(layernorm_bwd4_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
                                        dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D, (unsigned int*)amax_out,        \
-                                       two_stage ? partials : nullptr)
+                                       two_stage ? partials : nullptr, in_kernel_clear ? dy_clear : nullptr)
     // four rows per wave (the default): the variant that keeps all four in flight; wide rows (D > 1024: 8 float4 per lane and row)
     // would not fit its registers and take the row-at-a-time kernel, like every other rows_per_wave
+    // the clearing rides in the four-row kernel when nothing reads dy after it (the deterministic column pass does)
+    const bool bwd4 = rpw == 4 && D <= 1024;
+    const bool in_kernel_clear = dy_clear && bwd4 && !det;
     if (rpw == 4 && D <= 256) LN_BWD4(1);
     else if (rpw == 4 && D <= 768) LN_BWD4(3);
     else if (rpw == 4 && D <= 1024) LN_BWD4(4);
@@ -489,6 +507,8 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
     if (det)
         hipLaunchKernelGGL(ln_dgb_det_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)s, dy, x, mean, rstd, dgamma, dbeta,
                            (long)rows, D);
+    if (dy_clear && !in_kernel_clear)
+        hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, dy_clear, 0.f, (long)rows * D);
     return dupl_launch_status();
 }
 

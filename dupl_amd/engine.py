@@ -126,6 +126,7 @@ SK_DGRAD = os.environ.get("DUPL_SK_DGRAD", "1") != "0"
 WGRAD_GROUP = os.environ.get("DUPL_WGRAD_GROUP", "1") != "0"
 
 SK_DGRAD_MAX_COLS = 1024
+ZERO_WS = os.environ.get("DUPL_ZERO_WS", "1") != "0"
 
 
 class FlatStorage:
@@ -975,7 +976,8 @@ def _linear_backward16_km(P: StudentParams, dy: Tensor, x16, name: str, dgelu_of
     if SK_DGRAD and dgelu_of is None and not dx_feeds_split and not ops.deterministic() and W16.cols <= SK_DGRAD_MAX_COLS:
         # plain dx = alpha dy . W whose consumer reads fp32 (LayerNorm backward): stream-K into a zero-filled dx -- the narrow
         # outputs (768 columns = 78 tiles of 256 x 128 at 4 images, 42 at 2) then occupy every CU
-        dx = ops.zeros((M, W16.cols), dy.device)
+        # cleared again by the LayerNorm backward that consumes it (DUPL_ZERO_WS=0: a fresh tensor and a fill launch per use)
+        dx = ops.zero_workspace(M, W16.cols, dy.device) if ZERO_WS else ops.zeros((M, W16.cols), dy.device)
         ops.linear16(dy16.rows_slice(0, M), W16, out=dx, accumulate=True, alpha=alpha, b_kmajor=True)
         return dx
     dx, _ = ops.linear16(dy16.rows_slice(0, M), W16, alpha=alpha, dgelu_of=dgelu_of, amax_for_next=dx_feeds_split, b_kmajor=True)

@@ -471,7 +471,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
                   dres: Optional[Tensor] = None, amax_for_next: bool = False, two_stage: Optional[bool] = None) -> Tensor:
     """Returns dx = dres + LN'(dy); accumulates into dgamma / dbeta -- fp32 atomics from the main kernel, or (two_stage; the
     default in deterministic mode) per-block partial sums + a fixed-order reduce kernel (dupl_layernorm_bwd's partials).
-    amax_for_next: as in linear16."""
+    amax_for_next: as in linear16.  A dy that came from zero_workspace() is handed back zero-filled by the same kernel."""
     rows, D = x.shape
     if two_stage is None:
         two_stage = deterministic()
@@ -481,11 +481,35 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     if two_stage:
         nb = L().dupl_layernorm_bwd_blocks(rows, LNB_ROWS_PER_WAVE)
         part = torch.empty((nb, 2 * D), device=x.device, dtype=torch.float32)
+    ws = getattr(dy, "_dupl_zero_ws", None)
     L().dupl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
-                           dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, word, _p(part), nb, LNB_ROWS_PER_WAVE, _stream())
+                           dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, word, _p(part), nb, LNB_ROWS_PER_WAVE,
+                           dy.data_ptr() if ws is not None else None, _stream())
+    if ws is not None:
+        ws[1] = True            # clean again, in the order of the stream it belongs to
     if tok is not None:
         dx._dupl_amax = tok
     return dx
+
+
+_ZERO_WS = {}
+
+
+def zero_workspace(rows: int, cols: int, device) -> Tensor:
+    """A [rows, cols] fp32 tensor that IS zero in the order of the current stream: one buffer per (stream, shape), handed out
+    clean, dirtied by its user (a stream-K data gradient accumulates into it) and cleaned again by the consumer that reads it
+    last -- layernorm_bwd recognises it and has its kernel write zeros behind its reads.  If the previous user never reached
+    that consumer (another path, an exception), the buffer is still marked dirty and gets an explicit fill."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, rows, cols)
+    ws = _ZERO_WS.get(key)
+    if ws is None:
+        ws = _ZERO_WS[key] = [torch.zeros((rows, cols), device=device, dtype=torch.float32), True]
+    buf = ws[0]
+    if not ws[1]:
+        buf.zero_()
+    ws[1] = False
+    buf._dupl_zero_ws = ws
+    return buf
 
 
 # ------------------------------------------------------------------------------------------ attention

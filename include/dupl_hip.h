@@ -200,12 +200,14 @@ int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, 
  * partials != NULL (two-stage dgamma / dbeta): every wave writes its partial sums to partials [partial_rows][2 D] (partial_rows >=
  * dupl_layernorm_bwd_blocks(rows, rows_per_wave)) and a second kernel adds them up -- in a fixed order under
  * dupl_set_deterministic(1): the bit-reproducible form without a second pass over dy and x (not faster than the atomics: 27 vs
- * 22 us at 3140 x 768); partials == NULL: one kernel, fp32 atomics.  rows_per_wave: 0 = default (4); a block = 4 waves. */
+ * 22 us at 3140 x 768); partials == NULL: one kernel, fp32 atomics.  rows_per_wave: 0 = default (4); a block = 4 waves.
+ * dy_clear: NULL, or dy itself = hand dy back ZERO-FILLED (dy is the accumulation target of a stream-K data gradient, which wants
+ * zeros for its next use: the rows are cleared by the kernel that has just read them instead of a fill launch). */
 int dupl_layernorm_bwd_blocks(int64_t rows, int32_t rows_per_wave);   /* a count, not a status */
 int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                        int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows, int32_t rows_per_wave,
-                       dupl_stream_t s);
+                       float* dy_clear, dupl_stream_t s);
 
 /* column sums: out[n] (+)= sum_m x[m][n]: the bias gradients autograd derives for nn.Linear (vit.py:92-102,115-122)
  * and the patch-embed conv (vit.py:176-183).  accumulate!=0 adds to out (atomic). */

@@ -1271,6 +1271,44 @@ def test_kmajor_backward_gemms_are_fp32_equivalent(dev, tokens, n_out, n_in, x_r
     assert torch.equal(gw2, outs[1]), "the fixed-order weight gradient must be bit-reproducible"
 
 
+@pytest.mark.parametrize("rows,D", [(3140, 768), (37, 96), (130, 1280)])
+def test_layernorm_bwd_hands_a_zero_workspace_back_clean(dev, rows, D):
+    """ops.zero_workspace: the accumulation target of the stream-K data gradients.  layernorm_bwd on such a dy returns the same dx as
+    on an ordinary tensor (bit for bit) and leaves the buffer zero-filled -- inside the four-row kernel for D <= 1024, by a fill
+    behind the row-at-a-time kernel for wider rows and in deterministic mode; the next request gets the same buffer without a fill,
+    a request after an unconsumed use gets it cleared."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g).to(dev)
+    dyv = (torch.randn(rows, D, generator=g) * 1e-4).to(dev)
+    gamma = (1.0 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-6).rsqrt()
+    for det in (0, 1):
+        ops.L().dupl_set_deterministic(det)
+        try:
+            dg0, db0 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+            ref = ops.layernorm_bwd(dyv.clone(), x, gamma, mean, rstd, dg0, db0)
+            ws = ops.zero_workspace(rows, D, dev)
+            assert float(ws.abs().max()) == 0.0
+            ws.copy_(dyv)
+            dg1, db1 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+            out = ops.layernorm_bwd(ws, x, gamma, mean, rstd, dg1, db1)
+            assert torch.equal(out, ref)
+            if det:
+                assert torch.equal(dg1, dg0) and torch.equal(db1, db0)
+            else:
+                assert torch.allclose(dg1, dg0, rtol=1e-4, atol=1e-7) and torch.allclose(db1, db0, rtol=1e-4, atol=1e-7)
+            assert float(ws.abs().max()) == 0.0, "the consumer must hand the workspace back zero-filled"
+            ws2 = ops.zero_workspace(rows, D, dev)
+            assert ws2.data_ptr() == ws.data_ptr()
+            ws2.fill_(3.0)                              # a use that never reaches a LayerNorm backward
+            ws3 = ops.zero_workspace(rows, D, dev)
+            assert ws3.data_ptr() == ws.data_ptr() and float(ws3.abs().max()) == 0.0
+            ops.layernorm_bwd(ws3, x, gamma, mean, rstd, dg1, db1)      # leave it clean for whoever comes next
+        finally:
+            ops.L().dupl_set_deterministic(0)
+
+
 @pytest.mark.parametrize("tokens,D", [(3140, 768), (1570, 768), (34, 96)])
 def test_grouped_weight_gradients(dev, tokens, D):
     """dupl_gemm_f16x3_group: the four weight gradients of a transformer block (qkv 3D x D, proj D x D, fc1 4D x D, fc2 D x 4D) as ONE
