@@ -127,6 +127,8 @@ WGRAD_GROUP = os.environ.get("DUPL_WGRAD_GROUP", "1") != "0"
 
 SK_DGRAD_MAX_COLS = 1024
 ZERO_WS = os.environ.get("DUPL_ZERO_WS", "1") != "0"
+# AdamW writes the operand planes of the parameters it updates (no split pass over all weights before the next forward)
+FUSED_PLANES = os.environ.get("DUPL_ADAMW_PLANES", "1") != "0"
 
 
 class FlatStorage:
@@ -166,6 +168,7 @@ class FlatStorage:
         self.dirty = 0
         self.rewrites = 0           # bulk rewrites through raw pointers / collectives (mark_dirty(rewritten=True))
         self._w16_key = [None] * n_students
+        self._planes_fresh: Dict = {}      # student -> parameter key whose planes the optimiser has written
         self._w16T: Dict = {}
         self._w16F0: Dict = {}
         self.guard = RangeGuard(self)
@@ -201,6 +204,19 @@ class FlatStorage:
     def _param_key(self):
         return (self.data._version, self.dirty, self.data.data_ptr(), self.rewrites)
 
+    # ---- the optimiser writes the planes of the parameters it updates (dupl_adamw p_hi / p_lo): utils/optimizer.py
+    def planes_current(self, student: int) -> bool:
+        """The student's planes match its parameters right now (so that rewriting the updated segments keeps them complete)."""
+        return FUSED_PLANES and self.data16 is not None and self._w16_key[student] == self._param_key()
+
+    def plane_pointers(self, offset: int, seg: int):
+        """(hi pointer, lo pointer, plane exponent) of the planes at flat parameter `offset`, which lies in segment `seg`."""
+        return (self.data16.data_ptr() + 2 * offset, self.data16.data_ptr() + 2 * (self.data.numel() + offset),
+                ops.EXP_W if (FMT1 and seg == SEG_BACKBONE) else 0)
+
+    def planes_written(self, student: int):
+        self._planes_fresh[student] = self._param_key()
+
     def ensure_w16(self, student: int):
         """Bring the fp16 hi / lo planes of one student's parameters up to date (on the current stream)."""
         key = self._param_key()
@@ -209,9 +225,12 @@ class FlatStorage:
         if self.data16 is None or self.data16.device != self.data.device:
             self.data16 = torch.empty((2, self.data.numel()), device=self.data.device, dtype=torch.float16)
             self._w16_key = [None] * self.n_students
+            self._planes_fresh = {}
         n, base = self.student_numel, student * self.student_numel
         tot = self.data.numel()
-        if FMT1:
+        if self._planes_fresh.get(student) == key:
+            pass        # the optimiser step that produced these parameters wrote their planes
+        elif FMT1:
             # the backbone segment (every encoder Linear weight) as format 1 planes of w * 2^EXP_W (single-accumulator forward
             # GEMMs), everything else (decoder convs) as format 0
             b0, b1 = self.seg_bounds[SEG_BACKBONE]

@@ -14,12 +14,14 @@ from .. import ops
 from ..engine import FlatStorage
 
 
-def adamw_segment(p, g, m, v, step, lr, beta1, beta2, eps, wd):
-    """One fused AdamW update of flat fp32 tensors (torch.optim.AdamW single-tensor semantics)."""
+def adamw_segment(p, g, m, v, step, lr, beta1, beta2, eps, wd, planes=None):
+    """One fused AdamW update of flat fp32 tensors (torch.optim.AdamW single-tensor semantics).  planes = (hi pointer, lo pointer,
+    plane exponent): the updated values are also written as the f16x3 operand planes of the next forward."""
     bc1 = 1.0 - beta1 ** step
     bc2_sqrt = math.sqrt(1.0 - beta2 ** step)
+    hi, lo, e = planes if planes is not None else (None, None, 0)
     ops.L().dupl_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
-                       float(beta2), float(eps), float(wd), float(bc1), float(bc2_sqrt), ops._stream())
+                       float(beta2), float(eps), float(wd), float(bc1), float(bc2_sqrt), hi, lo, e, ops._stream())
 
 
 class PolyWarmupAdamW(torch.optim.Optimizer):
@@ -86,6 +88,9 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
                                "parameter buffer with fused HIP launches (no per-tensor fallback)")
         store, m, v, steps = self._flat
         store.wait_streams()     # the students' backward passes may still be running on their own streams
+        # a student whose operand planes are current gets them rewritten by the update itself (no split pass over the weights
+        # before the next forward); segments without gradients keep their values, hence their planes
+        with_planes = [store.planes_current(s) for s in range(store.n_students)]
         for s in range(store.n_students):
             base = s * store.student_numel
             for seg in range(1, 5):
@@ -99,8 +104,11 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
                 b1, b2 = grp["betas"]
                 sl = slice(base + lo, base + hi)
                 adamw_segment(store.data[sl], store.grad[sl], m[sl], v[sl], steps[s][seg], grp["lr"], b1, b2, grp["eps"],
-                              grp["weight_decay"])
-        store.mark_dirty()       # parameters were rewritten through raw pointers: their f16x3 operand planes are stale
+                              grp["weight_decay"], planes=store.plane_pointers(base + lo, seg) if with_planes[s] else None)
+        store.mark_dirty()       # parameters were rewritten through raw pointers: f16x3 operand planes not written above are stale
+        for s in range(store.n_students):
+            if with_planes[s]:
+                store.planes_written(s)
         self.global_step += 1
 
     # ---- resume (the reference saves no optimiser state; --start_iter with a checkpoint is this build's own path) --------

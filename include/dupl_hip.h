@@ -407,9 +407,11 @@ int dupl_col2im_dil3(const float* dcol, float* dx, int32_t B, int32_t h, int32_t
 /* ---------------------------------------------------------------------------------------------
  * Optimiser (utils/optimizer.py:38-68 -> torch.optim.AdamW) and small element-wise helpers. */
 /* PolyWarmupAdamW.step -> torch.optim.AdamW.step (utils/optimizer.py:38-68) fused over one flat fp32 segment (16-byte
- * aligned); bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t) (host, double) */
+ * aligned); bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t) (host, double).  p_hi / p_lo (both or neither; 8-byte aligned): the updated
+ * parameters are also written as the f16x3 operand planes of the next forward -- format 0 (plane_exp 0) or format 1 (p * 2^plane_exp,
+ * unscaled lo), bit-identical to dupl_split_f16x2 / dupl_split_f16x2b of the updated segment */
 int dupl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-               float eps, float wd, float bc1, float bc2_sqrt, dupl_stream_t s);
+               float eps, float wd, float bc1, float bc2_sqrt, void* p_hi, void* p_lo, int32_t plane_exp, dupl_stream_t s);
 /* optimizer.zero_grad() (train_final_voc.py:470) and buffer initialisation: p[0..n) = v */
 int dupl_fill(float* p, float v, int64_t n, dupl_stream_t s);
 /* y += a*x: the aux-branch gradient joining the residual stream (autograd of vit.py:316-326) */

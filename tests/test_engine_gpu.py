@@ -1071,3 +1071,48 @@ def test_range_guard_routes_out_of_range_operands_to_f32(dev):
     # closer to fp64 there varies with the planted values by a factor ~2 either way: the bar is 3x, against 1e7x without the guard
     assert w16 <= 3.0 * w32 + 5e-7
     assert max(bad[0].values()) > 100 * max(e16[0].values()) or wbad > 100 * w16, "without the guard the clamp must be visible"
+
+
+def test_adamw_planes_give_the_same_training_run(dev):
+    """engine.FUSED_PLANES: three optimiser steps of the tiny dual model (deterministic mode) with the operand planes written by
+    dupl_adamw are bit-identical (losses, parameters, and the planes themselves) to three steps that re-split all weights before
+    every forward."""
+    from dupl_amd import engine, trainer, ops
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd.utils.optimizer import PolyWarmupAdamW
+    from dupl_amd.synthetic import synthetic_batch
+
+    def run(fused):
+        prev = engine.FUSED_PLANES
+        engine.FUSED_PLANES = fused
+        ops.L().dupl_set_deterministic(1)         # bit-reproducible steps: no fp32 atomics anywhere
+        try:
+            torch.manual_seed(0)
+            model = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+            groups = model.get_param_groups()
+            model.to(dev)
+            model.enable_dual_stream(True)
+            optim = PolyWarmupAdamW(params=[{"params": groups[i], "lr": 6e-4 * (1 if i < 2 else 10), "weight_decay": 1e-2}
+                                            for i in range(4)], lr=6e-4, weight_decay=1e-2, betas=(0.9, 0.999), warmup_iter=2,
+                                    max_iter=40, warmup_ratio=1e-6, power=0.9).bind(model.flat_storage)
+            par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+            sargs = trainer.StepArgs(cam_iters=1, gmm_iters=30, max_iters=40)
+            losses = []
+            for it in range(3):
+                inputs, cls_label, img_box = synthetic_batch(2, 20, 224, seed=it)
+                out = trainer.train_step(model, optim, par, inputs.to(dev), cls_label.to(dev), img_box, 2 + it, sargs, cls_label_host=cls_label)
+                losses.append(out["loss"].detach().clone())
+            st = model.flat_storage
+            for s in range(st.n_students):
+                st.ensure_w16(s)
+            torch.cuda.synchronize()
+            return torch.stack([l.reshape(-1)[0] for l in losses]), st.data.clone(), st.data16.clone()
+        finally:
+            engine.FUSED_PLANES = prev
+            ops.L().dupl_set_deterministic(0)
+    la, pa, qa = run(True)
+    lb, pb, qb = run(False)
+    assert torch.equal(la, lb), (la, lb)
+    assert torch.equal(pa, pb)
+    assert torch.equal(qa, qb), "planes written by the optimiser differ from a split of the same parameters"

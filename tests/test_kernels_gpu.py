@@ -384,6 +384,40 @@ def test_loss_kernels(dev, golden_dir):
     assert relerr(l.grad, l64.grad) < 1e-5
 
 
+@pytest.mark.parametrize("n,plane_exp", [(4096 + 8, 0), (4096 + 8, 9), (1 << 20, 9), (37 * 4 + 2, 0)])
+def test_adamw_writes_the_operand_planes_of_the_next_forward(dev, n, plane_exp):
+    """dupl_adamw with p_hi / p_lo: the update is the same as without (bit for bit) and the planes are bit-identical to a split of the
+    updated parameters (dupl_split_f16x2 / dupl_split_f16x2b) -- including the scalar tail of a segment whose length is not a
+    multiple of 4 and values that leave fp16's normal range on either side."""
+    from dupl_amd import ops
+    from dupl_amd.utils.optimizer import adamw_segment
+    g = torch.Generator().manual_seed(n + plane_exp)
+    p0 = (torch.randn(n, generator=g) * 0.05)
+    p0[:8] = torch.tensor([0.0, 1e-9, -3e-7, 2.5e-5, 60.0, -110.0, 7e-4, 1.0])
+    gr = (torch.randn(n, generator=g) * 1e-3).to(dev)
+    m0, v0 = (torch.randn(n, generator=g) * 1e-4).to(dev), (torch.rand(n, generator=g) * 1e-6).to(dev)
+    pa, ma, va = p0.to(dev), m0.clone(), v0.clone()
+    pb, mb, vb = p0.to(dev), m0.clone(), v0.clone()
+    npad = (n + 3) // 4 * 4      # both planes 8-byte aligned
+    planes = torch.full((2, npad), 7.0, device=dev, dtype=torch.float16)
+    adamw_segment(pa, gr, ma, va, 3, 6e-4, 0.9, 0.999, 1e-8, 0.01)
+    adamw_segment(pb, gr, mb, vb, 3, 6e-4, 0.9, 0.999, 1e-8, 0.01,
+                  planes=(planes.data_ptr(), planes.data_ptr() + 2 * npad, plane_exp))
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    ref = torch.empty((2, npad), device=dev, dtype=torch.float16)
+    n4 = n // 4 * 4           # the split entry points take whole float4 chunks; the tail is checked against the definition
+    if plane_exp:
+        ops.L().dupl_split_f16x2b(pa.data_ptr(), ref.data_ptr(), ref.data_ptr() + 2 * npad, n4, plane_exp, ops._stream())
+    else:
+        ops.L().dupl_split_f16x2(pa.data_ptr(), ref.data_ptr(), ref.data_ptr() + 2 * npad, n4, ops._stream())
+    assert torch.equal(planes[:, :n4], ref[:, :n4])
+    if n4 < n:
+        X = pa[n4:].double() * (2.0 ** plane_exp)
+        hi = planes[0, n4:n].double()
+        lo = planes[1, n4:n].double() / (1.0 if plane_exp else 2048.0)
+        assert float(((hi + lo) - X).abs().max()) <= 2.0 ** -21 * float(X.abs().max()) + 1e-12
+
+
 def test_conv_and_adamw(dev, golden_dir):
     import os
     from dupl_amd import ops
