@@ -14,7 +14,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             long rows, int D, float eps, __half* __restrict__ y_hi,
                                                             __half* __restrict__ y_lo, long f32_rows, float plane_scale) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the row is wave-uniform: with the wave index in a scalar register every row pointer below lives in SGPRs (36 -> 30 VGPRs at
+    // D <= 768).  30 is below the 32 registers per SIMD that a 256 x 256 split-GEMM block (2 x 240 of 512) leaves free, but the step
+    // did not change (52.8 ms either way, three same-box pairs): the waves do not measurably run in that GEMM's shadow
+    const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = D >> 2;
     const float4* xr = reinterpret_cast<const float4*>(x + row * D);
