@@ -12,18 +12,21 @@
 //   dv kernel (lane = key,   loop over 32-query tiles): S = Q K^T, P,               dv^T += dO^T P
 //   dk kernel (lane = key,   loop over 32-query tiles): S = Q K^T, dP = dO V^T, dS, dk^T += Q^T dS
 // (dk and dv are separate kernels: together their accumulators, the K and V fragments and the S / dP tiles exceed the 256
-// registers of two waves per SIMD.)  Row-major tiles are [32 rows][128 B], transposed tiles (K^T, Q^T, dO^T: planes
-// [B*H*64][Npad] written by planes_transpose_kernel) are [64 rows][64 B]; all are filled by direct-to-LDS DMA with the bank
-// swizzle on the source side, two stages, one barrier per tile (explicit vmcnt(0) before it on every path).
+// registers of two waves per SIMD.)  Row-major tiles are [32 rows][128 B] with the bank swizzle on the source side.  The last
+// product of each kernel contracts over the tile's ROWS (K^T dS^T, dO^T P, Q^T dS): its A operand is the same K / dO / Q rows read
+// k-major -- a second DMA of the tile lays it out as 512-byte subtiles [8 rows][32 d] and ds_read_b64_tr_b16 gathers the fragments
+// (gemm_split.hip's k-major operands; round 4: the three planes_transpose launches per call and their scratch are gone).  Two
+// stages, one barrier per tile (explicit vmcnt(0) before it on every path).
 #include "common.h"
 #include "../../include/dupl_hip.h"
 
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr float LO_INV = 1.f / DUPL_LO_SCALE;
 constexpr int HD = 64, TT = 32;             // rows (keys or queries) per tile
-constexpr int PL = 4096;                    // bytes of one tile plane (row-major 32 x 128 B, or transposed 64 x 64 B)
+constexpr int PL = 4096;                    // bytes of one tile plane (row-major 32 x 128 B, or k-major: 8 subtiles of 512 B)
 constexpr int MAXN = 2048;                  // lse / delta of one (b, h) are kept in LDS by the key-owner kernels
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
@@ -54,6 +57,49 @@ __device__ __forceinline__ int pi_row(int r) {
     const int g = (r >> 2) & 3;
     return (r & ~12) | ((g == 1 ? 2 : (g == 2 ? 1 : g)) << 2);
 }
+
+// k-major image of a [32 rows][64 d] tile plane: subtile (2 sg + jj) * 2 + dblk = [8 rows][32 d] halfs, holding rows
+// 16 sg + 4 jj + {0..3, 8..11} -- what one ds_read_b64_tr_b16 of row step sg, half jj gathers.  DMA piece w (1 KB, wave w) = row
+// group w, both d blocks: lane -> subtile row (lane >> 2) & 7, 16-byte chunk lane & 3 of d block lane >> 5.
+__device__ __forceinline__ int km_piece_row(int wave, int lane) {
+    const int srow = (lane >> 2) & 7;
+    return (wave >> 1) * 16 + (srow >> 2) * 8 + (wave & 1) * 4 + (srow & 3);
+}
+__device__ __forceinline__ int km_piece_col_bytes(int lane) { return ((lane >> 5) * 32 + (lane & 3) * 8) * 2; }
+// per-lane byte offset of the transposing reads inside a plane image (lane (g = lane >> 4, q = lane & 15): subtile row
+// (g >> 1) * 4 + (q >> 2), d 16 (g & 1) + 4 (q & 3) .. + 3)
+__device__ __forceinline__ int km_read_lane_off(int lane) {
+    const int g = lane >> 4, q = lane & 15;
+    return ((g >> 1) * 4 + (q >> 2)) * 64 + (16 * (g & 1) + 4 * (q & 3)) * 2;
+}
+// The reads are inline asm: behind an LDS-DMA hipcc waits vmcnt(0) before every ds_read_b64_tr_b16 builtin (gemm_split.hip), which
+// would drain the prefetch of the next tile; the consumer waits lgkmcnt(0) itself.
+template <int OFF>
+__device__ __forceinline__ h4 km_tr_read(const unsigned addr) {
+    h4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// all 16 fragments halves of one tile: [(sg * 2 + d) * 2 + plane][half]
+__device__ __forceinline__ void km_read_tile(const unsigned base_hi, h4 (&f)[8][2]) {
+#define KM_RD(SG, DD, PLN, JJ) f[((SG) * 2 + (DD)) * 2 + (PLN)][JJ] = km_tr_read<(PLN) * PL + (((SG) * 2 + (JJ)) * 2 + (DD)) * 512>(base_hi)
+    KM_RD(0, 0, 0, 0); KM_RD(0, 0, 0, 1); KM_RD(0, 0, 1, 0); KM_RD(0, 0, 1, 1);
+    KM_RD(0, 1, 0, 0); KM_RD(0, 1, 0, 1); KM_RD(0, 1, 1, 0); KM_RD(0, 1, 1, 1);
+    KM_RD(1, 0, 0, 0); KM_RD(1, 0, 0, 1); KM_RD(1, 0, 1, 0); KM_RD(1, 0, 1, 1);
+    KM_RD(1, 1, 0, 0); KM_RD(1, 1, 0, 1); KM_RD(1, 1, 1, 0); KM_RD(1, 1, 1, 1);
+#undef KM_RD
+}
+// the wait of the consumer: lgkmcnt(0), with every fragment as an in / out operand -- nothing that uses them (an MFMA is no memory
+// operation: a "memory" clobber alone does not hold it back) can be scheduled above it
+__device__ __forceinline__ void km_wait(h4 (&f)[8][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1]),
+                   "+v"(f[4][0]), "+v"(f[4][1]), "+v"(f[5][0]), "+v"(f[5][1]), "+v"(f[6][0]), "+v"(f[6][1]), "+v"(f[7][0]), "+v"(f[7][1])
+                 :
+                 : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ h8 h8of(const h4 lo, const h4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
 // hi / lo planes of 16 accumulator values, two at a time: one packed convert, one packed multiply, one FMA per element --
 // lo = f16(fma(f32(hi), -2048, 2048 x)) is the same value as f16((x - hi) * 2048) (every step before the final rounding is
@@ -101,55 +147,13 @@ __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ ou
     delta[((long)b * H + h) * N + n] = s;
 }
 
-// Per-head transposed planes: src planes [B*N][ld] (columns col0 + h*64 ..) -> dst [(b*H + h)*64 + d][Npad], zero for n >= N.
-__global__ __launch_bounds__(256) void planes_transpose_kernel(const __half* __restrict__ s_hi, const __half* __restrict__ s_lo,
-                                                               int ld, int col0, __half* __restrict__ d_hi,
-                                                               __half* __restrict__ d_lo, int N, int H, int Npad) {
-    __shared__ unsigned int tile[64][65];          // (hi | lo << 16)
-    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i;               // row c / 8, columns (c % 8) * 8 .. + 7
-        const int r = c >> 3, d0 = (c & 7) << 3;
-        uint4 vh = make_uint4(0u, 0u, 0u, 0u), vl = vh;
-        if (k0 + r < N) {
-            const size_t off = ((size_t)b * N + k0 + r) * ld + col0 + h * HD + d0;
-            vh = *reinterpret_cast<const uint4*>(s_hi + off);
-            vl = *reinterpret_cast<const uint4*>(s_lo + off);
-        }
-        const unsigned short* ph = reinterpret_cast<const unsigned short*>(&vh);
-        const unsigned short* pl = reinterpret_cast<const unsigned short*>(&vl);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tile[r][d0 + j] = (unsigned int)ph[j] | ((unsigned int)pl[j] << 16);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i;               // d = c / 8, rows (c % 8) * 8 .. + 7
-        const int d = c >> 3, rr = (c & 7) << 3;
-        unsigned int w[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = tile[rr + j][d];
-        uint4 oh, ol;
-        oh.x = (w[0] & 0xffffu) | (w[1] << 16); oh.y = (w[2] & 0xffffu) | (w[3] << 16);
-        oh.z = (w[4] & 0xffffu) | (w[5] << 16); oh.w = (w[6] & 0xffffu) | (w[7] << 16);
-        ol.x = (w[0] >> 16) | (w[1] & 0xffff0000u); ol.y = (w[2] >> 16) | (w[3] & 0xffff0000u);
-        ol.z = (w[4] >> 16) | (w[5] & 0xffff0000u); ol.w = (w[6] >> 16) | (w[7] & 0xffff0000u);
-        const size_t off = ((size_t)(b * H + h) * HD + d) * Npad + k0 + rr;
-        *reinterpret_cast<uint4*>(d_hi + off) = oh;
-        *reinterpret_cast<uint4*>(d_lo + off) = ol;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------- dq
-// Stage (24 KB): K_hi | K_lo | V_hi | V_lo (row-major [32 keys][128 B]) | KT_hi | KT_lo ([64 d][64 B])
+// Stage (24 KB): K_hi | K_lo | V_hi | V_lo (row-major [32 keys][128 B]) | K_hi | K_lo again, k-major
 __global__ __launch_bounds__(256, 2) void attn_bwd16_dq_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
                                                                const __half* __restrict__ do_hi, const __half* __restrict__ do_lo,
-                                                               const __half* __restrict__ kT_hi, const __half* __restrict__ kT_lo,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                const float* __restrict__ slot, float* __restrict__ dqkv, unsigned int* __restrict__ amax_out, int N, int H,
-                                                               int Npad, float scale, int remap) {
+                                                               float scale, int remap) {
     constexpr int STAGE = 6 * PL;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
@@ -180,24 +184,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dq_kernel(const __half* __r
 
     // DMA plan: wave w fetches piece w of every plane
     const int rrow = 8 * wave + (lane >> 3), rch = ((lane & 7) ^ ((rrow >> 1) & 7)) * 16;         // row-major pieces
-    const int trow = 16 * wave + (lane >> 2), tch = ((lane & 3) ^ ((trow >> 2) & 3)) * 16;        // transposed pieces
-    const char* k_hi = reinterpret_cast<const char*>(qkv_hi + (size_t)b * N * ld + D + h * HD) + rch;
-    const char* k_lo = reinterpret_cast<const char*>(qkv_lo + (size_t)b * N * ld + D + h * HD) + rch;
-    const char* t_hi = reinterpret_cast<const char*>(kT_hi + ((size_t)(b * H + h) * HD + trow) * Npad) + tch;
-    const char* t_lo = reinterpret_cast<const char*>(kT_lo + ((size_t)(b * H + h) * HD + trow) * Npad) + tch;
+    const int trow = km_piece_row(wave, lane), tcb = km_piece_col_bytes(lane);                    // k-major pieces
+    const char* k_hi = reinterpret_cast<const char*>(qkv_hi + (size_t)b * N * ld + D + h * HD);
+    const char* k_lo = reinterpret_cast<const char*>(qkv_lo + (size_t)b * N * ld + D + h * HD);
     auto issue = [&](int t, int buf) __attribute__((always_inline)) {
         char* dst = smem + buf * STAGE + wave * 1024;
-        const size_t ro = (size_t)min(t * TT + rrow, N - 1) * (ld * 2);
+        const size_t ro = (size_t)min(t * TT + rrow, N - 1) * (ld * 2) + rch;
         dma16(k_hi + ro, dst);
         dma16(k_lo + ro, dst + PL);
         dma16(k_hi + ro + D * 2, dst + 2 * PL);          // V = K columns + D
         dma16(k_lo + ro + D * 2, dst + 3 * PL);
-        dma16(t_hi + (size_t)t * (TT * 2), dst + 4 * PL);
-        dma16(t_lo + (size_t)t * (TT * 2), dst + 5 * PL);
+        const size_t to = (size_t)min(t * TT + trow, N - 1) * (ld * 2) + tcb;      // keys past N meet dS = 0
+        dma16(k_hi + to, dst + 4 * PL);
+        dma16(k_lo + to, dst + 5 * PL);
     };
     const int prow = pi_row(l31);
     const int a_off = prow * 128, a_sw = (prow >> 1) & 7;             // K / V rows as A operand
-    const int kt_sw = (l31 >> 2) & 3;                                  // K^T rows d = 32 dt + l31 (64-byte rows)
+    const unsigned km_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + 4 * PL + km_read_lane_off(lane);
 
     f32x16 dqM[2], dqX[2];
 #pragma unroll
@@ -240,15 +243,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dq_kernel(const __half* __r
             const float p = kvld ? fast_exp(sv - my_lse) : 0.f;
             ds[e] = __fmul_rn(p, __fsub_rn(pM[e] + pX[e] * LO_INV, my_delta));   // s_do * dS^T[key][q]; un-contracted, see dkv
         }
+        // the k-major K fragments of the last product: in flight under the hi / lo split of dS (~100 VALU instructions)
+        h4 kf[8][2];
+        km_read_tile(km_lds + (t & 1) * STAGE, kf);
         h8 dh[2], dl[2];
         split_regs(ds, dh, dl);
+        km_wait(kf);
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
-            const int ch = ((2 * sg + hf) ^ kt_sw) * 16;
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
-                const h8 th = *reinterpret_cast<const h8*>(st + 4 * PL + (32 * d + l31) * 64 + ch);
-                const h8 tl = *reinterpret_cast<const h8*>(st + 5 * PL + (32 * d + l31) * 64 + ch);
+                const h8 th = h8of(kf[(sg * 2 + d) * 2][0], kf[(sg * 2 + d) * 2][1]);
+                const h8 tl = h8of(kf[(sg * 2 + d) * 2 + 1][0], kf[(sg * 2 + d) * 2 + 1][1]);
                 dqM[d] = MFMA16(th, dh[sg], dqM[d]);
                 dqX[d] = MFMA16(th, dl[sg], dqX[d]);
                 dqX[d] = MFMA16(tl, dh[sg], dqX[d]);
@@ -276,15 +282,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dq_kernel(const __half* __r
 }
 
 // ---------------------------------------------------------------------------------------------------- dk / dv
-// MODE 0 (dv): stage = Q_hi | Q_lo (row-major [32 q][128 B]) | dOT_hi | dOT_lo ([64 d][64 B])                       (16 KB)
-// MODE 1 (dk): stage = Q_hi | Q_lo | dO_hi | dO_lo (row-major) | QT_hi | QT_lo ([64 d][64 B])                        (24 KB)
+// MODE 0 (dv): stage = Q_hi | Q_lo (row-major [32 q][128 B]) | dO_hi | dO_lo k-major                                (16 KB)
+// MODE 1 (dk): stage = Q_hi | Q_lo | dO_hi | dO_lo (row-major) | Q_hi | Q_lo again, k-major                         (24 KB)
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd16_dkv_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
                                                                 const __half* __restrict__ do_hi, const __half* __restrict__ do_lo,
-                                                                const __half* __restrict__ xT_hi, const __half* __restrict__ xT_lo,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 const float* __restrict__ slot, float* __restrict__ dqkv, unsigned int* __restrict__ amax_out, int N, int H,
-                                                                int Npad, float scale, int remap) {
+                                                                float scale, int remap) {
     constexpr int NPL = MODE == 0 ? 4 : 6;
     constexpr int STAGE = NPL * PL;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + (MODE == 0 ? 1 : 2) * MAXN * 4];
@@ -321,28 +326,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dkv_kernel(const __half* __
     }
 
     const int rrow = 8 * wave + (lane >> 3), rch = ((lane & 7) ^ ((rrow >> 1) & 7)) * 16;
-    const int trow = 16 * wave + (lane >> 2), tch = ((lane & 3) ^ ((trow >> 2) & 3)) * 16;
-    const char* q_hi = reinterpret_cast<const char*>(qkv_hi + (size_t)b * N * ld + h * HD) + rch;
-    const char* q_lo = reinterpret_cast<const char*>(qkv_lo + (size_t)b * N * ld + h * HD) + rch;
-    const char* o_hi = reinterpret_cast<const char*>(do_hi + (size_t)b * N * D + h * HD) + rch;
-    const char* o_lo = reinterpret_cast<const char*>(do_lo + (size_t)b * N * D + h * HD) + rch;
-    const char* t_hi = reinterpret_cast<const char*>(xT_hi + ((size_t)(b * H + h) * HD + trow) * Npad) + tch;
-    const char* t_lo = reinterpret_cast<const char*>(xT_lo + ((size_t)(b * H + h) * HD + trow) * Npad) + tch;
+    const int trow = km_piece_row(wave, lane), tcb = km_piece_col_bytes(lane);
+    const char* q_hi = reinterpret_cast<const char*>(qkv_hi + (size_t)b * N * ld + h * HD);
+    const char* q_lo = reinterpret_cast<const char*>(qkv_lo + (size_t)b * N * ld + h * HD);
+    const char* o_hi = reinterpret_cast<const char*>(do_hi + (size_t)b * N * D + h * HD);
+    const char* o_lo = reinterpret_cast<const char*>(do_lo + (size_t)b * N * D + h * HD);
     auto issue = [&](int t, int buf) __attribute__((always_inline)) {
         char* dst = smem + buf * STAGE + wave * 1024;
         const int rr = min(t * TT + rrow, N - 1);
-        dma16(q_hi + (size_t)rr * (ld * 2), dst);
-        dma16(q_lo + (size_t)rr * (ld * 2), dst + PL);
+        dma16(q_hi + (size_t)rr * (ld * 2) + rch, dst);
+        dma16(q_lo + (size_t)rr * (ld * 2) + rch, dst + PL);
         if (MODE == 1) {
-            dma16(o_hi + (size_t)rr * (D * 2), dst + 2 * PL);
-            dma16(o_lo + (size_t)rr * (D * 2), dst + 3 * PL);
+            dma16(o_hi + (size_t)rr * (D * 2) + rch, dst + 2 * PL);
+            dma16(o_lo + (size_t)rr * (D * 2) + rch, dst + 3 * PL);
         }
-        dma16(t_hi + (size_t)t * (TT * 2), dst + (NPL - 2) * PL);
-        dma16(t_lo + (size_t)t * (TT * 2), dst + (NPL - 1) * PL);
+        const int tr = min(t * TT + trow, N - 1);            // queries past N meet P = dS = 0
+        if (MODE == 0) {
+            dma16(o_hi + (size_t)tr * (D * 2) + tcb, dst + (NPL - 2) * PL);
+            dma16(o_lo + (size_t)tr * (D * 2) + tcb, dst + (NPL - 1) * PL);
+        } else {
+            dma16(q_hi + (size_t)tr * (ld * 2) + tcb, dst + (NPL - 2) * PL);
+            dma16(q_lo + (size_t)tr * (ld * 2) + tcb, dst + (NPL - 1) * PL);
+        }
     };
     const int prow = pi_row(l31);
     const int a_off = prow * 128, a_sw = (prow >> 1) & 7;
-    const int xt_sw = (l31 >> 2) & 3;
+    const unsigned km_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + (NPL - 2) * PL + km_read_lane_off(lane);
 
     f32x16 gM[2], gX[2];
 #pragma unroll
@@ -390,15 +399,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dkv_kernel(const __half* __
             // dS = P (dP - delta): the difference first, then the product (never fma(p, dP, -(p * delta)))
             w[e] = MODE == 0 ? p : __fmul_rn(p, __fsub_rn(pM[e] + pX[e] * LO_INV, Ds[qc]));   // P[q][key] or s_do * dS[q][key]
         }
+        // the k-major dO / Q fragments of the last product: in flight under the hi / lo split of P / dS
+        h4 xf[8][2];
+        km_read_tile(km_lds + (t & 1) * STAGE, xf);
         h8 wh[2], wl[2];
         split_regs(w, wh, wl);
+        km_wait(xf);
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
-            const int ch = ((2 * sg + hf) ^ xt_sw) * 16;
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
-                const h8 th = *reinterpret_cast<const h8*>(st + (NPL - 2) * PL + (32 * d + l31) * 64 + ch);
-                const h8 tl = *reinterpret_cast<const h8*>(st + (NPL - 1) * PL + (32 * d + l31) * 64 + ch);
+                const h8 th = h8of(xf[(sg * 2 + d) * 2][0], xf[(sg * 2 + d) * 2][1]);
+                const h8 tl = h8of(xf[(sg * 2 + d) * 2 + 1][0], xf[(sg * 2 + d) * 2 + 1][1]);
                 gM[d] = MFMA16(th, wh[sg], gM[d]);           // dv^T += dO^T P   /   dk^T += Q^T dS
                 gX[d] = MFMA16(th, wl[sg], gX[d]);
                 gX[d] = MFMA16(tl, wh[sg], gX[d]);
@@ -430,37 +442,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dkv_kernel(const __half* __
 constexpr int g_attnb16_remap = 1;     // XCD-aware workgroup order
 
 extern "C" int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
-                                    const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T,
-                                    float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale,
-                                    void* amax_out, dupl_stream_t stream) {
+                                    const void* do_lo, const float* do_slot, const float* lse, float* delta, float* dqkv, int32_t B,
+                                    int32_t N, int32_t H, int32_t hd, float scale, void* amax_out, dupl_stream_t stream) {
     (void)hipGetLastError();
     unsigned int* ax = static_cast<unsigned int*>(amax_out);
-    if (!qkv_hi || !qkv_lo || !out || !dout || !do_hi || !do_lo || !do_slot || !lse || !delta || !scratch_T || !dqkv || B <= 0 ||
-        N <= 0 || N > MAXN || H <= 0 || hd != HD || Npad < N || (Npad % 64))
+    if (!qkv_hi || !qkv_lo || !out || !dout || !do_hi || !do_lo || !do_slot || !lse || !delta || !dqkv || B <= 0 || N <= 0 ||
+        N > MAXN || H <= 0 || hd != HD)
         return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const int D = H * HD;
     const long total = (long)B * N * H;
     hipLaunchKernelGGL(delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, delta, B, N, H);
-    // transposed planes: scratch_T holds 3 x 2 planes of B*H*64*Npad halfs: K^T, Q^T, dO^T
-    const size_t pl = (size_t)B * H * HD * Npad;
-    __half* T = static_cast<__half*>(scratch_T);
-    __half *kT_hi = T, *kT_lo = T + pl, *qT_hi = T + 2 * pl, *qT_lo = T + 3 * pl, *oT_hi = T + 4 * pl, *oT_lo = T + 5 * pl;
-    const dim3 tg(Npad / 64, H, B);
-    hipLaunchKernelGGL(planes_transpose_kernel, tg, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo, 3 * D, D, kT_hi,
-                       kT_lo, N, H, Npad);
-    hipLaunchKernelGGL(planes_transpose_kernel, tg, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo, 3 * D, 0, qT_hi,
-                       qT_lo, N, H, Npad);
-    hipLaunchKernelGGL(planes_transpose_kernel, tg, dim3(256), 0, s, (const __half*)do_hi, (const __half*)do_lo, D, 0, oT_hi, oT_lo,
-                       N, H, Npad);
     const dim3 grid((N + 127) / 128, H, B);
     hipLaunchKernelGGL(attn_bwd16_dq_kernel, grid, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo, (const __half*)do_hi,
-                       (const __half*)do_lo, kT_hi, kT_lo, lse, delta, do_slot, dqkv, ax, N, H, Npad, scale, g_attnb16_remap);
+                       (const __half*)do_lo, lse, delta, do_slot, dqkv, ax, N, H, scale, g_attnb16_remap);
     hipLaunchKernelGGL(attn_bwd16_dkv_kernel<0>, grid, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo,
-                       (const __half*)do_hi, (const __half*)do_lo, oT_hi, oT_lo, lse, delta, do_slot, dqkv, ax, N, H, Npad, scale,
-                       g_attnb16_remap);
+                       (const __half*)do_hi, (const __half*)do_lo, lse, delta, do_slot, dqkv, ax, N, H, scale, g_attnb16_remap);
     hipLaunchKernelGGL(attn_bwd16_dkv_kernel<1>, grid, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo,
-                       (const __half*)do_hi, (const __half*)do_lo, qT_hi, qT_lo, lse, delta, do_slot, dqkv, ax, N, H, Npad, scale,
-                       g_attnb16_remap);
+                       (const __half*)do_hi, (const __half*)do_lo, lse, delta, do_slot, dqkv, ax, N, H, scale, g_attnb16_remap);
     return dupl_launch_status();
 }

@@ -551,14 +551,11 @@ def attention_bwd16(qkv16, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: in
     dout = dout.contiguous()
     do16, _, alpha = split_prepare(dout, scaled=True, want_rm=True, want_T=False, target_exp=4)
     alpha.check()
-    npad = (N + 63) // 64 * 64
-    scratch = torch.empty((6, B * H * hd * npad), device=dev, dtype=torch.float16)
     delta = torch.empty((B, H, N), device=dev, dtype=torch.float32)
     dqkv = torch.empty((B * N, 3 * H * hd), device=dev, dtype=torch.float32)
     word, tok = reserve_amax(dev) if amax_for_next else (None, None)       # after dout's split took its slot
     L().dupl_attention_bwd16(qkv16.hi, qkv16.lo, out.data_ptr(), dout.data_ptr(), do16.hi, do16.lo, int(alpha) - 4, lse.data_ptr(),
-                             delta.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(), B, N, H, hd, npad, float(scale), word,
-                             _stream())
+                             delta.data_ptr(), dqkv.data_ptr(), B, N, H, hd, float(scale), word, _stream())
     if tok is not None:
         dqkv._dupl_amax = tok
     return dqkv

@@ -442,12 +442,12 @@ int dupl_multilabel_f1_accum(const float* logits, const float* label, int32_t B,
 /* Attention backward as fp32-equivalent f16x3 split products (csrc/attn_split_bwd.hip; head dim 64, N <= 2048): autograd of
  * vit.py:123-135.  qkv_hi / qkv_lo: planes of the qkv GEMM output saved by the forward; out / dout: fp32 attention output
  * and its gradient ([B*N][H*hd]); do_hi / do_lo + do_slot: dout as planes scaled with target_exp 4 (dupl_split_prepare;
- * do_slot = its {scale, 1/scale,..} record); lse from the forward; delta: B*H*N floats of scratch; scratch_T: 6 planes of
- * B*H*hd*Npad halfs (K^T, Q^T, dO^T); dqkv [B*N][3*H*hd] fp32 receives dq | dk | dv.  amax_out != NULL: max |dqkv| is raised into
+ * do_slot = its {scale, 1/scale,..} record); lse from the forward; delta: B*H*N floats of scratch (the only one: K, Q and dO are
+ * read in place as k-major operands where a product contracts over their rows); dqkv [B*N][3*H*hd] fp32 receives dq | dk | dv.  amax_out != NULL: max |dqkv| is raised into
  * *amax_out (the amax word of a scale slot, see dupl_split_prepare amax_mode 1). */
 int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
-                         const void* do_lo, const float* do_slot, const float* lse, float* delta, void* scratch_T, float* dqkv,
-                         int32_t B, int32_t N, int32_t H, int32_t hd, int32_t Npad, float scale, void* amax_out, dupl_stream_t stream);
+                         const void* do_lo, const float* do_slot, const float* lse, float* delta, float* dqkv, int32_t B, int32_t N,
+                         int32_t H, int32_t hd, float scale, void* amax_out, dupl_stream_t stream);
 
 /* ------------------------------------------------------------------ per-step strong augmentation
  * utils/imutils.py:305-317 augment_data_strong / utils/randomaug.py RandAugment on the device: planar uint8 images

@@ -91,7 +91,7 @@ def main():
         out = torch.empty(B * N, H * hd, device=dev)
         lse = ops.attention_fwd16(qkv16, B, N, H, hd, hd ** -0.5, need_lse=True, out=out)
         t = timeit(lambda: ops.attention_bwd16(qkv16, out, dout, lse, B, N, H, hd, hd ** -0.5), n=100)
-        print(f"attention_bwd16 B{B} N{N}: {t:.1f} us (delta + 3 transposes + dq + dv + dk + the dout split)")
+        print(f"attention_bwd16 B{B} N{N}: {t:.1f} us (delta + dq + dv + dk + the dout split)")
 
 
 if __name__ == "__main__":
