@@ -784,6 +784,40 @@ def test_split_kernels_are_deterministic_under_stream_concurrency(dev):
         assert bad == 0, name
 
 
+@pytest.mark.parametrize("rise", [3.0, 40.0, 400.0])
+def test_attention_fwd16_lazy_maximum_with_rising_scores(dev, rise):
+    """The split attention keeps a LAZY running maximum (it moves only when a probability would pass 2^8).  Scores that keep
+    rising along the key axis -- by `rise` nats over the sequence, i.e. a fraction of, about, and many times the 5.5-nat threshold per
+    64-key tile -- exercise the stale-maximum path, the rescaling path and their mix; output and lse against float64, same bars as
+    the well-scaled test (2x the exact-f32 kernel's error + 2e-7; lse 2x + 1e-6)."""
+    from dupl_amd import ops
+    B, N, H, hd = 1, 1000, 12, 64
+    D = H * hd
+    g = torch.Generator().manual_seed(int(rise))
+    qkv = torch.randn(B * N, 3 * D, generator=g) * 0.3
+    t = qkv.view(B * N, 3, H, hd)
+    u = torch.randn(H, hd, generator=g)
+    u = u / u.norm(dim=1, keepdim=True)
+    scale = hd ** -0.5
+    t[:, 0] += 4.0 * u                                                       # every query has a component 4 along u
+    ramp = torch.linspace(0.0, 1.0, N).view(N, 1, 1)
+    t[:, 1] += ramp * (rise / (4.0 * scale)) * u                             # key j adds (j / N) * rise to every score
+    qkv = qkv.to(dev)
+    qd, kd, vd = (qkv.double().view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+    att = (qd @ kd.transpose(-1, -2)) * scale
+    ref = (att.softmax(-1) @ vd).transpose(1, 2).reshape(B * N, D)
+    ref_lse = torch.logsumexp(att, dim=-1)
+    o32, l32 = ops.attention_fwd(qkv, B, N, H, hd, scale, need_lse=True)
+    out = torch.empty(B * N, D, device=dev)
+    l16 = ops.attention_fwd16(ops.split16(qkv), B, N, H, hd, scale, need_lse=True, out=out)
+    sc = float(ref.abs().max())
+    e16, e32 = float((out.double() - ref).abs().max()) / sc, float((o32.double() - ref).abs().max()) / sc
+    a16, a32 = float((l16.double() - ref_lse).abs().max()), float((l32.double() - ref_lse).abs().max())
+    print(f"rise {rise}: out f16x3 {e16:.2e} f32 {e32:.2e}; lse f16x3 {a16:.2e} f32 {a32:.2e} (|lse| to {float(ref_lse.abs().max()):.0f})")
+    assert torch.isfinite(out).all() and e16 <= 2.0 * e32 + 2e-7
+    assert a16 <= 2.0 * a32 + 1e-6 * max(1.0, float(ref_lse.abs().max()))
+
+
 @pytest.mark.parametrize("B,N", [(2, 197), (1, 785), (2, 64), (1, 130), (3, 50)])
 def test_attention_bwd16_is_fp32_equivalent(dev, B, N):
     """dupl_attention_bwd16 (q / k / v planes saved by the forward, dO as power-of-two-scaled planes, P / dS split in
