@@ -94,8 +94,33 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start the N ranks here,
+    the way the reference is started (README.md:83,93: torch.distributed.run --nproc_per_node=N), and pass the ranks' exit
+    code on.  Refuses to run when the node has fewer than N GPUs -- N ranks never silently share a device."""
+    import socket
+    import subprocess
+    share = os.environ.get("DUPL_BENCH_RANKS_SHARE_GPU0") == "1"      # test hook (gloo, every rank on device 0)
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s); refusing to run {args.gpus} ranks on fewer devices")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without a launcher: starting {args.gpus} ranks through torch.distributed.run (port {port})")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def build_world(args):
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the line would report the wrong n_gpus")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -104,8 +129,11 @@ def build_world(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ.get("DUPL_BENCH_RANKS_SHARE_GPU0") == "1":    # test hook: every rank on device 0 (needs --backend gloo)
             local = 0
+        elif torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py --gpus {world}: this node exposes {torch.cuda.device_count()} GPU(s)")
         torch.cuda.set_device(local)
         dist.init_process_group(backend=args.backend)
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
     else:
         torch.cuda.set_device(0)
     return world, rank, local

@@ -37,8 +37,10 @@ def install_reference_aliases(override: bool = False):
 
 def set_deterministic(on: bool = True):
     """Bit-reproducible steps (the reference's `torch.backends.cudnn.deterministic = True`, train_final_voc.py:95-102):
-    every accumulation that otherwise uses fp32 atomics -- split-K weight gradients, LayerNorm dgamma / dbeta, bias column
-    sums, the seg-loss backward scatter -- runs in a fixed order.  Costs throughput (the weight-gradient GEMMs lose their
-    k-split); off by default.  Also switched on by the environment variable DUPL_DETERMINISTIC=1."""
-    from ._lib import lib
-    lib().dupl_set_deterministic(1 if on else 0)
+    every accumulation that otherwise uses fp32 atomics -- split-K / stream-K gradients, LayerNorm dgamma / dbeta, bias column
+    sums, the seg-loss backward scatter -- runs in a fixed order (the loss scalars are order-independent in either mode: 64-bit
+    fixed-point sums, csrc/loss.hip).  Costs throughput (the weight-gradient GEMMs lose their k-split); off by default.  Also
+    switched on by the environment variable DUPL_DETERMINISTIC=1.  The switch lives on the caller's side (ops.set_deterministic):
+    since ABI 3 the library holds no mode, every call is handed the value."""
+    from . import ops
+    ops.set_deterministic(on)

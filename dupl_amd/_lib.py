@@ -29,7 +29,7 @@ class GemmDesc(ctypes.Structure):
         ("sA0", ctypes.c_int64), ("sA1", ctypes.c_int64), ("sB0", ctypes.c_int64), ("sB1", ctypes.c_int64),
         ("sC0", ctypes.c_int64), ("sC1", ctypes.c_int64), ("sR0", ctypes.c_int64), ("sR1", ctypes.c_int64),
         ("sX0", ctypes.c_int64), ("sX1", ctypes.c_int64), ("sBias0", ctypes.c_int64), ("sBias1", ctypes.c_int64),
-        ("alpha", ctypes.c_float), ("flags", ctypes.c_int32),
+        ("alpha", ctypes.c_float), ("flags", ctypes.c_int32), ("deterministic", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
     def __init__(self, *a, **kw):
@@ -40,7 +40,7 @@ class GemmDesc(ctypes.Structure):
 class Gemm16Desc(ctypes.Structure):
     """Mirror of `dupl_gemm16_desc` (include/dupl_hip.h): operands as fp16 hi / lo planes."""
     _fields_ = [
-        ("struct_size", ctypes.c_uint32), ("reserved0", ctypes.c_int32),
+        ("struct_size", ctypes.c_uint32), ("deterministic", ctypes.c_int32),
         ("A_hi", ctypes.c_void_p), ("A_lo", ctypes.c_void_p), ("B_hi", ctypes.c_void_p), ("B_lo", ctypes.c_void_p),
         ("C", ctypes.c_void_p), ("C_hi", ctypes.c_void_p), ("C_lo", ctypes.c_void_p),
         ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p), ("aux", ctypes.c_void_p),
@@ -66,7 +66,7 @@ class SplitDesc(ctypes.Structure):
         ("x", ctypes.c_void_p), ("slot", ctypes.c_void_p), ("next_bits", ctypes.c_void_p),
         ("hi", ctypes.c_void_p), ("lo", ctypes.c_void_p), ("hiT", ctypes.c_void_p), ("loT", ctypes.c_void_p),
         ("Rp", ctypes.c_int32), ("target_exp", ctypes.c_int32), ("colsum_accum", ctypes.c_void_p),
-        ("amax_mode", ctypes.c_int32), ("fmt", ctypes.c_int32), ("rows_zero_to", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("amax_mode", ctypes.c_int32), ("fmt", ctypes.c_int32), ("rows_zero_to", ctypes.c_int32), ("deterministic", ctypes.c_int32),
     ]
 
     def __init__(self, *a, **kw):
@@ -143,7 +143,7 @@ class _Lib:
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
             # getters return a value, everything else a status (0 = ok) that is checked on every call
-            setattr(self, name, fn if name in ("dupl_abi_version", "dupl_get_deterministic", "dupl_layernorm_bwd_blocks") else self._checked(name, fn))
+            setattr(self, name, fn if name in ("dupl_abi_version", "dupl_layernorm_bwd_blocks") else self._checked(name, fn))
 
     @staticmethod
     def _checked(name, fn):
@@ -164,6 +164,4 @@ def lib() -> _Lib:
     global _LIB
     if _LIB is None:
         _LIB = _Lib()
-        if os.environ.get("DUPL_DETERMINISTIC", "0") == "1":
-            _LIB.dupl_set_deterministic(1)
     return _LIB

@@ -10,9 +10,9 @@
 
 #define DUPL_WAVE 64
 
-// dupl_set_deterministic (gemm.hip): 1 = every accumulation that otherwise uses fp32 atomics (split-K weight gradients,
-// LayerNorm dgamma / dbeta, bias column sums, seg-loss backward) runs in a fixed order -> bit-reproducible steps
-extern int g_dupl_deterministic;
+// Determinism is a per-call argument (dupl_hip.h, ABI 3): the library keeps no mode.  `deterministic` != 0 = the accumulation that
+// otherwise uses fp32 atomics (split-K / stream-K gradients, LayerNorm dgamma / dbeta, bias column sums, seg-loss backward scatter)
+// runs in a fixed order.  The loss scalars are reduced in 64-bit fixed point (loss.hip): order-independent in every mode.
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -250,15 +250,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
 
 }  // namespace
 
-int g_dupl_deterministic = 0;
-
-extern "C" int dupl_get_deterministic(void) { return g_dupl_deterministic; }
-
-extern "C" int dupl_set_deterministic(int32_t on) {
-    g_dupl_deterministic = on ? 1 : 0;
-    return DUPL_OK;
-}
-
 extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!d || d->struct_size != sizeof(dupl_gemm_desc)) return DUPL_ERR_ARG;       // a caller built against another header
@@ -297,7 +288,7 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
             if (ksplit < 1) ksplit = 1;
         }
     }
-    if (g_dupl_deterministic) ksplit = 1;          // no fp32 atomics: one block owns the whole reduction of its tile
+    if (d->deterministic) ksplit = 1;          // no fp32 atomics: one block owns the whole reduction of its tile
     dim3 grid(nbm * nbn, d->batch, ksplit), block(NT);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool amc = d->flags & DUPL_GEMM_A_MCONTIG, bnc = d->flags & DUPL_GEMM_B_NCONTIG;
@@ -331,4 +322,4 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     return dupl_launch_status();
 }
 
-extern "C" int dupl_abi_version(void) { return 2; }
+extern "C" int dupl_abi_version(void) { return 3; }

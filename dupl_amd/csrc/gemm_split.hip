@@ -1636,7 +1636,7 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         const int maxs = (d->K / TBK + 7) / 8;
         if (ksplit > maxs) ksplit = maxs;
         if (ksplit < 1) ksplit = 1;
-        if (g_dupl_deterministic) ksplit = 1;      // no fp32 atomics
+        if (d->deterministic) ksplit = 1;      // no fp32 atomics
     }
     int tile = g16_tile;
     if (tile == 0) {
@@ -1672,11 +1672,11 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         if (!d->a_layout && d->ka_valid) return DUPL_ERR_ARG;
         if (!d->b_layout && d->kb_valid) return DUPL_ERR_ARG;
         const int nb21 = ((d->M + 255) / 256) * ((d->N + 127) / 128);
-        const bool sk = accum && !g_dupl_deterministic && ksplit > 1;
+        const bool sk = accum && !d->deterministic && ksplit > 1;
         if (accum && !d->a_layout) {
             // a data gradient with a LINEAR epilogue (dx = alpha dy . W, nothing else) into a zero-filled dx: stream-K pieces meet in
             // fp32 atomics, so that the N = 768 outputs (78 tiles of 256 x 128 at 4 images, 42 at 2) run on every CU
-            if (!d->b_layout || g_dupl_deterministic) return DUPL_ERR_ARG;      // (the caller takes the one-block-per-tile form then)
+            if (!d->b_layout || d->deterministic) return DUPL_ERR_ARG;      // (the caller takes the one-block-per-tile form then)
             hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, false, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d, g16_group_ring);
         } else if (accum) {
             if (!(d->a_layout && d->b_layout)) return DUPL_ERR_ARG;            // the weight gradient: both operands token-major
@@ -1702,7 +1702,7 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         return dupl_launch_status();
     }
     if (tile == 10 && (accum || d->K / TBK < 3)) tile = 6;      // the persistent kernel has no split-K and a 3-stage prologue
-    if (tile == 11 && (!accum || g_dupl_deterministic || d->K / TBK < 8)) tile = accum ? 5 : 6;   // stream-K: atomics, pieces >= 3 k-steps
+    if (tile == 11 && (!accum || d->deterministic || d->K / TBK < 8)) tile = accum ? 5 : 6;   // stream-K: atomics, pieces >= 3 k-steps
     if (tile == 11) {
         hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d,
                            g16_group_ring);

@@ -5,6 +5,32 @@
 
 namespace {
 
+// ----------------------------------------------------------------------------------------------- order-independent loss sums
+// The four scalar sums of a loss are reduced over thousands of blocks.  fp32 atomics would make them depend on the order the
+// blocks retire in (the last bit of the printed loss changes from run to run); instead every block adds its partial sums as Q28
+// FIXED POINT into 64-bit integer accumulators -- integer addition commutes, so the result is the same in any order, in every
+// mode, and it is more accurate than a chain of fp32 adds (a partial < 2^35 converts exactly to 2^-28; one rounding at the end).
+// Layout of the caller's zero-filled `sums` (DUPL_LOSS_SUMS_FLOATS = 16 floats): [0..3] the four results, written by the
+// last block to retire; [4..11] four uint64 accumulators; [12] retired-block counter; [13] "a partial was inf / NaN" flag (a
+// diverged run must still print a non-finite loss: the results are NaN then).
+constexpr float Q28 = 268435456.f;
+__device__ __forceinline__ void loss_sums_commit(float* __restrict__ sums, float a, float b, float c, float d, unsigned nblocks) {
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(sums + 4);
+    unsigned* done = reinterpret_cast<unsigned*>(sums + 12);
+    if (!(isfinite(a) && isfinite(b) && isfinite(c) && isfinite(d))) { atomicOr(done + 1, 1u); a = b = c = d = 0.f; }
+    if (a != 0.f) atomicAdd(&acc[0], (unsigned long long)__float2ll_rn(a * Q28));
+    if (b != 0.f) atomicAdd(&acc[1], (unsigned long long)__float2ll_rn(b * Q28));
+    if (c != 0.f) atomicAdd(&acc[2], (unsigned long long)__float2ll_rn(c * Q28));
+    if (d != 0.f) atomicAdd(&acc[3], (unsigned long long)__float2ll_rn(d * Q28));
+    __threadfence();
+    if (atomicAdd(done, 1u) == nblocks - 1u) {
+        __threadfence();
+        const bool bad = atomicOr(done + 1, 0u) != 0u;
+        for (int i = 0; i < 4; ++i)
+            sums[i] = bad ? __int_as_float(0x7fc00000) : (float)((double)atomicAdd(&acc[i], 0ull) * (1.0 / 268435456.0));
+    }
+}
+
 // ----------------------------------------------------------------------------------------------- PTC
 // cos (b,hw,hw) signed cosine matrix; label (b,hw) int64.  The reference's (b,hw,hw) int64 affinity mask
 // (cam_helper.py:323-335) is evaluated on the fly: pos = same label, neg = different, ignored if either is
@@ -36,9 +62,7 @@ __global__ __launch_bounds__(256) void ptc_reduce_kernel(const float* __restrict
         if (kind == 1) { sp += v; np += 1.f; } else { sn += v; nn += 1.f; }
     }
     sp = block_sum(sp, red); np = block_sum(np, red); sn = block_sum(sn, red); nn = block_sum(nn, red);
-    if (threadIdx.x == 0) {
-        atomicAdd(&sums[0], sp); atomicAdd(&sums[1], np); atomicAdd(&sums[2], sn); atomicAdd(&sums[3], nn);
-    }
+    if (threadIdx.x == 0) loss_sums_commit(sums, sp, np, sn, nn, gridDim.x * gridDim.y);
 }
 
 // in place: cos_signed -> d loss / d cos_signed  (g = upstream scalar gradient gscale[0])
@@ -159,9 +183,7 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     }
     if (!BWD) {
         ce_bg = block_sum(ce_bg, red); n_bg = block_sum(n_bg, red); ce_fg = block_sum(ce_fg, red); n_fg = block_sum(n_fg, red);
-        if (threadIdx.x == 0 && (n_bg + n_fg) > 0.f) {
-            atomicAdd(&sums[0], ce_bg); atomicAdd(&sums[1], n_bg); atomicAdd(&sums[2], ce_fg); atomicAdd(&sums[3], n_fg);
-        }
+        if (threadIdx.x == 0) loss_sums_commit(sums, ce_bg, n_bg, ce_fg, n_fg, gridDim.x * gridDim.y * gridDim.z);
     } else {
         // d loss/d z_c = coef * (softmax_c - [c==lab]); scatter to the 4 low-res cells.  All lanes of a wave (4 rows x 16
         // px of the shifted tile) share the same 2x2 cells, so reduce over the wave first: 4*C1 atomics per wave.
@@ -480,10 +502,10 @@ extern "C" int dupl_seg_ce_map(const float* logits, const void* label, int32_t i
 
 extern "C" int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, const float* sums,
                                  const float* gscale, float* dlogits, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H,
-                                 int32_t W, int32_t flip, int32_t balanced, dupl_stream_t s) {
+                                 int32_t W, int32_t flip, int32_t balanced, int32_t deterministic, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!logits || !label || !sums || !gscale || !dlogits || b <= 0 || C1 <= 0 || H < h || W < w) return DUPL_ERR_ARG;
-    if (g_dupl_deterministic) {
+    if (deterministic) {
         int nthr = 256;                                        // <= 64 KB of dynamic LDS: [threads][C1 + 1] floats
         while (nthr > 64 && (size_t)nthr * (C1 + 1) * sizeof(float) > 64 * 1024) nthr >>= 1;
         if ((size_t)nthr * (C1 + 1) * sizeof(float) > 64 * 1024) return DUPL_ERR_ARG;

@@ -465,7 +465,7 @@ extern "C" int dupl_layernorm_bwd_blocks(int64_t rows, int32_t rows_per_wave) {
 extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                                   int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows,
-                                  int32_t rows_per_wave, float* dy_clear, dupl_stream_t s) {
+                                  int32_t rows_per_wave, float* dy_clear, int32_t deterministic, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256)
         return DUPL_ERR_ARG;
@@ -478,7 +478,7 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
     if (two_stage && partial_rows < 4 * (int64_t)grid) return DUPL_ERR_ARG;      // one partial row per wave
     // deterministic mode: the two-stage form with a single, fixed-order second stage; without a partials buffer the
     // separate column-walk pass (ln_dgb_det_kernel)
-    const bool det = g_dupl_deterministic && want_dgb && !two_stage;
+    const bool det = deterministic && want_dgb && !two_stage;
     float* dg_k = det ? nullptr : dgamma;
     float* db_k = det ? nullptr : dbeta;
 #define LN_BWD(MC) hipLaunchKernelGGL(layernorm_bwd_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
@@ -502,7 +502,7 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
 #undef LN_BWD
 #undef LN_BWD4
     if (two_stage) {
-        int gy = g_dupl_deterministic ? 1 : (grid + 63) / 64;
+        int gy = deterministic ? 1 : (grid + 63) / 64;
         if (gy > 16) gy = 16;
         hipLaunchKernelGGL(ln_dgb_reduce_kernel, dim3((2 * D + 63) / 64, gy), dim3(256), 0, (hipStream_t)s, partials, 4 * grid, D,
                            dgamma, dbeta);
@@ -516,14 +516,14 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
 }
 
 extern "C" int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int32_t ldx, int32_t accumulate,
-                           dupl_stream_t s) {
+                           int32_t deterministic, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !out || M <= 0 || N <= 0) return DUPL_ERR_ARG;
     if (!accumulate) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, out, 0.f, (long)N);
     long gy = (M + 63) / 64;       // 16 rows per thread-row-group pass: enough blocks to fill the chip on B*N ~ 3000 rows
     if (gy > 256) gy = 256;
     if (gy < 1) gy = 1;
-    if (g_dupl_deterministic) gy = 1;      // one block per 64 columns: a single, fixed-order addition per output
+    if (deterministic) gy = 1;      // one block per 64 columns: a single, fixed-order addition per output
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (int)gy), dim3(256), 0, (hipStream_t)s, x, out, (long)M, N, ldx);
     return dupl_launch_status();
 }

@@ -193,7 +193,7 @@ extern "C" int dupl_split_prepare(const dupl_split_desc* d, dupl_stream_t stream
     float* slot = d->slot;
     void *hi = d->hi, *lo = d->lo, *hiT = d->hiT, *loT = d->loT;
     if (amax_mode < 0 || amax_mode > 2 || (amax_mode && !slot)) return DUPL_ERR_ARG;
-    if (d->colsum_accum && g_dupl_deterministic) return DUPL_ERR_ARG;     // atomics: the caller uses dupl_colsum in that mode
+    if (d->colsum_accum && d->deterministic) return DUPL_ERR_ARG;     // atomics: the caller uses dupl_colsum in that mode
     if (!x || R <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C || (!hi && !hiT) || ((hi == nullptr) != (lo == nullptr)) ||
         ((hiT == nullptr) != (loT == nullptr)) || (hiT && (Rp < R || (Rp & 7))) || target_exp < 1 || target_exp > 15)
         return DUPL_ERR_ARG;

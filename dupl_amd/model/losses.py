@@ -28,7 +28,7 @@ class _PTC(torch.autograd.Function):
         cos = torch.empty((b, hw, hw), device=x.device, dtype=torch.float32)
         ops.gemm_raw(xh.data_ptr(), xh.data_ptr(), cos.data_ptr(), hw, hw, c, c, c, hw, batch=b, zdiv=1,
                      sA=(hw * c, 0), sB=(hw * c, 0), sC=(hw * hw, 0))
-        sums = ops.zeros((4,), x.device)
+        sums = ops.zeros((ops.LOSS_SUMS_FLOATS,), x.device)     # [0..3] results, rest = the order-independent reduction's state
         L().dupl_ptc_reduce(cos.data_ptr(), _p(label), _p(mask), ignore_index, sums.data_ptr(), b, hw, _stream())
         loss = 0.5 * (1 - sums[0] / (sums[1] + 1)) + 0.5 * sums[2] / (sums[3] + 1)
         ctx.save_for_backward(xh, nrm, cos, sums, label if label is not None else mask)
@@ -81,7 +81,7 @@ class _SegLoss(torch.autograd.Function):
         if not is_i64:
             label = label.float()
         label = label.contiguous()
-        sums = ops.zeros((4,), seg.device)
+        sums = ops.zeros((ops.LOSS_SUMS_FLOATS,), seg.device)
         L().dupl_seg_loss_fwd(logits.data_ptr(), label.data_ptr(), is_i64, ignore_index, sums.data_ptr(), b, C1, h, w, H, W,
                               int(flip), _stream())
         if balanced:
@@ -99,7 +99,7 @@ class _SegLoss(torch.autograd.Function):
         g = g.reshape(1).contiguous().float()
         dl = ops.zeros(tuple(logits.shape), logits.device)
         L().dupl_seg_loss_bwd(logits.data_ptr(), label.data_ptr(), is_i64, ignore_index, sums.data_ptr(), g.data_ptr(),
-                              dl.data_ptr(), b, C1, h, w, H, W, flip, balanced, _stream())
+                              dl.data_ptr(), b, C1, h, w, H, W, flip, balanced, int(ops.deterministic()), _stream())
         return ops.tokens_to_nchw(dl, b, h * w, C1, h, w, skip_cls=False), None, None, None, None, None, None
 
 

@@ -6,6 +6,7 @@ current torch stream.  Outputs are freshly allocated unless an `out=` is given.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -21,9 +22,17 @@ def L():
     return _lib.lib()
 
 
+# The caller-side determinism switch (dupl_amd.set_deterministic / DUPL_DETERMINISTIC=1).  The library keeps no mode (ABI 3): every
+# call that could accumulate with fp32 atomics is handed this value as its `deterministic` argument / descriptor field.
+_DETERMINISTIC = [os.environ.get("DUPL_DETERMINISTIC", "0") == "1"]
+
+
 def deterministic() -> bool:
-    """dupl_amd.set_deterministic state (held by the library): fused atomics paths check it."""
-    return bool(L().dupl_get_deterministic())
+    return _DETERMINISTIC[0]
+
+
+def set_deterministic(on) -> None:
+    _DETERMINISTIC[0] = bool(on)
 
 
 def _stream() -> int:
@@ -65,6 +74,7 @@ def gemm_raw(A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int,
     d.sX0, d.sX1 = sX
     d.sBias0, d.sBias1 = sBias
     d.alpha, d.flags = alpha, flags
+    d.deterministic = int(deterministic())
     d.tile_rows, d.tile_cols, d.group = GEMM32_TUNING["tile_rows"], GEMM32_TUNING["tile_cols"], GEMM32_TUNING["group"]
     L().dupl_gemm_f32(ctypes.byref(d), _stream())
 
@@ -242,6 +252,7 @@ def split_prepare(x: Tensor, scaled: bool, want_rm: bool, want_T: bool, rows_pad
     d.hiT, d.loT = (T.hi, T.lo) if T else (None, None)
     d.Rp, d.target_exp, d.colsum_accum, d.amax_mode = Rp, target_exp, _p(colsum_into), amax_mode
     d.fmt, d.rows_zero_to = int(fmt1), (rm_rows if (rm is not None and rm_rows > R) else 0)
+    d.deterministic = int(deterministic())
     L().dupl_split_prepare(ctypes.byref(d), _stream())
     if scaled:
         for o in (rm, T):
@@ -308,6 +319,7 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
         y = out if out is not None else torch.empty((c_rows or M, N), device=dev, dtype=torch.float32)
     y16 = out16 if out16 is not None else (split16_empty(M, N, dev, out_exp) if want16 else None)
     d = _lib.Gemm16Desc()
+    d.deterministic = int(deterministic())
     # operand format: both format 0, or both format 1 (then the product carries 2^(xe + we), taken out in the epilogue)
     xe, we = getattr(x, "exp", 0), getattr(W, "exp", 0)
     xf, wf = getattr(x, "fmt", int(xe > 0)), getattr(W, "fmt", int(we > 0))
@@ -366,6 +378,7 @@ def wgrad16_group(items):
         if isinstance(alpha, _Alpha):
             alpha.check()
         d = _lib.Gemm16Desc()
+        d.deterministic = int(deterministic())      # (whole tiles over all of K: the grouped form has no atomics in either mode)
         d.A_hi, d.A_lo, d.B_hi, d.B_lo = dy16.hi, dy16.lo, x16.hi, x16.lo
         d.C = out.data_ptr()
         d.M, d.N, d.K = dy16.cols, x16.cols, Kp
@@ -430,7 +443,7 @@ def linear_wgrad(dy: Tensor, x: Tensor, out: Tensor, accumulate: bool = False):
 
 def colsum(x: Tensor, out: Tensor, accumulate: bool = False):
     M, N = x.shape
-    L().dupl_colsum(x.data_ptr(), out.data_ptr(), M, N, x.stride(0), int(accumulate), _stream())
+    L().dupl_colsum(x.data_ptr(), out.data_ptr(), M, N, x.stride(0), int(accumulate), int(deterministic()), _stream())
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
@@ -484,7 +497,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     ws = getattr(dy, "_dupl_zero_ws", None)
     L().dupl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
                            dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, word, _p(part), nb, LNB_ROWS_PER_WAVE,
-                           dy.data_ptr() if ws is not None else None, _stream())
+                           dy.data_ptr() if ws is not None else None, int(deterministic()), _stream())
     if ws is not None:
         ws[1] = True            # clean again, in the order of the stream it belongs to
     if tok is not None:
@@ -770,6 +783,9 @@ def axpy_(y: Tensor, x: Tensor, a: float = 1.0):
 def scale_(y: Tensor, a: float):
     L().dupl_scale(y.data_ptr(), float(a), y.numel(), _stream())
     return y
+
+
+LOSS_SUMS_FLOATS = 16     # include/dupl_hip.h DUPL_LOSS_SUMS_FLOATS: the `sums` buffers of dupl_ptc_reduce / dupl_seg_loss_fwd
 
 
 def zeros(shape, device) -> Tensor:

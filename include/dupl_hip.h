@@ -23,14 +23,16 @@ extern "C" {
 typedef void* dupl_stream_t;
 
 /* library info: returns the ABI version (2: descriptors carry struct_size, tuning knobs travel in the descriptors, one entry point
- * per operation).  Infrastructure, no reference counterpart. */
+ * per operation; 3: the loss-sum buffers of dupl_ptc_reduce / dupl_seg_loss_fwd are DUPL_LOSS_SUMS_FLOATS floats, the determinism
+ * switch is per call -- see INTEGRATION.md).  Infrastructure, no reference counterpart. */
 int dupl_abi_version(void);
-/* on != 0: every accumulation that otherwise uses fp32 atomics (split-K weight gradients, LayerNorm dgamma / dbeta, bias
- * column sums, seg-loss backward scatter) runs in a fixed order, so that two identical steps give bit-identical gradients
- * (torch.use_deterministic_algorithms / cudnn.deterministic of train_final_voc.py:95-102).  Slower; default 0. */
-int dupl_set_deterministic(int32_t on);
-/* the current setting (1 / 0) */
-int dupl_get_deterministic(void);
+/* DETERMINISM is a per-call argument since ABI 3 (the library holds no mode: re-entrant per stream and per caller).  Every entry
+ * point that otherwise accumulates with fp32 atomics takes `deterministic` (a descriptor field or a trailing argument): != 0 =
+ * that accumulation runs in a fixed order, so that two identical steps give bit-identical gradients (torch.use_deterministic_
+ * algorithms / cudnn.deterministic of train_final_voc.py:95-102; slower).  These are: dupl_gemm_f32 / dupl_gemm_f16x3 (split-K
+ * and stream-K weight / data gradients), dupl_split_prepare (fused bias column sums: refused), dupl_layernorm_bwd (dgamma / dbeta),
+ * dupl_colsum, dupl_seg_loss_bwd (bilinear scatter).  The loss scalars (dupl_ptc_reduce, dupl_seg_loss_fwd) are order-independent
+ * in every mode.  dupl_amd.set_deterministic (Python) is the caller-side switch that fills the argument. */
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 in / fp32 accumulate / fp32 out.
@@ -40,6 +42,7 @@ int dupl_get_deterministic(void);
  * (vit.py:176-183), LargeFOV convs as im2col GEMMs (conv_head.py:32-41), the PTC Gram matrix
  * (losses.py:12) and every dgrad / wgrad autograd derives from them.
  * flags: */
+#define DUPL_LOSS_SUMS_FLOATS 16 /* size of the `sums` buffers of dupl_ptc_reduce / dupl_seg_loss_fwd (results in [0..3]) */
 #define DUPL_GEMM_A_MCONTIG 1   /* A stored [K][lda] (m contiguous) instead of [M][lda] (k contiguous) */
 #define DUPL_GEMM_B_NCONTIG 2   /* B stored [K][ldb] (n contiguous) instead of [N][ldb] (k contiguous) */
 #define DUPL_GEMM_GELU 4        /* v = gelu_erf(v) after bias */
@@ -65,6 +68,8 @@ typedef struct dupl_gemm_desc {
     int64_t sA0, sA1, sB0, sB1, sC0, sC1, sR0, sR1, sX0, sX1, sBias0, sBias1; /* element strides */
     float alpha;
     int32_t flags;
+    int32_t deterministic; /* != 0: no split-K (fp32 atomics): one block owns the whole reduction of its tile */
+    int32_t reserved0;
 } dupl_gemm_desc;
 /* the GEMM described above (vit.py:92-136, model_dupl.py:82-95, conv_head.py:32-41, losses.py:12 and their autograd) */
 int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
@@ -82,7 +87,7 @@ int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream);
 typedef struct dupl_gemm16_desc {
     uint32_t struct_size;                 /* sizeof(dupl_gemm16_desc) of the header the CALLER was built against: a mismatch is
                                              refused (DUPL_ERR_ARG) instead of reading fields the caller never wrote */
-    int32_t reserved0;
+    int32_t deterministic;                /* != 0: no split-K / stream-K (fp32 atomics) under DUPL_GEMM_ACCUM: one block per tile over all of K */
     const void* A_hi; const void* A_lo;   /* [M][lda] fp16   (a_layout 1: [K][lda], the M rows contiguous) */
     const void* B_hi; const void* B_lo;   /* [N][ldb] fp16   (b_layout 1: [K][ldb], the N rows contiguous) */
     float* C;                             /* [M][ldc] fp32 or NULL */
@@ -155,7 +160,8 @@ typedef struct dupl_split_desc {
     void* hi; void* lo; void* hiT; void* loT;
     int32_t Rp, target_exp;
     float* colsum_accum;
-    int32_t amax_mode, fmt, rows_zero_to, reserved0;
+    int32_t amax_mode, fmt, rows_zero_to;
+    int32_t deterministic;                /* != 0: colsum_accum (fp32 atomics) is refused -- the caller uses dupl_colsum(..., deterministic) */
 } dupl_split_desc;
 int dupl_split_prepare(const dupl_split_desc* d, dupl_stream_t stream);
 /* several UNSCALED matrices (saved activations, weights: the x^T / W^T operands of one transformer block's backward) in ONE
@@ -207,12 +213,12 @@ int dupl_layernorm_bwd_blocks(int64_t rows, int32_t rows_per_wave);   /* a count
 int dupl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                        int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows, int32_t rows_per_wave,
-                       float* dy_clear, dupl_stream_t s);
+                       float* dy_clear, int32_t deterministic, dupl_stream_t s);
 
 /* column sums: out[n] (+)= sum_m x[m][n]: the bias gradients autograd derives for nn.Linear (vit.py:92-102,115-122)
  * and the patch-embed conv (vit.py:176-183).  accumulate!=0 adds to out (atomic). */
 int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int32_t ldx, int32_t accumulate,
-                dupl_stream_t s);
+                int32_t deterministic, dupl_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused multi-head self-attention core (flash style, exact-fp32 MFMA, online softmax).
@@ -324,7 +330,9 @@ int dupl_refine_merge(const float* lab_h, const float* lab_l, float* out, float 
  * cos (b,hw,hw) = SIGNED xhat^T xhat from dupl_gemm_f32; pairs are classified from label (b,hw) int64, or -- the
  * reference API get_masked_ptc_loss(inputs, mask) -- from an explicit mask (b,hw,hw) int64 (1 pos / 0 neg / else ignored)
  * when mask != NULL.
- * sums[4] += {sum_pos |cos|, n_pos, sum_neg |cos|, n_neg} (zero first). */
+ * sums: DUPL_LOSS_SUMS_FLOATS (16) floats, zero-filled by the caller; after the launch sums[0..3] = {sum_pos |cos|, n_pos,
+ * sum_neg |cos|, n_neg}.  The rest is the reduction's own state (ABI 3): the blocks accumulate in 64-bit fixed point, so the
+ * four results do not depend on the order the blocks retire in -- bit-reproducible in every mode. */
 int dupl_ptc_reduce(const float* cos, const int64_t* label, const int64_t* mask, int32_t ignore_index, float* sums,
                     int32_t b, int32_t hw, dupl_stream_t s);
 /* backward of get_masked_ptc_loss (autograd of losses.py:6-21), in place: cos_signed -> d loss/d cos_signed = sign(cos) * (pos ? -0.5*g/(n_pos+1) : neg ? 0.5*g/(n_neg+1) : 0), g = gscale[0] */
@@ -340,7 +348,8 @@ int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const float* nor
                          dupl_stream_t s);
 /* fused bilinear upsample (align_corners False) + CE, bg/fg balanced (get_seg_loss, losses.py:24-39 on
  * F.interpolate(segs, (H,W)), train_final_voc.py:345-352).  logits token-major [b][h*w][C1]; label (b,H,W) float32
- * or int64 (is_i64).  sums[4] += {ce_bg, n_bg, ce_fg, n_fg} (zero first). */
+ * or int64 (is_i64).  sums: DUPL_LOSS_SUMS_FLOATS zero-filled floats, sums[0..3] = {ce_bg, n_bg, ce_fg, n_fg} after the
+ * launch (order-independent fixed-point reduction, see dupl_ptc_reduce). */
 int dupl_seg_loss_fwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* sums,
                       int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip, dupl_stream_t s);
 /* same fused upsample + CE, but the per-pixel value ce_map (b,H,W) (0 where label == ignore): the detached
@@ -378,7 +387,7 @@ int dupl_mask_fill(float* label, const uint8_t* mask, float value, int64_t n, du
  * valid pixels (sum CE / count: the consistency loss, train_final_voc.py:430-434). */
 int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, const float* sums,
                       const float* gscale, float* dlogits, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W,
-                      int32_t flip, int32_t balanced, dupl_stream_t s);
+                      int32_t flip, int32_t balanced, int32_t deterministic, dupl_stream_t s);
 /* nn.CosineSimilarity(dim=-1) over the n tokens of every (image, channel) (train_final_voc.py:247-254); a, b
  * token-major (element (i, t, c) at + i*img_stride + t*ld + c).  out [B][c]; stats [B][c][3] = {dot, |a|^2, |b|^2}. */
 int dupl_cos_sim_fwd(const float* a, const float* b, float* out, float* stats, int32_t B, int32_t n, int32_t c,

@@ -20,7 +20,7 @@
 static float frand(unsigned* s) { *s = *s * 1664525u + 1013904223u; return ((*s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
 
 int main(void) {
-    if (dupl_abi_version() != 2) return 1;
+    if (dupl_abi_version() != 3) return 1;
     const int M = 197, N = 96, K = 72;
     unsigned seed = 7;
     float *hA = malloc(sizeof(float) * M * K), *hB = malloc(sizeof(float) * N * K), *hb = malloc(sizeof(float) * N);
@@ -48,7 +48,7 @@ int main(void) {
     d.batch = 1; d.zdiv = 1; d.alpha = 1.0f; d.flags = DUPL_GEMM_RELU;
     OK(dupl_gemm_f32(&d, st));
     OK(dupl_layernorm_fwd(dC, dg, dbeta, dY, NULL, NULL, M, N, 1e-6f, st));
-    OK(dupl_colsum(dC, dS, M, N, N, 0, st));
+    OK(dupl_colsum(dC, dS, M, N, N, 0, 0, st));
     if (dupl_gemm_f32(NULL, st) != -1) return 4;          /* bad argument -> -1, no launch */
     CHECK(hipStreamSynchronize(st));
     CHECK(hipMemcpy(hC, dC, sizeof(float) * M * N, hipMemcpyDeviceToHost));
