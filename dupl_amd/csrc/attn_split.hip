@@ -262,9 +262,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
         // 2^8 (wave-uniform decision).  exp2(s - m) with a stale m is the same softmax -- numerator, denominator and lse use the one
         // constant -- and P <= 256 keeps the fp16 hi / lo split as accurate as P <= 1; what it saves is the rescaling of the 64
         // accumulators, which otherwise runs whenever any of 32 maxima moves at all (most tiles).
+        // (mx is the maximum of the MAIN products: the cross terms add <= 2^-10 |s| to a score in the exponent domain, so the bound is
+        // P <= 2^(8 + 2^-10 max|s c1|) -- 2^8.1 for a score of 100 in that domain, far inside fp16's range either way.)
         const float m_cand = fmaxf(m_run, mx);
         const bool move = __builtin_amdgcn_ballot_w64(m_cand - m_run > 8.f) != 0;       // -inf start: inf > 8
-        const float m_new = move ? m_cand : m_run;
+        const float m_run2 = move ? m_cand : m_run;
+        // a query that has seen only masked keys so far (m_run2 = -inf: cannot happen while every tile holds a key < N, which N >= 1
+        // guarantees today -- ADVICE r4: a future masked / variable-length caller must not meet inf - inf) subtracts 0: its scores
+        // are -inf, its probabilities exp2(-inf) = 0, alpha = exp2(-inf - 0) = 0 on accumulators that are still 0
+        const float m_new = m_run2 == -INFINITY ? 0.f : m_run2;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                     // exactly 1 when the maximum stays
         f32x2 psum2 = {0.f, 0.f};
         h8 ph[4], pl[4];
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { oM[d][e] *= alpha; oX[d][e] *= alpha; }
         }
-        m_run = m_new;
+        m_run = m_run2;
         if (ATT_ABL & 16) { asm volatile("" ::"v"(ph[0]), "v"(ph[3]), "v"(pl[0]), "v"(pl[3]), "v"(oM[0]), "v"(oX[1])); }
         ATT_STAMP(2)
         // ---- O^T += V^T P^T, same read-ahead and accumulator rotation

@@ -211,6 +211,9 @@ class FlatStorage:
 
     def plane_pointers(self, offset: int, seg: int):
         """(hi pointer, lo pointer, plane exponent) of the planes at flat parameter `offset`, which lies in segment `seg`."""
+        lo, hi = self.seg_bounds[seg]
+        assert lo <= offset % self.student_numel < max(hi, lo + 1), \
+            f"offset {offset} is not inside segment {seg}: the optimiser's ranges must be the plane-format ranges of ensure_w16"
         return (self.data16.data_ptr() + 2 * offset, self.data16.data_ptr() + 2 * (self.data.numel() + offset),
                 ops.EXP_W if (FMT1 and seg == SEG_BACKBONE) else 0)
 

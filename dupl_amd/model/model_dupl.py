@@ -414,6 +414,10 @@ class siamese_network(nn.Module):
             self._store.streams = list(_STREAM_PAIRS[dev])
         if not on:
             self._store.streams = []
+            # the CU-mask experiment (DUPL_CU_MASK) sizes the persistent grids for its masks: a single-stream model (a validation
+            # pass, a second model of the process) must not inherit that
+            from .. import ops as _ops
+            _ops.GEMM16_TUNING["persist_blocks"] = int(os.environ.get("DUPL_PERSIST_BLOCKS", 0))
         # the split GEMM picks its tile for the number of launches that share the chip (dupl_gemm16_desc.concurrency, a per-call
         # field: ops.GEMM16_TUNING is this Python caller's default for it)
         from .. import ops

@@ -495,34 +495,56 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
         nb = L().dupl_layernorm_bwd_blocks(rows, LNB_ROWS_PER_WAVE)
         part = torch.empty((nb, 2 * D), device=x.device, dtype=torch.float32)
     ws = getattr(dy, "_dupl_zero_ws", None)
+    if ws is not None:
+        assert ws.stream == _stream() and ws.dirty == dy.numel(), "a zero_workspace view is produced and consumed on its own stream"
     L().dupl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
                            dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, word, _p(part), nb, LNB_ROWS_PER_WAVE,
                            dy.data_ptr() if ws is not None else None, int(deterministic()), _stream())
     if ws is not None:
-        ws[1] = True            # clean again, in the order of the stream it belongs to
+        ws.dirty = 0            # clean again, in the order of the stream it belongs to
     if tok is not None:
         dx._dupl_amax = tok
     return dx
 
 
-_ZERO_WS = {}
+_ZERO_WS = {}              # (device index, raw stream handle) -> _ZeroWs; at most _ZERO_WS_MAX entries (least recently used out)
+_ZERO_WS_MAX = 8
+
+
+class _ZeroWs:
+    """One zero-filled fp32 arena per (device, stream): `buf` holds the largest rows * cols asked for so far, callers get a
+    contiguous prefix view.  `clean_upto`: the prefix [0, clean_upto) IS zero in the order of the owning stream; a user dirties
+    its view, the consumer that reads it last (layernorm_bwd: its kernel writes zeros behind its reads) cleans exactly that view."""
+    __slots__ = ("buf", "dirty", "stream")
+
+    def __init__(self, n, device, stream):
+        self.buf = torch.zeros(n, device=device, dtype=torch.float32)
+        self.dirty = 0          # elements [0, dirty) may be non-zero
+        self.stream = stream
 
 
 def zero_workspace(rows: int, cols: int, device) -> Tensor:
-    """A [rows, cols] fp32 tensor that IS zero in the order of the current stream: one buffer per (stream, shape), handed out
+    """A [rows, cols] fp32 tensor that IS zero in the order of the current stream: a prefix view of the stream's arena (one
+    buffer per stream, sized to the largest request; ADVICE r4: no buffer per shape, and the cache is bounded), handed out
     clean, dirtied by its user (a stream-K data gradient accumulates into it) and cleaned again by the consumer that reads it
-    last -- layernorm_bwd recognises it and has its kernel write zeros behind its reads.  If the previous user never reached
-    that consumer (another path, an exception), the buffer is still marked dirty and gets an explicit fill."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, rows, cols)
-    ws = _ZERO_WS.get(key)
-    if ws is None:
-        ws = _ZERO_WS[key] = [torch.zeros((rows, cols), device=device, dtype=torch.float32), True]
-    buf = ws[0]
-    if not ws[1]:
-        buf.zero_()
-    ws[1] = False
-    buf._dupl_zero_ws = ws
-    return buf
+    last -- layernorm_bwd recognises the view and has its kernel write zeros behind its reads.  If the previous user never
+    reached that consumer (another path, an exception), the arena is still marked dirty and gets an explicit fill.
+    Every producer and consumer of the view must run on the stream it was requested on (asserted by layernorm_bwd)."""
+    stream = torch.cuda.current_stream(device).cuda_stream
+    key = (device.index, stream)
+    n = rows * cols
+    ws = _ZERO_WS.pop(key, None)
+    if ws is None or ws.buf.numel() < n:
+        ws = _ZeroWs(n, device, stream)          # (the old arena, if any, is released when its last view dies)
+    _ZERO_WS[key] = ws                            # most recently used last
+    while len(_ZERO_WS) > _ZERO_WS_MAX:
+        _ZERO_WS.pop(next(iter(_ZERO_WS)))
+    if ws.dirty:
+        fill_(ws.buf[:ws.dirty], 0.0)
+    ws.dirty = n
+    view = ws.buf[:n].view(rows, cols)
+    view._dupl_zero_ws = ws
+    return view
 
 
 # ------------------------------------------------------------------------------------------ attention

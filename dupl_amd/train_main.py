@@ -160,15 +160,53 @@ def setup_seed(seed):
     random.seed(seed)
 
 
+_RESUME_FILES = ("optimizer.pth", "checkpoint.pth", "checkpoint.n_iter")
+
+
+def _prev(name):
+    stem, ext = os.path.splitext(name)
+    return f"{stem}.prev{ext}"
+
+
+def _read_generation(resume_dir, prev=False):
+    """(optimiser payload, n_iter) of the current (or previous) generation if it is COMPLETE -- its iteration tag, written last, equals
+    the n_iter inside its optimizer file, written first -- else (None, reason)."""
+    opt, ck, tag = (os.path.join(resume_dir, _prev(n) if prev else n) for n in _RESUME_FILES)
+    if not (os.path.exists(opt) and os.path.exists(ck)):
+        return None, "files missing"
+    ost = torch.load(opt, map_location="cpu")
+    if not os.path.exists(tag):
+        return None, f"no iteration tag (a save was interrupted after its optimizer file reached n_iter {int(ost['n_iter'])})"
+    with open(tag) as f:
+        saved_at = int(f.read().strip())
+    if saved_at != int(ost["n_iter"]):
+        return None, (f"the last completed save was at n_iter {saved_at} but the optimizer file is from n_iter {int(ost['n_iter'])}: a later "
+                      "save was interrupted after replacing it, the weights file is from one of the two")
+    return ost, saved_at
+
+
 def _save_resume_state(ckpt_dir, wrapped, model, optim, n_iter):
     """checkpoint.pth (keys prefixed `module.`, train_final_voc.py:519) + optimizer.pth + checkpoint.n_iter, each written to a
     temporary file and renamed into place, in THIS order: optimizer.pth (it carries n_iter) first, then checkpoint.pth, then the
-    iteration tag.  A job killed between any two renames leaves a tag that differs from optimizer.pth's n_iter, which
-    `_load_resume_state` refuses: after the first rename the optimiser is new and the weights old (mixed), after the second
-    both are new but the tag is not (consistent, refused all the same: the tag cannot tell the two apart).  Only a save that
-    ran to its end, or one that never renamed anything, resumes."""
+    iteration tag -- a job killed between any two renames leaves a tag that differs from optimizer.pth's n_iter, which
+    `_load_resume_state` recognises as an incomplete generation.  So that one complete generation ALWAYS exists (an
+    interrupted save used to leave a directory that could not be resumed at all), the current generation -- if complete -- is
+    first kept as *.prev (hard links: no copy; its tag linked last), and the loader falls back to it."""
     os.makedirs(ckpt_dir, exist_ok=True)
     sd = wrapped.state_dict() if wrapped is not None else {"module." + k: v for k, v in model.state_dict().items()}
+
+    if _read_generation(ckpt_dir)[0] is not None:
+        for name in _RESUME_FILES:                       # tag last: an interrupted rotation leaves an incomplete .prev, never a mixed one
+            dst = os.path.join(ckpt_dir, _prev(name))
+            if os.path.exists(dst):
+                os.remove(dst)
+        for name in _RESUME_FILES:
+            src, dst = os.path.join(ckpt_dir, name), os.path.join(ckpt_dir, _prev(name))
+            try:
+                os.link(src, dst)
+            except OSError:                              # a filesystem without hard links
+                import shutil
+                shutil.copy2(src, dst)
 
     def put(obj, name):
         tmp = os.path.join(ckpt_dir, name + ".tmp")
@@ -184,21 +222,20 @@ def _save_resume_state(ckpt_dir, wrapped, model, optim, n_iter):
 
 
 def _load_resume_state(resume_dir):
-    """(model state_dict without `module.`, optimiser state, n_iter) of a directory written by _save_resume_state; raises if
-    the iteration tag (written last) is missing or differs from optimizer.pth's n_iter (written first): some rename of the
-    last save did not happen, so checkpoint.pth may be older than optimizer.pth."""
-    ost = torch.load(os.path.join(resume_dir, "optimizer.pth"), map_location="cpu")
-    tag = os.path.join(resume_dir, "checkpoint.n_iter")
-    if not os.path.exists(tag):
-        raise RuntimeError(f"{resume_dir}: no checkpoint.n_iter tag (the first save of this run was interrupted after "
-                           f"optimizer.pth reached n_iter {int(ost['n_iter'])}): refusing to resume")
-    with open(tag) as f:
-        saved_at = int(f.read().strip())
-    if saved_at != int(ost["n_iter"]):
-        raise RuntimeError(f"{resume_dir}: the last COMPLETED save was at n_iter {saved_at}, but optimizer.pth is from n_iter "
-                           f"{int(ost['n_iter'])}: a later save was interrupted after it replaced optimizer.pth, and "
-                           "checkpoint.pth is from one of the two -- refusing to resume from possibly mixed state")
-    ck = torch.load(os.path.join(resume_dir, "checkpoint.pth"), map_location="cpu")
+    """(model state_dict without `module.`, optimiser state, n_iter) of a directory written by _save_resume_state: the current
+    generation if it is complete, else the previous one (*.prev, kept by every save), else an error naming what is inconsistent --
+    never a possibly mixed pair of files."""
+    ost, n = _read_generation(resume_dir)
+    prev = False
+    if ost is None:
+        why = n
+        ost, n = _read_generation(resume_dir, prev=True)
+        if ost is None:
+            raise RuntimeError(f"{resume_dir}: {why}; no complete previous generation either ({n}) -- refusing to resume from "
+                               "possibly mixed state")
+        prev = True
+        print(f"[resume] {resume_dir}: the last save is incomplete ({why}); resuming from the previous complete one at n_iter {n}")
+    ck = torch.load(os.path.join(resume_dir, _prev("checkpoint.pth") if prev else "checkpoint.pth"), map_location="cpu")
     sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ck.items()}
     return sd, ost["optimizer"], int(ost["n_iter"])
 

@@ -208,6 +208,8 @@ def train_step(model, optim, par, inputs, cls_label, img_box, n_iter: int, args:
     """zero_grad -> losses -> backward -> optimiser step (train_final_voc.py:470-472)."""
     optim.zero_grad()
     loss, out = compute_losses(model, par, inputs, cls_label, img_box, n_iter, args, cls_label_host, inputs_aug)
+    if hasattr(optim, "begin_step"):
+        optim.begin_step(model)       # world 1: the update of each gradient range is issued as the backward pass finalises it
     loss.sum().backward()
     optim.step()
     return out

@@ -10,8 +10,13 @@ import math
 
 import torch
 
+import os
+
 from .. import ops
-from ..engine import FlatStorage
+from ..engine import FlatStorage, SEG_BACKBONE
+
+# the AdamW launches of a step ride in its backward pass (PolyWarmupAdamW.begin_step; world 1): DUPL_ADAMW_IN_BWD=0 = all in step()
+ADAMW_IN_BACKWARD = os.environ.get("DUPL_ADAMW_IN_BWD", "1") != "0"
 
 
 def adamw_segment(p, g, m, v, step, lr, beta1, beta2, eps, wd, planes=None):
@@ -65,6 +70,73 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
                         break
         return self
 
+    # ---- the update rides in the backward pass (world 1) -----------------------------------------------------------------
+    def begin_step(self, model) -> bool:
+        """Call between the forward and loss.backward() of a step (trainer.train_step does): from then on each piece of a student's
+        gradient range is updated AS SOON AS the backward pass reports it final (network_backward's on_ready events: the heads, then
+        the transformer blocks two at a time), on that student's stream -- so the HBM-bound AdamW launches run under the other
+        student's MFMA-bound backward instead of alone on the chip after it (1.1 ms of a 52 ms step).  step() then updates what is
+        left (the stem, the LayerNorm segment) and does the bookkeeping.  The result is bit-identical to a plain step(): the same
+        element-wise kernel with the same scalars over a partition of the same ranges.
+        Not armed (returns False; step() does everything) under a gradient exchange: a rank's gradient is only final after the
+        all-reduce (ddp.GradReducer), and when DUPL_ADAMW_IN_BWD=0."""
+        self._armed = None
+        if not ADAMW_IN_BACKWARD or self._flat is None:
+            return False
+        core = model.module if hasattr(model, "module") else model
+        if core is not model and getattr(getattr(model, "reducer", None), "world", 1) > 1:
+            return False
+        store = self._flat[0]
+        nets = [core.branch1, core.branch2] if hasattr(core, "branch1") else [core]
+        if getattr(core, "flat_storage", getattr(core, "_store", None)) is not store:
+            return False
+        for net in nets:
+            if self._on_grad_ready not in net._grad_ready_hooks:
+                net._grad_ready_hooks.append(self._on_grad_ready)
+        self._set_schedule_lr()
+        self._armed = {"with_planes": [store.planes_current(s) for s in range(store.n_students)],
+                       "done": [[] for _ in range(store.n_students)],            # (lo, hi) flat ranges already updated this step
+                       "stepped": [set() for _ in range(store.n_students)],      # segments whose step count was advanced
+                       "plan": [store.grad_buckets(s) for s in range(store.n_students)]}
+        return True
+
+    def _update_range(self, s: int, lo: int, hi: int):
+        """AdamW over the flat range [lo, hi) of student s (absolute offsets), segment by segment, on the current stream."""
+        store, m, v, steps = self._flat
+        arm = self._armed
+        base = s * store.student_numel
+        for seg in range(1, 5):
+            if seg not in self._seg_group or not store.seg_has_grad[s][seg]:
+                continue
+            slo, shi = store.seg_bounds[seg]
+            a, b = max(lo, base + slo), min(hi, base + shi)
+            if b <= a:
+                continue
+            if seg not in arm["stepped"][s]:
+                arm["stepped"][s].add(seg)
+                steps[s][seg] += 1
+            grp = self.param_groups[self._seg_group[seg]]
+            b1, b2 = grp["betas"]
+            sl = slice(a, b)
+            adamw_segment(store.data[sl], store.grad[sl], m[sl], v[sl], steps[s][seg], grp["lr"], b1, b2, grp["eps"],
+                          grp["weight_decay"], planes=store.plane_pointers(a, seg) if arm["with_planes"][s] else None)
+            arm["done"][s].append((a, b))
+
+    def _on_grad_ready(self, net, event):
+        """network_backward's on_ready (last pending backward of this student, on its stream): update the buckets `event` finalises.
+        The stem / LayerNorm buckets wait for step(): SEG_BACKBONE / SEG_NORM are marked as having gradients at the very end."""
+        arm = getattr(self, "_armed", None)
+        if arm is None or event == "stem":
+            return
+        store = self._flat[0]
+        s = net._student
+        if event != "heads":
+            store.seg_has_grad[s][SEG_BACKBONE] = True     # a transformer block was back-propagated (P.mark_grad comes at the end)
+        with torch.no_grad():
+            for lo, hi, trig in arm["plan"][s]:
+                if trig == event:
+                    self._update_range(s, lo, hi)
+
     def zero_grad(self, set_to_none: bool = False):
         if self._flat is not None:
             self._flat[0].wait_streams()
@@ -72,8 +144,7 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
         else:
             super().zero_grad(set_to_none=False)
 
-    @torch.no_grad()
-    def step(self, closure=None):
+    def _set_schedule_lr(self):
         # schedule (optimizer.py:51-63)
         if self.global_step < self.warmup_iter:
             lr_mult = 1 - (1 - self.global_step / self.warmup_iter) * (1 - self.warmup_ratio)
@@ -83,6 +154,10 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
             lr_mult = (1 - self.global_step / self.max_iter) ** self.power
             for i in range(len(self.param_groups)):
                 self.param_groups[i]["lr"] = self.__init_lr[i] * lr_mult
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._set_schedule_lr()
         if self._flat is None:
             raise RuntimeError("PolyWarmupAdamW.bind(model.flat_storage) must be called once: dupl_amd updates the flat "
                                "parameter buffer with fused HIP launches (no per-tensor fallback)")
@@ -90,9 +165,12 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
         store.wait_streams()     # the students' backward passes may still be running on their own streams
         # a student whose operand planes are current gets them rewritten by the update itself (no split pass over the weights
         # before the next forward); segments without gradients keep their values, hence their planes
-        with_planes = [store.planes_current(s) for s in range(store.n_students)]
+        arm = getattr(self, "_armed", None)
+        self._armed = None
+        with_planes = arm["with_planes"] if arm is not None else [store.planes_current(s) for s in range(store.n_students)]
         for s in range(store.n_students):
             base = s * store.student_numel
+            done = sorted(arm["done"][s]) if arm is not None else []
             for seg in range(1, 5):
                 if not store.seg_has_grad[s][seg] or seg not in self._seg_group:
                     continue
@@ -100,11 +178,23 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
                 lo, hi = store.seg_bounds[seg]
                 if hi <= lo:
                     continue
-                steps[s][seg] += 1
+                if arm is None or seg not in arm["stepped"][s]:
+                    steps[s][seg] += 1
                 b1, b2 = grp["betas"]
-                sl = slice(base + lo, base + hi)
-                adamw_segment(store.data[sl], store.grad[sl], m[sl], v[sl], steps[s][seg], grp["lr"], b1, b2, grp["eps"],
-                              grp["weight_decay"], planes=store.plane_pointers(base + lo, seg) if with_planes[s] else None)
+                # what the backward pass has not updated already (begin_step): the gaps of `done` inside this segment
+                cur, rest = base + lo, []
+                for a_, b_ in done:
+                    if b_ <= cur or a_ >= base + hi:
+                        continue
+                    if a_ > cur:
+                        rest.append((cur, a_))
+                    cur = max(cur, b_)
+                if cur < base + hi:
+                    rest.append((cur, base + hi))
+                for a_, b_ in rest:
+                    sl = slice(a_, b_)
+                    adamw_segment(store.data[sl], store.grad[sl], m[sl], v[sl], steps[s][seg], grp["lr"], b1, b2, grp["eps"],
+                                  grp["weight_decay"], planes=store.plane_pointers(a_, seg) if with_planes[s] else None)
         store.mark_dirty()       # parameters were rewritten through raw pointers: f16x3 operand planes not written above are stale
         for s in range(store.n_students):
             if with_planes[s]:

@@ -1172,3 +1172,52 @@ def test_adamw_planes_give_the_same_training_run(dev):
     assert torch.equal(la, lb), (la, lb)
     assert torch.equal(pa, pb)
     assert torch.equal(qa, qb), "planes written by the optimiser differ from a split of the same parameters"
+
+
+def test_adamw_in_backward_is_bit_identical_to_a_plain_step(dev):
+    """PolyWarmupAdamW.begin_step (round 5): the update of every gradient range is launched from inside the backward pass as soon
+    as the range is final (heads, then the transformer blocks two at a time), on its student's stream, and step() only does the
+    rest.  Four steps of the tiny dual model across the phase A -> B border (the decoder gets its first gradient -- and its own
+    bias-correction count -- at step 2) in deterministic mode: parameters, both moments, operand planes, per-segment step counts
+    and losses are BIT-identical to the same run with every update in step()."""
+    from dupl_amd import trainer, ops
+    from dupl_amd.utils import optimizer as OPT
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd.synthetic import synthetic_batch
+
+    def run(in_backward):
+        prev = OPT.ADAMW_IN_BACKWARD
+        OPT.ADAMW_IN_BACKWARD = in_backward
+        ops.set_deterministic(1)
+        try:
+            torch.manual_seed(0)
+            model = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+            groups = model.get_param_groups()
+            model.to(dev)
+            model.enable_dual_stream(True)
+            optim = OPT.PolyWarmupAdamW(params=[{"params": groups[i], "lr": 6e-4 * (1 if i < 2 else 10), "weight_decay": 1e-2}
+                                                for i in range(4)], lr=6e-4, weight_decay=1e-2, betas=(0.9, 0.999), warmup_iter=2,
+                                        max_iter=40, warmup_ratio=1e-6, power=0.9).bind(model.flat_storage)
+            par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+            sargs = trainer.StepArgs(cam_iters=2, gmm_iters=30, max_iters=40)
+            losses, armed = [], []
+            for it in range(4):
+                inputs, cls_label, img_box = synthetic_batch(2, 20, 128, seed=it)
+                out = trainer.train_step(model, optim, par, inputs.to(dev), cls_label.to(dev), img_box, it, sargs, cls_label_host=cls_label)
+                losses.append(out["loss"].detach().reshape(-1)[0].clone())
+            st = model.flat_storage
+            fresh = all(st._planes_fresh.get(s) == st._param_key() for s in range(st.n_students))
+            for s in range(st.n_students):
+                st.ensure_w16(s)
+            torch.cuda.synchronize()
+            _, m, v, steps = optim._flat
+            return torch.stack(losses), st.data.clone(), st.data16.clone(), m.clone(), v.clone(), [list(r) for r in steps], fresh
+        finally:
+            OPT.ADAMW_IN_BACKWARD = prev
+            ops.set_deterministic(0)
+    a, b = run(True), run(False)
+    assert a[5] == b[5] and a[5][0][4] == 2, a[5]          # the decoder segment has had 2 updates (steps 2 and 3), the rest 4
+    assert a[6] and b[6], "the planes after the last step are the optimiser's in both forms"
+    for name, x, y in zip(("losses", "parameters", "planes", "exp_avg", "exp_avg_sq"), a[:5], b[:5]):
+        assert torch.equal(x, y), name

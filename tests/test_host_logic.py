@@ -273,9 +273,12 @@ def test_command_line_flags_match_the_reference(golden_dir):
     assert n >= 95
 
 
-def test_interrupted_resume_save_is_refused(tmp_path, monkeypatch):
-    """a job killed between any two renames of _save_resume_state must not resume from mixed state.  The save is
-    cut after 0 .. 3 of its three os.replace calls; only the uncut save (3) and the one that renamed nothing (0) resume."""
+def test_interrupted_resume_save_falls_back_to_the_previous_generation(tmp_path, monkeypatch):
+    """ADVICE r3 + r4: a job killed between any two renames of _save_resume_state must never resume from mixed state -- and must
+    still be resumable.  The save at n_iter 200 is cut after 0 .. 3 of its three os.replace calls: the uncut save (3) resumes at 200;
+    every cut one resumes from the last COMPLETE generation, 100 (cut 0: nothing was renamed, the current files are still it; cut
+    1 / 2: optimizer.pth -- and checkpoint.pth -- are already new, the tag is not: the loader takes the *.prev generation every
+    save keeps).  With neither generation complete the loader refuses."""
     from dupl_amd import train_main as TM
 
     class Obj:
@@ -305,17 +308,27 @@ def test_interrupted_resume_save_is_refused(tmp_path, monkeypatch):
         except KeyboardInterrupt:
             pass
         monkeypatch.setattr(TM.os, "replace", real)
-        if cut in (1, 2):
-            with pytest.raises(RuntimeError, match="refusing to resume"):
-                TM._load_resume_state(d)
-        else:
-            sd, opt, at = TM._load_resume_state(d)
-            want = (100, 1, 10) if cut == 0 else (200, 2, 20)
-            assert (at, float(sd["w"][0]), float(opt["w"][0])) == want
-        # restore a clean state at 100 for the next cut
+        sd, opt, at = TM._load_resume_state(d)
+        want = (200, 2, 20) if cut == 3 else (100, 1, 10)
+        assert (at, float(sd["w"][0]), float(opt["w"][0])) == want, cut
+        # restore a clean state at 100 for the next cut (its own .prev is then whatever complete generation was current)
         TM._save_resume_state(d, None, Obj(1), Obj(10), 100)
+    # a THIRD save interrupted while the second one's generation is the .prev: still resumable, from the second
+    TM._save_resume_state(d, None, Obj(3), Obj(30), 300)
+    monkeypatch.setattr(TM.os, "replace", lambda a, b, _n={"k": 0}: (_n.__setitem__("k", _n["k"] + 1), real(a, b))[1] if _n["k"] < 1
+                        else (_ for _ in ()).throw(KeyboardInterrupt("killed")))
+    try:
+        TM._save_resume_state(d, None, Obj(4), Obj(40), 400)
+    except KeyboardInterrupt:
+        pass
+    monkeypatch.setattr(TM.os, "replace", real)
+    sd, opt, at = TM._load_resume_state(d)
+    assert (at, float(sd["w"][0]), float(opt["w"][0])) == (300, 3, 30)
+    # neither generation complete -> refused, never a mixed pair
     os.remove(os.path.join(d, "checkpoint.n_iter"))
-    with pytest.raises(RuntimeError, match="no checkpoint.n_iter"):
+    os.remove(os.path.join(d, "checkpoint.n_iter.prev")) if os.path.exists(os.path.join(d, "checkpoint.n_iter.prev")) else None
+    os.remove(os.path.join(d, "checkpoint.prev.n_iter")) if os.path.exists(os.path.join(d, "checkpoint.prev.n_iter")) else None
+    with pytest.raises(RuntimeError, match="refusing to resume"):
         TM._load_resume_state(d)
 
 
