@@ -52,6 +52,7 @@ class Gemm16Desc(ctypes.Structure):
         ("amax_out", ctypes.c_void_p),
         ("a_layout", ctypes.c_int32), ("b_layout", ctypes.c_int32), ("ka_valid", ctypes.c_int32), ("kb_valid", ctypes.c_int32),
         ("tile", ctypes.c_int32), ("concurrency", ctypes.c_int32), ("persist_blocks", ctypes.c_int32), ("group", ctypes.c_int32),
+        ("sk_slices", ctypes.c_int32), ("reserved1", ctypes.c_int32),
     ]
 
     def __init__(self, *a, **kw):

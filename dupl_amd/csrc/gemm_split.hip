@@ -1387,6 +1387,28 @@ __device__ __forceinline__ void gemm_f16x3_km_body(const dupl_gemm16_desc& p, co
     int m0, n0;
     if constexpr (SK) {
         const int T = nblk * ntf, G = grid;
+        if (p.sk_slices > 0) {
+            // ALIGNED k-slices (round 5): the k axis of every tile is cut into S = sk_slices equal slices and a block takes ONE (tile,
+            // slice) unit; units are numbered slice-major and dealt to the XCDs in contiguous runs, so the ~G / 8 blocks of an XCD
+            // work on neighbouring tiles OVER THE SAME k-RANGE at the same time: the A rows of a row band and the B columns of the
+            // slice are fetched into that XCD's L2 once and shared.  The equal-run cut below gives every block its own k-range
+            // (run l starts at k = 29.25 l mod 96 for fc1's data gradient): nothing is shared, 256 blocks x 1.4 MB = 365 MB come over
+            // the fabric for 58 MB of operands (profiles/r04_final_pmc_hbm.txt: 380 MB per launch, 4.9 TB/s -- the kernel was bound by
+            // that, not by its MFMAs).
+            const int S = p.sk_slices, U = nblk * S;
+            const int xcd = bid & 7, idx = bid >> 3;
+            const int ulo = (int)((long)U * xcd / 8), uhi = (int)((long)U * (xcd + 1) / 8);
+            if (idx >= uhi - ulo) return;
+            const int u = ulo + idx;
+            const int slice = u / nblk, lid = u - slice * nblk;
+            const int per = (ntf + S - 1) / S;
+            const int k0 = slice * per;
+            nt = min(per, ntf - k0);            // >= 3 for every slice (host)
+            pos = lid * ntf + k0;
+            pend = pos + nt;
+            lid_origin(lid, m0, n0);
+            plan(m0, n0, k0);
+        } else {
         const int L = (bid & 7) * (G >> 3) + (bid >> 3);
         auto cut = [&](const int l) {
             int x = (int)((long)T * l / G);
@@ -1402,6 +1424,7 @@ __device__ __forceinline__ void gemm_f16x3_km_body(const dupl_gemm16_desc& p, co
         nt = min(pend - pos, ntf - k0);
         lid_origin(lid, m0, n0);
         plan(m0, n0, k0);
+        }
     } else {
         if (!has_tile(bid)) return;
         tile_origin(bid, m0, n0);
@@ -1673,14 +1696,34 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         if (!d->b_layout && d->kb_valid) return DUPL_ERR_ARG;
         const int nb21 = ((d->M + 255) / 256) * ((d->N + 127) / 128);
         const bool sk = accum && !d->deterministic && ksplit > 1;
+        // stream-K forms: aligned k-slices (dupl_gemm16_desc.sk_slices: 0 = as many slices per tile as the grid has blocks for, every
+        // slice >= 3 k-steps (the prologue depth); < 0 = the equal-run cut of round 4)
+        dupl_gemm16_desc dsk = *d;
+        if (accum) {
+            const int ntf = d->K / TBK;
+            auto per = [&](int s_) { return (ntf + s_ - 1) / s_; };
+            if (dsk.sk_slices == 0) {
+                // more tiles than blocks: the equal-run cut (a block's run then spans several tiles); otherwise as many slices as
+                // there are blocks for.  Measured (profiles/r05_sk_slices.txt): stand-alone 3140 x 768 x 3072 244 vs 211 TF/s-eq, 1570 x
+                // 768 x 3072 171-187 vs 149; with a second stream's launch in flight the 4-image shape is slower stand-alone (2 slices
+                // = 156 of 192 blocks: 287 vs 312) but the STEP is faster with it at 4 images too (52.0 vs 52.35 ms, 30.5 vs 30.9 at 2):
+                // the blocks it leaves free and the fabric bandwidth it no longer takes go to the other student's kernels
+                int S = nb21 > g16_persist_blocks ? -1 : g16_persist_blocks / nb21;
+                while (S > 1 && (per(S) < 3 || ntf - (S - 1) * per(S) < 3)) --S;
+                dsk.sk_slices = S;
+            }
+            if (dsk.sk_slices > 0 && ((long)nb21 * dsk.sk_slices > g16_persist_blocks || per(dsk.sk_slices) < 3 ||
+                                      ntf - (dsk.sk_slices - 1) * per(dsk.sk_slices) < 3))
+                return DUPL_ERR_ARG;      // one unit per block, every slice at least the prologue's 3 k-steps
+        }
         if (accum && !d->a_layout) {
             // a data gradient with a LINEAR epilogue (dx = alpha dy . W, nothing else) into a zero-filled dx: stream-K pieces meet in
             // fp32 atomics, so that the N = 768 outputs (78 tiles of 256 x 128 at 4 images, 42 at 2) run on every CU
             if (!d->b_layout || d->deterministic) return DUPL_ERR_ARG;      // (the caller takes the one-block-per-tile form then)
-            hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, false, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d, g16_group_ring);
+            hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, false, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, dsk, g16_group_ring);
         } else if (accum) {
             if (!(d->a_layout && d->b_layout)) return DUPL_ERR_ARG;            // the weight gradient: both operands token-major
-            if (sk) hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, true, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d, g16_group_ring);
+            if (sk) hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, true, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, dsk, g16_group_ring);
             else hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 2, true, true>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
         } else {
             if (d->a_layout || !d->b_layout) return DUPL_ERR_ARG;              // the data gradient: dy k-contiguous, W k-major

@@ -135,7 +135,9 @@ class W16:
 # concurrency: streams that issue split GEMMs at a time (siamese_network.enable_dual_stream sets 2); tile: DUPL_GEMM16_TILE.
 import os as _os
 GEMM16_TUNING = {"tile": int(_os.environ.get("DUPL_GEMM16_TILE", "0")), "concurrency": 1,
-                 "persist_blocks": int(_os.environ.get("DUPL_PERSIST_BLOCKS", "0")), "group": 0}
+                 "persist_blocks": int(_os.environ.get("DUPL_PERSIST_BLOCKS", "0")), "group": 0,
+                 # stream-K data / weight gradients: 0 = aligned k-slices chosen by the library, n > 0 = n slices, -1 = round 4's equal runs
+                 "sk_slices": int(_os.environ.get("DUPL_SK_SLICES", "0"))}
 
 
 # format 1 scales (powers of two): activations * 2^3, weights * 2^9 -- typical |x| ~ 1 and |w| ~ 0.02 both land near 8 .. 10,
@@ -355,6 +357,7 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     d.c_rows = int(c_rows)
     d.tile, d.concurrency = GEMM16_TUNING["tile"], GEMM16_TUNING["concurrency"]
     d.persist_blocks, d.group = GEMM16_TUNING["persist_blocks"], GEMM16_TUNING["group"]
+    d.sk_slices = GEMM16_TUNING["sk_slices"]
     tok = None
     if amax_for_next and y is not None and not accumulate and not c_rows:
         d.amax_out, tok = reserve_amax(dev)

@@ -125,6 +125,10 @@ typedef struct dupl_gemm16_desc {
                                              siamese_network run on their own streams, model_dupl.py:157-213): tile heuristic input */
     int32_t persist_blocks;               /* blocks of the persistent kernels, a multiple of 8 (0: 256 alone, 192 at concurrency 2) */
     int32_t group;                        /* row tiles per group of the block -> tile order */
+    int32_t sk_slices;                    /* stream-K forms of the k-major kernels (DUPL_GEMM_ACCUM, not deterministic): n > 0 = every tile's k axis
+                                             in n aligned slices, one (tile, slice) unit per block, units dealt slice-major to the XCDs (operands
+                                             shared in L2); 0 = the library picks n from the grid; < 0 = equal runs of (tile, k-step) pairs */
+    int32_t reserved1;
 } dupl_gemm16_desc;
 int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream);
 /* n (<= DUPL_GEMM16_GROUP_MAX) independent weight gradients C_i += alpha_i A_i^T . B_i (every descriptor: fmt 1, a_layout = b_layout = 1,

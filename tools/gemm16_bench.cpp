@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
     int iters = 20, epi = 0, probe_iters = 40000, window_ms = 0;
     bool check_only = false, two = false, dbg = false, probe = false, f1 = false;   // f1: format 1 operand planes (single accumulator)
     std::string sel = "fwd", layout = "nn";
-    int group = 0;
+    int group = 0, sk_slices = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-t") && i + 1 < argc) tiles = parse_ints(argv[++i]);
         else if (!strcmp(argv[i], "-n") && i + 1 < argc) iters = atoi(argv[++i]);
@@ -126,6 +126,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "-e") && i + 1 < argc) epi = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-c")) check_only = true;
         else if (!strcmp(argv[i], "-2")) two = true;
+        else if (!strcmp(argv[i], "-K") && i + 1 < argc) sk_slices = atoi(argv[++i]);   // stream-K forms: 0 heuristic, n slices, -1 equal runs
         else if (!strcmp(argv[i], "-g") && i + 1 < argc) group = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-L") && i + 1 < argc) layout = argv[++i];   // nn (default) | nk: B k-major (dgrad) | kk: A and B k-major (wgrad, use -e 4)
         else if (!strcmp(argv[i], "-p")) probe = true;
@@ -223,6 +224,7 @@ int main(int argc, char** argv) {
             memset(&d, 0, sizeof d);
             d.struct_size = sizeof d;
             d.group = group;
+            d.sk_slices = sk_slices;
             d.concurrency = two ? 2 : 1;
             d.A_hi = Ah[s]; d.A_lo = Ah[s] + nA; d.B_hi = Bh[s]; d.B_lo = Bh[s] + nB;
             d.M = M; d.N = N; d.K = K; d.lda = akm ? M : K; d.ldb = bkm ? N : K; d.ldc = N; d.ldo = N; d.ldr = N; d.ldaux = N;
