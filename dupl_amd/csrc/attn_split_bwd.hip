@@ -149,16 +149,14 @@ __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ ou
 
 // ---------------------------------------------------------------------------------------------------- dq
 // Stage (24 KB): K_hi | K_lo | V_hi | V_lo (row-major [32 keys][128 B]) | K_hi | K_lo again, k-major
-__global__ __launch_bounds__(256, 2) void attn_bwd16_dq_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
-                                                               const __half* __restrict__ do_hi, const __half* __restrict__ do_lo,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               const float* __restrict__ slot, float* __restrict__ dqkv, unsigned int* __restrict__ amax_out, int N, int H,
-                                                               float scale, int remap) {
-    constexpr int STAGE = 6 * PL;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+__device__ __forceinline__ void attn_bwd16_dq_body(char* __restrict__ smem, const int bx, const int h, const int b,
+                                                   const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
+                                                   const __half* __restrict__ do_hi, const __half* __restrict__ do_lo,
+                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                   const float* __restrict__ slot, float* __restrict__ dqkv, unsigned int* __restrict__ amax_out, int N, int H,
+                                                   float scale) {
+    constexpr int STAGE = 6 * PL;                              // 2 stages = 48 KB of the block's 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    int bx, h, b;
-    xcd_remap3(remap, bx, h, b);
     const int q0 = bx * 128 + wave * 32;
     const int D = H * HD, ld = 3 * D;
     const int qrow = q0 + l31;
@@ -285,19 +283,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dq_kernel(const __half* __r
 // MODE 0 (dv): stage = Q_hi | Q_lo (row-major [32 q][128 B]) | dO_hi | dO_lo k-major                                (16 KB)
 // MODE 1 (dk): stage = Q_hi | Q_lo | dO_hi | dO_lo (row-major) | Q_hi | Q_lo again, k-major                         (24 KB)
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bwd16_dkv_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
-                                                                const __half* __restrict__ do_hi, const __half* __restrict__ do_lo,
-                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                const float* __restrict__ slot, float* __restrict__ dqkv, unsigned int* __restrict__ amax_out, int N, int H,
-                                                                float scale, int remap) {
+__device__ __forceinline__ void attn_bwd16_dkv_body(char* __restrict__ smem, const int bx, const int h, const int b,
+                                                    const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
+                                                    const __half* __restrict__ do_hi, const __half* __restrict__ do_lo,
+                                                    const float* __restrict__ lse, const float* __restrict__ delta,
+                                                    const float* __restrict__ slot, float* __restrict__ dqkv, unsigned int* __restrict__ amax_out, int N, int H,
+                                                    float scale) {
     constexpr int NPL = MODE == 0 ? 4 : 6;
-    constexpr int STAGE = NPL * PL;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + (MODE == 0 ? 1 : 2) * MAXN * 4];
+    constexpr int STAGE = NPL * PL;                          // MODE 1: 2 x 24 KB + 16 KB of lse / delta = the block's 64 KB
     float* Ls = reinterpret_cast<float*>(smem + 2 * STAGE);
     float* Ds = Ls + MAXN;                                   // MODE 1 only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    int bx, h, b;
-    xcd_remap3(remap, bx, h, b);
     const int k0 = bx * 128 + wave * 32;
     const int D = H * HD, ld = 3 * D;
     const int krow = k0 + l31;
@@ -437,6 +433,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_dkv_kernel(const __half* __
     attn_bwd_amax_flush(amax_out, amx);
 }
 
+// ---------------------------------------------------------------------------------------------------- one launch for all three
+// Round 5.  dq, dv and dk are independent given the dO planes, and each of them alone is a grid of B H ceil(N / 128) blocks (336 at 4
+// x 785 tokens) for the chip's 512 block slots (two 256-thread blocks per CU): three launches = three rounds at 66 % fill, each
+// ending in its own tail.  As ONE launch of 3 x 336 blocks -- the role is the leading index, the slowest role (dk) first -- the same
+// blocks take two rounds and the short dv blocks fill the tail of the long ones.  Same code per block, same results bit for bit.
+constexpr int ATTNB_LDS = 2 * 6 * PL + 2 * MAXN * 4;       // the dk role's 64 KB; the other roles use a prefix
+__global__ __launch_bounds__(256, 2) void attn_bwd16_all_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
+                                                                const __half* __restrict__ do_hi, const __half* __restrict__ do_lo,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                const float* __restrict__ slot, float* __restrict__ dqkv,
+                                                                unsigned int* __restrict__ amax_out, int N, int H, int B, float scale,
+                                                                int remap) {
+    __shared__ __attribute__((aligned(1024))) char smem[ATTNB_LDS];
+    const int gx = (N + 127) / 128;
+    const int G = gx * H * B;
+    const int role = __builtin_amdgcn_readfirstlane((int)blockIdx.x / G);     // 0: dk, 1: dq, 2: dv
+    const int L = (int)blockIdx.x - role * G;
+    int w = L;
+    if (remap) {               // whole heads per XCD inside each role (xcd_remap3 on the role's own index)
+        const int q = G >> 3, r = G & 7;
+        const int xcd = L & 7, idx = L >> 3;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bx = w % gx, h = (w / gx) % H, b = w / (gx * H);
+    if (role == 0) attn_bwd16_dkv_body<1>(smem, bx, h, b, qkv_hi, qkv_lo, do_hi, do_lo, lse, delta, slot, dqkv, amax_out, N, H, scale);
+    else if (role == 1) attn_bwd16_dq_body(smem, bx, h, b, qkv_hi, qkv_lo, do_hi, do_lo, lse, delta, slot, dqkv, amax_out, N, H, scale);
+    else attn_bwd16_dkv_body<0>(smem, bx, h, b, qkv_hi, qkv_lo, do_hi, do_lo, lse, delta, slot, dqkv, amax_out, N, H, scale);
+}
+
 }  // namespace
 
 constexpr int g_attnb16_remap = 1;     // XCD-aware workgroup order
@@ -452,12 +477,8 @@ extern "C" int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, cons
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * N * H;
     hipLaunchKernelGGL(delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, delta, B, N, H);
-    const dim3 grid((N + 127) / 128, H, B);
-    hipLaunchKernelGGL(attn_bwd16_dq_kernel, grid, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo, (const __half*)do_hi,
-                       (const __half*)do_lo, lse, delta, do_slot, dqkv, ax, N, H, scale, g_attnb16_remap);
-    hipLaunchKernelGGL(attn_bwd16_dkv_kernel<0>, grid, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo,
-                       (const __half*)do_hi, (const __half*)do_lo, lse, delta, do_slot, dqkv, ax, N, H, scale, g_attnb16_remap);
-    hipLaunchKernelGGL(attn_bwd16_dkv_kernel<1>, grid, dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo,
-                       (const __half*)do_hi, (const __half*)do_lo, lse, delta, do_slot, dqkv, ax, N, H, scale, g_attnb16_remap);
+    const unsigned blocks = 3u * (unsigned)(((N + 127) / 128) * H * B);
+    hipLaunchKernelGGL(attn_bwd16_all_kernel, dim3(blocks), dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo,
+                       (const __half*)do_hi, (const __half*)do_lo, lse, delta, do_slot, dqkv, ax, N, H, B, scale, g_attnb16_remap);
     return dupl_launch_status();
 }

@@ -1425,6 +1425,10 @@ __device__ __forceinline__ void gemm_f16x3_km_body(const dupl_gemm16_desc& p, co
         lid_origin(lid, m0, n0);
         plan(m0, n0, k0);
         }
+    } else if constexpr (ONESHOT) {
+        if (bid >= nblk) return;             // grouped launch: bid0 IS the tile's position in this problem's grouped order
+        lid_origin(bid, m0, n0);
+        plan(m0, n0, 0);
     } else {
         if (!has_tile(bid)) return;
         tile_origin(bid, m0, n0);
@@ -1535,9 +1539,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_km_kernel(cons
 // only 18 .. 72 tiles of 256 x 128 -- as ONE launch of 216 tiles: every block owns a whole tile and walks all of K (the token
 // axis: 99 k-steps at 4 images), so nothing is split, nothing meets in atomics (C += tile by the one owner: the same bits in
 // deterministic mode and out of it), the 3-stage prologue and the epilogue are paid once per 99 k-steps instead of once per
-// ~14 (stream-K pieces), and the tile count does not depend on the batch.  Problem i owns the block range [first[i],
-// first[i + 1]), a multiple of 8 blocks long so that a block's local index keeps its XCD (blockIdx % 8): the XCD-aware tile
-// order of every problem stays intact.
+// ~14 (stream-K pieces), and the tile count does not depend on the batch.  Problem i owns the tiles [first[i], first[i + 1]) of
+// one list, which the kernel deals to the XCDs in contiguous eighths (round 5).
 struct g16_group_args {
     dupl_gemm16_desc d[DUPL_GEMM16_GROUP_MAX];
     int first[DUPL_GEMM16_GROUP_MAX + 1];
@@ -1545,12 +1548,21 @@ struct g16_group_args {
 };
 template <int WM, int WN, int NWM, int NWN, int WPS>
 __global__ __launch_bounds__(64 * NWM * NWN, WPS) void gemm_f16x3_km_group_kernel(const g16_group_args g, const int g_gm) {
+    // tile list = problem after problem, each in its grouped order (g_gm row tiles x all column tiles per group); XCD x (= blockIdx % 8)
+    // takes the x-th eighth of the LIST: ~27 consecutive tiles of (mostly) one problem = 4-5 row tiles x all its column tiles, whose dy
+    // columns and x columns meet in that XCD's L2 -- round 4 dealt every problem over all 8 XCDs (9 / 9 / 7 / 2 tiles each): every XCD
+    // fetched nearly all of every x and a band of every dy, 487 MB of fabric traffic per launch for 183 MB of operands
+    const int T = g.first[g.n];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int lo = (int)((long)T * xcd / 8), hi = (int)((long)T * (xcd + 1) / 8);
+    if (idx >= hi - lo) return;
+    const int t = lo + idx;
     int i = 0;
 #pragma unroll 1
-    while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
+    while (i + 1 < g.n && t >= g.first[i + 1]) ++i;
     i = __builtin_amdgcn_readfirstlane(i);
     // one tile per block: a step of the whole grid ends the persistent walk after the first tile
-    gemm_f16x3_km_body<WM, WN, NWM, NWN, WPS, false, 2, true, true, 3, true>(g.d[i], g_gm, (int)blockIdx.x - g.first[i], 1 << 28);
+    gemm_f16x3_km_body<WM, WN, NWM, NWN, WPS, false, 2, true, true, 3, true>(g.d[i], g_gm, t - g.first[i], 1 << 28);
 }
 
 }  // namespace
@@ -1608,11 +1620,11 @@ extern "C" int dupl_gemm_f16x3_group(const dupl_gemm16_desc* descs, int32_t n, d
         g.d[i] = d;
         g.first[i] = total;
         const int nblk = ((d.M + 255) / 256) * ((d.N + 127) / 128);
-        total += 8 * ((nblk + 7) / 8);          // a multiple of 8: the local block index keeps the block's XCD
+        total += nblk;                          // first[] counts TILES: the kernel deals the list to the XCDs in eighths
         if (d.group) group = d.group;
     }
     g.first[n] = total;
-    hipLaunchKernelGGL((gemm_f16x3_km_group_kernel<2, 2, 4, 2, 2>), dim3((unsigned)total), dim3(512), 0, (hipStream_t)stream, g,
+    hipLaunchKernelGGL((gemm_f16x3_km_group_kernel<2, 2, 4, 2, 2>), dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), 0, (hipStream_t)stream, g,
                        group ? group : G16_GROUP_RING);
     return dupl_launch_status();
 }

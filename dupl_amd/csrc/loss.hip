@@ -10,24 +10,40 @@ namespace {
 // blocks retire in (the last bit of the printed loss changes from run to run); instead every block adds its partial sums as Q28
 // FIXED POINT into 64-bit integer accumulators -- integer addition commutes, so the result is the same in any order, in every
 // mode, and it is more accurate than a chain of fp32 adds (a partial < 2^35 converts exactly to 2^-28; one rounding at the end).
-// Layout of the caller's zero-filled `sums` (DUPL_LOSS_SUMS_FLOATS = 16 floats): [0..3] the four results, written by the
-// last block to retire; [4..11] four uint64 accumulators; [12] retired-block counter; [13] "a partial was inf / NaN" flag (a
-// diverged run must still print a non-finite loss: the results are NaN then).
+// Layout of the caller's zero-filled `sums` (DUPL_LOSS_SUMS_FLOATS = 136 floats): [0..3] the four results, written by the last
+// block to retire; [4] retired-block counter; [5] "a partial was inf / NaN" flag (a diverged run must still print a non-finite
+// loss: the results are NaN then); [8 ..] LOSS_SETS = 16 sets of four uint64 accumulators -- a block adds into set (block id % 16),
+// the last block adds the sets up (integers: any order).  One set for all blocks made 3 364 blocks queue on the same four L2
+// addresses (seg-loss forward 55 -> 95 us); with 16 sets the reduction is off the kernel's critical path again.
 constexpr float Q28 = 268435456.f;
-__device__ __forceinline__ void loss_sums_commit(float* __restrict__ sums, float a, float b, float c, float d, unsigned nblocks) {
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(sums + 4);
-    unsigned* done = reinterpret_cast<unsigned*>(sums + 12);
-    if (!(isfinite(a) && isfinite(b) && isfinite(c) && isfinite(d))) { atomicOr(done + 1, 1u); a = b = c = d = 0.f; }
-    if (a != 0.f) atomicAdd(&acc[0], (unsigned long long)__float2ll_rn(a * Q28));
-    if (b != 0.f) atomicAdd(&acc[1], (unsigned long long)__float2ll_rn(b * Q28));
-    if (c != 0.f) atomicAdd(&acc[2], (unsigned long long)__float2ll_rn(c * Q28));
-    if (d != 0.f) atomicAdd(&acc[3], (unsigned long long)__float2ll_rn(d * Q28));
-    __threadfence();
-    if (atomicAdd(done, 1u) == nblocks - 1u) {
-        __threadfence();
-        const bool bad = atomicOr(done + 1, 0u) != 0u;
-        for (int i = 0; i < 4; ++i)
-            sums[i] = bad ? __int_as_float(0x7fc00000) : (float)((double)atomicAdd(&acc[i], 0ull) * (1.0 / 268435456.0));
+constexpr int LOSS_SETS = 16;
+__device__ __forceinline__ void loss_sums_commit(float* __restrict__ sums, float a, float b, float c, float d, unsigned block_id,
+                                                 unsigned nblocks) {
+    unsigned* done = reinterpret_cast<unsigned*>(sums + 4);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(sums + 8) + 4 * (block_id % LOSS_SETS);
+    // Ordering without __threadfence(): on a multi-XCD part an agent-scope release fence writes the XCD's L2 back (buffer_wbl2) --
+    // per block, that was most of the 40 us the first fixed-point version added to the seg-loss forward.  Every access here is an
+    // agent-scope ATOMIC (performed at the coherence point, past the per-XCD L2s); the adds return their old values and the
+    // counter increment is issued only after those returns have arrived (vmcnt(0) on a value that depends on them), so the
+    // block that draws the last ticket finds every add of every other block performed.
+    unsigned long long r = 0ull;
+    if (!(isfinite(a) && isfinite(b) && isfinite(c) && isfinite(d))) {
+        r ^= __hip_atomic_fetch_or(done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = b = c = d = 0.f;
+    }
+    if (a != 0.f) r ^= __hip_atomic_fetch_add(&acc[0], (unsigned long long)__float2ll_rn(a * Q28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b != 0.f) r ^= __hip_atomic_fetch_add(&acc[1], (unsigned long long)__float2ll_rn(b * Q28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c != 0.f) r ^= __hip_atomic_fetch_add(&acc[2], (unsigned long long)__float2ll_rn(c * Q28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d != 0.f) r ^= __hip_atomic_fetch_add(&acc[3], (unsigned long long)__float2ll_rn(d * Q28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(r) : "memory");
+    if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1u) {
+        const bool bad = __hip_atomic_load(done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        unsigned long long* all = reinterpret_cast<unsigned long long*>(sums + 8);
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long t = 0ull;
+            for (int s = 0; s < LOSS_SETS; ++s) t += __hip_atomic_load(&all[4 * s + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sums[i] = bad ? __int_as_float(0x7fc00000) : (float)((double)t * (1.0 / 268435456.0));
+        }
     }
 }
 
@@ -45,6 +61,9 @@ __device__ __forceinline__ int ptc_pair(const long long* lb, const long long* mk
     return lr == lc ? 1 : 0;
 }
 
+// Round 5: one ROW of the (hw, hw) matrix per block pass and the columns over the threads -- no 64-bit division per element, the row's
+// label is read once, the column labels and the cosines are coalesced (the flat-index form spent ~40 instructions of integer
+// division per element and chained two dependent label loads behind it: 76-109 us for 9.8 MB; now bound by the read).
 __global__ __launch_bounds__(256) void ptc_reduce_kernel(const float* __restrict__ cosm, const long long* __restrict__ label,
                                                          const long long* __restrict__ mask, int ignore,
                                                          float* __restrict__ sums, int hw) {
@@ -54,15 +73,24 @@ __global__ __launch_bounds__(256) void ptc_reduce_kernel(const float* __restrict
     const long long* mk = mask ? mask + (long)b * hw * hw : nullptr;
     const float* cb = cosm + (long)b * hw * hw;
     float sp = 0.f, np = 0.f, sn = 0.f, nn = 0.f;
-    const long total = (long)hw * hw;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int kind = ptc_pair(lb, mk, i, hw, ignore);
-        if (kind < 0) continue;
-        const float v = fabsf(cb[i]);
-        if (kind == 1) { sp += v; np += 1.f; } else { sn += v; nn += 1.f; }
+    for (int r = blockIdx.x; r < hw; r += gridDim.x) {
+        const float* row = cb + (long)r * hw;
+        const long long lr = lb ? lb[r] : 0;
+        const long long* mrow = mk ? mk + (long)r * hw : nullptr;
+        for (int c = threadIdx.x; c < hw; c += blockDim.x) {
+            int kind;
+            if (mrow) { const long long m = mrow[c]; kind = m == 1 ? 1 : (m == 0 ? 0 : -1); }
+            else {
+                const long long lc = lb[c];
+                kind = (r == c || lr == ignore || lc == ignore) ? -1 : (lr == lc ? 1 : 0);
+            }
+            if (kind < 0) continue;
+            const float v = fabsf(row[c]);
+            if (kind == 1) { sp += v; np += 1.f; } else { sn += v; nn += 1.f; }
+        }
     }
     sp = block_sum(sp, red); np = block_sum(np, red); sn = block_sum(sn, red); nn = block_sum(nn, red);
-    if (threadIdx.x == 0) loss_sums_commit(sums, sp, np, sn, nn, gridDim.x * gridDim.y);
+    if (threadIdx.x == 0) loss_sums_commit(sums, sp, np, sn, nn, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
 }
 
 // in place: cos_signed -> d loss / d cos_signed  (g = upstream scalar gradient gscale[0])
@@ -183,7 +211,8 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     }
     if (!BWD) {
         ce_bg = block_sum(ce_bg, red); n_bg = block_sum(n_bg, red); ce_fg = block_sum(ce_fg, red); n_fg = block_sum(n_fg, red);
-        if (threadIdx.x == 0) loss_sums_commit(sums, ce_bg, n_bg, ce_fg, n_fg, gridDim.x * gridDim.y * gridDim.z);
+        if (threadIdx.x == 0)
+            loss_sums_commit(sums, ce_bg, n_bg, ce_fg, n_fg, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
     } else {
         // d loss/d z_c = coef * (softmax_c - [c==lab]); scatter to the 4 low-res cells.  All lanes of a wave (4 rows x 16
         // px of the shifted tile) share the same 2x2 cells, so reduce over the wave first: 4*C1 atomics per wave.
@@ -352,17 +381,21 @@ __global__ void mask_fill_kernel(float* __restrict__ label, const unsigned char*
 
 // ----------------------------------------------------------------------------------------------- cosine
 // a, b token-major [B][n][c] (row stride ld, image stride ims); reduction over the n tokens per (image, channel)
-__global__ __launch_bounds__(256) void cos_sim_fwd_kernel(const float* __restrict__ a, const float* __restrict__ bb,
-                                                          float* __restrict__ out, float* __restrict__ stats, int n, int c,
-                                                          long ld, long ims, float eps) {
-    __shared__ float r0[4][64], r1[4][64], r2[4][64];
+// (round 5: 16 row groups per block instead of 4 -- the grid is only (c / 64) x B = 48 blocks, so each thread walked 196 tokens with
+// two dependent-free but un-overlapped loads per step: 58 us on the critical path between the loss section and the backward)
+constexpr int CS_RG = 16;
+__global__ __launch_bounds__(64 * CS_RG) void cos_sim_fwd_kernel(const float* __restrict__ a, const float* __restrict__ bb,
+                                                                 float* __restrict__ out, float* __restrict__ stats, int n, int c,
+                                                                 long ld, long ims, float eps) {
+    __shared__ float r0[CS_RG][64], r1[CS_RG][64], r2[CS_RG][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl, img = blockIdx.y;
     float d = 0.f, aa = 0.f, b2 = 0.f;
     if (col < c) {
         const float* pa = a + img * ims + col;
         const float* pb = bb + img * ims + col;
-        for (int i = rg; i < n; i += 4) {
+#pragma unroll 4
+        for (int i = rg; i < n; i += CS_RG) {
             const float x = pa[(long)i * ld], y = pb[(long)i * ld];
             d += x * y; aa += x * x; b2 += y * y;
         }
@@ -370,9 +403,9 @@ __global__ __launch_bounds__(256) void cos_sim_fwd_kernel(const float* __restric
     r0[rg][cl] = d; r1[rg][cl] = aa; r2[rg][cl] = b2;
     __syncthreads();
     if (rg == 0 && col < c) {
-        d = (r0[0][cl] + r0[1][cl]) + (r0[2][cl] + r0[3][cl]);
-        aa = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
-        b2 = (r2[0][cl] + r2[1][cl]) + (r2[2][cl] + r2[3][cl]);
+        d = aa = b2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < CS_RG; ++g) { d += r0[g][cl]; aa += r1[g][cl]; b2 += r2[g][cl]; }      // fixed order
         const float na = fmaxf(sqrtf(aa), eps), nb = fmaxf(sqrtf(b2), eps);
         out[(long)img * c + col] = d / (na * nb);
         float* st = stats + ((long)img * c + col) * 3;
@@ -441,8 +474,7 @@ extern "C" int dupl_ptc_reduce(const float* cosm, const int64_t* label, const in
                                int32_t b, int32_t hw, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!cosm || (!label && !mask) || !sums || b <= 0 || hw <= 0) return DUPL_ERR_ARG;
-    int gx = (int)(((long)hw * hw + 1023) / 1024);
-    if (gx > 512) gx = 512;
+    int gx = hw < 96 ? hw : 96;              // rows of the (hw, hw) matrix per image are dealt to the blocks (~8 rows each at 28 x 28)
     hipLaunchKernelGGL(ptc_reduce_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)s, cosm, (const long long*)label,
                        (const long long*)mask, ignore_index, sums, hw);
     return dupl_launch_status();
@@ -541,7 +573,7 @@ extern "C" int dupl_cos_sim_fwd(const float* a, const float* b, float* out, floa
                                 int64_t ld, int64_t img_stride, float eps, dupl_stream_t s) {
     (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!a || !b || !out || !stats || B <= 0 || n <= 0 || c <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(cos_sim_fwd_kernel, dim3((c + 63) / 64, B), dim3(256), 0, (hipStream_t)s, a, b, out, stats, n, c, (long)ld,
+    hipLaunchKernelGGL(cos_sim_fwd_kernel, dim3((c + 63) / 64, B), dim3(64 * CS_RG), 0, (hipStream_t)s, a, b, out, stats, n, c, (long)ld,
                        (long)img_stride, eps);
     return dupl_launch_status();
 }

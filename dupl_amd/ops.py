@@ -810,7 +810,7 @@ def scale_(y: Tensor, a: float):
     return y
 
 
-LOSS_SUMS_FLOATS = 16     # include/dupl_hip.h DUPL_LOSS_SUMS_FLOATS: the `sums` buffers of dupl_ptc_reduce / dupl_seg_loss_fwd
+LOSS_SUMS_FLOATS = 136     # include/dupl_hip.h DUPL_LOSS_SUMS_FLOATS: the `sums` buffers of dupl_ptc_reduce / dupl_seg_loss_fwd
 
 
 def zeros(shape, device) -> Tensor:

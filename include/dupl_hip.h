@@ -42,7 +42,7 @@ int dupl_abi_version(void);
  * (vit.py:176-183), LargeFOV convs as im2col GEMMs (conv_head.py:32-41), the PTC Gram matrix
  * (losses.py:12) and every dgrad / wgrad autograd derives from them.
  * flags: */
-#define DUPL_LOSS_SUMS_FLOATS 16 /* size of the `sums` buffers of dupl_ptc_reduce / dupl_seg_loss_fwd (results in [0..3]) */
+#define DUPL_LOSS_SUMS_FLOATS 136 /* size of the `sums` buffers of dupl_ptc_reduce / dupl_seg_loss_fwd (results in [0..3]) */
 #define DUPL_GEMM_A_MCONTIG 1   /* A stored [K][lda] (m contiguous) instead of [M][lda] (k contiguous) */
 #define DUPL_GEMM_B_NCONTIG 2   /* B stored [K][ldb] (n contiguous) instead of [N][ldb] (k contiguous) */
 #define DUPL_GEMM_GELU 4        /* v = gelu_erf(v) after bias */
@@ -334,7 +334,7 @@ int dupl_refine_merge(const float* lab_h, const float* lab_l, float* out, float 
  * cos (b,hw,hw) = SIGNED xhat^T xhat from dupl_gemm_f32; pairs are classified from label (b,hw) int64, or -- the
  * reference API get_masked_ptc_loss(inputs, mask) -- from an explicit mask (b,hw,hw) int64 (1 pos / 0 neg / else ignored)
  * when mask != NULL.
- * sums: DUPL_LOSS_SUMS_FLOATS (16) floats, zero-filled by the caller; after the launch sums[0..3] = {sum_pos |cos|, n_pos,
+ * sums: DUPL_LOSS_SUMS_FLOATS (136) floats, zero-filled by the caller; after the launch sums[0..3] = {sum_pos |cos|, n_pos,
  * sum_neg |cos|, n_neg}.  The rest is the reduction's own state (ABI 3): the blocks accumulate in 64-bit fixed point, so the
  * four results do not depend on the order the blocks retire in -- bit-reproducible in every mode. */
 int dupl_ptc_reduce(const float* cos, const int64_t* label, const int64_t* mask, int32_t ignore_index, float* sums,
