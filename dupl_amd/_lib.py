@@ -85,6 +85,13 @@ class SplitItem(ctypes.Structure):
                 ("Rp", ctypes.c_int32)]
 
 
+class AttnSeg(ctypes.Structure):
+    """dupl_attn_seg (include/dupl_hip.h): one batch of a segmented attention-forward launch."""
+    _fields_ = [("row0", ctypes.c_int64), ("B", ctypes.c_int32), ("N", ctypes.c_int32), ("B_f32", ctypes.c_int32),
+                ("reserved0", ctypes.c_int32), ("out", ctypes.c_void_p), ("lse", ctypes.c_void_p)]
+
+
+ATTN_SEGS_MAX = 4             # DUPL_ATTN_SEGS_MAX
 SPLIT_MULTI_MAX = 16
 GEMM16_GROUP_MAX = 8          # DUPL_GEMM16_GROUP_MAX
 

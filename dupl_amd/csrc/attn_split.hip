@@ -60,15 +60,50 @@ __device__ __forceinline__ void xcd_remap3(int remap, int& bx, int& by, int& bz)
     bz = w / (gx * gy);
 }
 
+// Several batches of one token buffer in ONE launch (round 5).  The ms-CAM pass of a step holds three batches of different length
+// (8 x 785, 8 x 197, 8 x 1 765 tokens at 448^2, 4 images); a launch per batch is 672 / 192 / 1 344 blocks for the chip's 512 block
+// slots -- 1.3, 0.4 and 2.6 rounds, each with its own tail.  As one grid, longest batch first, the 2 208 blocks run back to back and
+// the short ones fill the tails.  Segment = the batch's first token row in the planes, image count, tokens per image, its fp32
+// output / lse (NULL: planes only) and the block index its blocks start at.
+struct AttnSegs {
+    int n;
+    int row0[DUPL_ATTN_SEGS_MAX], B[DUPL_ATTN_SEGS_MAX], N[DUPL_ATTN_SEGS_MAX], B_f32[DUPL_ATTN_SEGS_MAX], first[DUPL_ATTN_SEGS_MAX + 1];
+    float* out[DUPL_ATTN_SEGS_MAX];
+    float* lse[DUPL_ATTN_SEGS_MAX];
+};
+
 __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo,
-                                                            float* __restrict__ out, __half* __restrict__ out_hi,
-                                                            __half* __restrict__ out_lo, float* __restrict__ lse, int N, int H,
-                                                            float scale, int remap, int B_f32, float out_scale) {
+                                                            __half* __restrict__ out_hi, __half* __restrict__ out_lo,
+                                                            const AttnSegs segs, int H, float scale, int remap, float out_scale) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // scalar: the LDS destination of a DMA piece goes through M0
+    int sg = 0;
+#pragma unroll 1
+    while (sg + 1 < segs.n && (int)blockIdx.x >= segs.first[sg + 1]) ++sg;
+    sg = __builtin_amdgcn_readfirstlane(sg);
+    const int N = segs.N[sg], B_f32 = segs.B_f32[sg];
+    float* __restrict__ out = segs.out[sg];
+    float* __restrict__ lse = segs.lse[sg];
     int bx, h, b;
-    xcd_remap3(remap, bx, h, b);
+    {
+        const int gx = (N + 127) / 128;
+        const int G = gx * H * segs.B[sg];
+        const int L = (int)blockIdx.x - segs.first[sg];
+        int w = L;
+        if (remap) {                  // whole heads per XCD inside the segment (xcd_remap3 on the segment's own index)
+            const int q = G >> 3, r = G & 7;
+            const int xcd = L & 7, idx = L >> 3;
+            w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        bx = w % gx; h = (w / gx) % H; b = w / (gx * H);
+    }
+    {
+        const size_t r0 = (size_t)segs.row0[sg];
+        qkv_hi += r0 * (size_t)(3 * H * HD);
+        qkv_lo += r0 * (size_t)(3 * H * HD);
+        if (out_hi) { out_hi += r0 * (size_t)(H * HD); out_lo += r0 * (size_t)(H * HD); }
+    }
     const int q0 = bx * 128 + wave * 32;
     const int D = H * HD, ld = 3 * D;
     const int qrow = q0 + l31;
@@ -369,20 +404,46 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const __half* __rest
 
 constexpr int g_attn16_remap = 1;      // XCD-aware workgroup order (whole heads per XCD)
 
+static int attn_fwd16_launch(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, const dupl_attn_seg* sv, int32_t n,
+                             int32_t H, int32_t hd, float scale, int32_t out_exp, dupl_stream_t s) {
+    if (out_exp < 0 || out_exp > 15 || !sv || n < 1 || n > DUPL_ATTN_SEGS_MAX) return DUPL_ERR_ARG;
+    if (!qkv_hi || !qkv_lo || ((out_hi == nullptr) != (out_lo == nullptr)) || H <= 0 || hd != HD) return DUPL_ERR_ARG;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(qkv_hi) || !al16(qkv_lo)) return DUPL_ERR_ARG;
+    // longest batch first (its blocks run longest); ties keep the caller's order
+    int order[DUPL_ATTN_SEGS_MAX];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && sv[order[j]].N > sv[order[j - 1]].N; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    AttnSegs g;
+    g.n = n;
+    int total = 0;
+    for (int k = 0; k < n; ++k) {
+        const dupl_attn_seg& q = sv[order[k]];
+        int bf = q.B_f32 == 0 ? q.B : q.B_f32;          // 0 = the fp32 output / lse for every image
+        if (q.B <= 0 || q.N <= 0 || q.row0 < 0 || bf < 0 || bf > q.B || (!q.out && !out_hi) || (bf < q.B && q.out && !out_hi)) return DUPL_ERR_ARG;
+        g.row0[k] = (int)q.row0; g.B[k] = q.B; g.N[k] = q.N; g.B_f32[k] = bf; g.out[k] = q.out; g.lse[k] = q.lse;
+        g.first[k] = total;
+        total += ((q.N + 127) / 128) * H * q.B;
+    }
+    g.first[n] = total;
+    hipLaunchKernelGGL(attn_fwd16_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi, (const __half*)qkv_lo,
+                       (__half*)out_hi, (__half*)out_lo, g, H, scale, g_attn16_remap, out_exp ? ldexpf(1.f, out_exp) : 0.f);
+    return dupl_launch_status();
+}
+
 extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, float* out, void* out_hi, void* out_lo, float* lse,
                                     int32_t B, int32_t N, int32_t H, int32_t hd, float scale, int32_t B_f32, int32_t out_exp,
                                     dupl_stream_t s) {
     (void)hipGetLastError();
-    if (out_exp < 0 || out_exp > 15) return DUPL_ERR_ARG;
-    if (B_f32 == 0) B_f32 = B;           // 0 = the fp32 output / lse for every image
-    if (B_f32 < 0 || B_f32 > B || (B_f32 < B && !out_hi)) return DUPL_ERR_ARG;
-    if (!qkv_hi || !qkv_lo || (!out && !out_hi) || ((out_hi == nullptr) != (out_lo == nullptr)) || B <= 0 || N <= 0 || H <= 0 ||
-        hd != HD)
-        return DUPL_ERR_ARG;
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (!al16(qkv_hi) || !al16(qkv_lo)) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(attn_fwd16_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi,
-                       (const __half*)qkv_lo, out, (__half*)out_hi, (__half*)out_lo, lse, N, H, scale, g_attn16_remap, B_f32,
-                       out_exp ? ldexpf(1.f, out_exp) : 0.f);
-    return dupl_launch_status();
+    if (B_f32 < 0 || B_f32 > B || (B_f32 != 0 && B_f32 < B && !out_hi) || (!out && !out_hi)) return DUPL_ERR_ARG;
+    dupl_attn_seg q;
+    q.row0 = 0; q.B = B; q.N = N; q.B_f32 = B_f32; q.out = out; q.lse = lse;
+    return attn_fwd16_launch(qkv_hi, qkv_lo, out_hi, out_lo, &q, 1, H, hd, scale, out_exp, s);
+}
+
+extern "C" int dupl_attention_fwd16_segs(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, const dupl_attn_seg* segs,
+                                         int32_t n, int32_t H, int32_t hd, float scale, int32_t out_exp, dupl_stream_t s) {
+    (void)hipGetLastError();
+    return attn_fwd16_launch(qkv_hi, qkv_lo, out_hi, out_lo, segs, n, H, hd, scale, out_exp, s);
 }

@@ -129,6 +129,14 @@ SK_DGRAD_MAX_COLS = 1024
 ZERO_WS = os.environ.get("DUPL_ZERO_WS", "1") != "0"
 # AdamW writes the operand planes of the parameters it updates (no split pass over all weights before the next forward)
 FUSED_PLANES = os.environ.get("DUPL_ADAMW_PLANES", "1") != "0"
+# a training step's ms-CAM scales and its training forward as ONE encoder pass (cam_logits_shared_multi); 0: scale 1.0 (saved) and
+# the remaining scales as two passes (round 4)
+MERGED_PASS = os.environ.get("DUPL_MERGED_PASS", "1") != "0"
+# the attention forward of all batches of a merged pass as ONE launch (ops.attention_fwd16_segs) while it has at most this many
+# 128-query blocks (0: always one launch per batch).  Measured, two student streams, same box: 2 img/GPU (1 104 blocks) 28.87 vs
+# 29.27 ms per step with the single launch; 4 img/GPU (2 208 blocks) 52.07 vs 51.80 -- a grid that holds every block slot of the chip
+# for several rounds keeps the other student's kernels out longer than its filled tails give back
+ATTN_SEGS = int(os.environ.get("DUPL_ATTN_SEGS", "1536"))
 
 
 class FlatStorage:
@@ -658,7 +666,7 @@ def encoder_forward(P: StudentParams, x: Tensor, save: bool, save_rows: int = 0)
     return tf, aux, sv
 
 
-def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
+def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0, whole: bool = False):
     """forward_features of ONE or SEVERAL batches (different resolutions) with every Linear on the f16x3 split GEMM.
     Token rows of all batches are concatenated (every row-wise kernel runs once over all of them, attention per batch on
     its row slice -- the merged ms-CAM pass of cam_logits_multi); with save=True (single batch only) the fp32 copies
@@ -670,14 +678,16 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
     cfg = P.cfg
     D, H, hd = cfg.embed_dim, cfg.num_heads, cfg.head_dim
     W = P.w
-    assert not (save and len(xs) > 1)
     P.store.ensure_w16(P.student)
     guard = P.store.guard.sites(P.student)      # which sites may run on fp16 planes (RangeGuard); the others run on f32
     # save_rows > 0 (shared ms-CAM / training pass: rows of the un-flipped images come first and only they are back-propagated):
     # the fp32 copies the backward needs are produced for those rows only -- planes, which the forward consumes, for all rows.
     # Only while every site runs on planes (an f32-routed consumer needs its fp32 input for all rows).
-    if save_rows and not (hd == 64 and all(b[k] for b in guard["blocks"] for k in RangeGuard.SITES)):
+    if save_rows and not partial_save_ok(P, guard):
         save_rows = 0
+    # several batches WITH saving (round 5: the whole ms-CAM of a step -- all scales -- and the training forward as ONE pass): only
+    # the first save_rows rows (a prefix of batch 0) are recorded, which needs the partial-save route above
+    assert not (save and len(xs) > 1 and not save_rows), "a merged pass can only save a row prefix of its first batch (partial_save_ok)"
     def ea(site_flags, site):             # plane format (format 1 exponent, 0 = format 0) of the activations that feed `site`'s GEMM
         return int(site_flags[site + "_f1"]) if FMT1 else 0
     toks, groups = [], []
@@ -721,7 +731,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         # f32-routed consumer needs them
         # the fp32 q / k / v exist only for consumers that cannot take planes: the f32 attention kernels (other head dims, an
         # out-of-range verdict) and the f32 attention backward of sequences beyond 2 048 tokens
-        need_qkv32 = (not attn16) or (save and max(gr[2] for gr in groups) > 2048)
+        need_qkv32 = (not attn16) or (save and groups[0][2] > 2048)       # (only batch 0 is ever back-propagated)
         if g["qkv"]:
             qkv, qkv16 = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D, bool(ln1_16.exp)), W[p + "attn.qkv.bias"],
                                       want_f32=need_qkv32, want16=attn16)
@@ -733,14 +743,31 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         need_att32 = save or not g["proj"]
         att = torch.empty((save_rows or R, D), device=t.device, dtype=torch.float32) if (need_att32 or not attn16) else None
         att16 = ops.split16_empty(R, D, t.device, ea(g, "proj")) if (attn16 and g["proj"]) else None
-        for (g0, B, N, _, _) in groups:
+        lse = None
+        use_segs = attn16 and 1 < len(groups) <= ops._lib.ATTN_SEGS_MAX and \
+            sum(B_ * H * ((N_ + 127) // 128) for (_, B_, N_, _, _) in groups) <= ATTN_SEGS
+        if use_segs:
+            # every batch of the pass in one launch, longest first (dupl_attention_fwd16_segs): the short batches fill the tails
+            segs = []
+            for gi, (g0, B, N, _, _) in enumerate(groups):
+                planes_only = bool(save_rows and gi > 0) or att is None
+                bf = save_rows // N if (save_rows and gi == 0) else 0
+                segs.append((g0, B, N, None if planes_only else att[g0:g0 + (bf or B) * N], bool(save and gi == 0), bf))
+            lse = ops.attention_fwd16_segs(qkv16, segs, H, hd, scale, out16=att16)[0]
+        for gi, (g0, B, N, _, _) in enumerate(() if use_segs else groups):
             if attn16:
+                if save_rows and gi > 0:      # rows beyond the saved prefix: planes only, no fp32 output, no lse
+                    ops.attention_fwd16(qkv16.rows_slice(g0, g0 + B * N), B, N, H, hd, scale, need_lse=False, out=None,
+                                        out16=att16.rows_slice(g0, g0 + B * N))
+                    continue
                 bf = save_rows // N if save_rows else 0
-                lse = ops.attention_fwd16(qkv16.rows_slice(g0, g0 + B * N), B, N, H, hd, scale, need_lse=save,
-                                          out=att[g0:g0 + (bf or B) * N] if att is not None else None,
-                                          out16=att16.rows_slice(g0, g0 + B * N) if att16 is not None else None, b_f32=bf)
+                lse_g = ops.attention_fwd16(qkv16.rows_slice(g0, g0 + B * N), B, N, H, hd, scale, need_lse=save,
+                                            out=att[g0:g0 + (bf or B) * N] if att is not None else None,
+                                            out16=att16.rows_slice(g0, g0 + B * N) if att16 is not None else None, b_f32=bf)
             else:   # other head dims (the 96-dim test backbone) or q / k / v beyond fp16's range: exact-f32 attention kernel
-                _, lse = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
+                _, lse_g = ops.attention_fwd(qkv[g0:g0 + B * N], B, N, H, hd, scale, need_lse=save, out=att[g0:g0 + B * N])
+            if gi == 0:
+                lse = lse_g
         if not attn16 and g["proj"]:
             att16 = ops.split16(att, exp=ea(g, "proj"))
         qkv16_keep = qkv16 if (save and attn16) else None
@@ -787,7 +814,19 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0):
         sv.x_last, sv.mean_f, sv.rstd_f = t, mf, rf
     if aux is None:
         aux = tf
-    return [(tf[g0:g0 + B * N], aux[g0:g0 + B * N], sv) for (g0, B, N, _, _) in groups]
+    outs = [(tf[g0:g0 + B * N], aux[g0:g0 + B * N], sv) for (g0, B, N, _, _) in groups]
+    if whole:
+        return outs, tf, aux
+    return outs
+
+
+def partial_save_ok(P: StudentParams, guard=None) -> bool:
+    """Can a pass record activations for a row PREFIX only (the shared ms-CAM / training pass)?  Only while every site of the
+    student runs on operand planes: an f32-routed consumer needs its fp32 input for all rows."""
+    if GEMM_MODE != "f16x3" or P.cfg.head_dim != 64:
+        return False
+    guard = guard if guard is not None else P.store.guard.sites(P.student)
+    return all(b[k] for b in guard["blocks"] for k in RangeGuard.SITES)
 
 
 def cam_logits(P: StudentParams, x: Tensor):
@@ -812,10 +851,8 @@ def cam_logits_multi(P: StudentParams, xs):
     W = P.w
     if GEMM_MODE == "f16x3":
         C = P.num_classes - 1
-        outs = _encoder_forward16(P, list(xs), save=False)
-        # the CAM heads (N = C columns) stay on the f32 kernel: one launch over the concatenated rows of all batches
-        tf_all = torch.cat([o[0] for o in outs], dim=0) if len(outs) > 1 else outs[0][0]
-        aux_all = torch.cat([o[1] for o in outs], dim=0) if len(outs) > 1 else outs[0][1]
+        outs, tf_all, aux_all = _encoder_forward16(P, list(xs), save=False, whole=True)
+        # the CAM heads (N = C columns) stay on the f32 kernel: one launch over the rows of all batches (which ARE one tensor)
         cam = ops.linear(tf_all, W["classifier.weight"].view(C, -1))
         cam_aux = ops.linear(aux_all, W["aux_classifier.weight"].view(C, -1))
         res, g0 = [], 0
@@ -913,6 +950,28 @@ def cam_logits_shared(P: StudentParams, x2: Tensor, b: int):
     cam_aux = ops.linear(aux, Wa)
     assert rows == tf.shape[0] // 2
     return cam_aux, cam, (tf[:rows], aux[:rows], _prefix_saved(enc, b, rows))
+
+
+def cam_logits_shared_multi(P: StudentParams, xs, b: int):
+    """The whole encoder work of a training step in ONE pass (round 5): xs[0] = [x ; flip(x)] at scale 1.0 (2b images, run WITH
+    activation saving for its un-flipped half, as cam_logits_shared) and xs[1:] the other ms-CAM scales' batches (no-grad) -- the
+    token rows of all of them concatenated: at 448^2, 4 images, 6 280 + 1 576 + 14 120 = 21 976 rows per Linear instead of a
+    6 280-row pass and a 15 696-row pass: half the launches, larger GEMM grids.  Row-wise kernels and per-batch attention make the
+    result bit-identical to the separate passes.  Needs partial_save_ok(P).
+    Returns [(cam_aux_tok, cam_tok)] per batch and the training forward's cache (tf, aux, EncoderSaved) of x = xs[0][:b]."""
+    C = P.num_classes - 1
+    n0 = (xs[0].shape[2] // P.cfg.patch) * (xs[0].shape[3] // P.cfg.patch) + 1
+    rows = (xs[0].shape[0] // 2) * n0
+    outs, tf, aux = _encoder_forward16(P, list(xs), save=True, save_rows=rows, whole=True)
+    enc = outs[0][2]
+    cam = ops.linear(tf, P.w["classifier.weight"].view(C, -1))
+    cam_aux = ops.linear(aux, P.w["aux_classifier.weight"].view(C, -1))
+    res, g0 = [], 0
+    for o in outs:
+        r = o[0].shape[0]
+        res.append((cam_aux[g0:g0 + r], cam[g0:g0 + r]))
+        g0 += r
+    return res, (tf[:rows], aux[:rows], _prefix_saved(enc, b, rows))
 
 
 def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):

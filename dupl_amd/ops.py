@@ -580,6 +580,29 @@ def attention_fwd16(qkv16, B: int, N: int, H: int, hd: int, scale: float, need_l
     return lse
 
 
+def attention_fwd16_segs(qkv16, segs, H: int, hd: int, scale: float, out16=None):
+    """Split attention forward of SEVERAL batches that live in one token buffer, as ONE launch (dupl_attention_fwd16_segs).
+    qkv16 / out16: planes of ALL rows; segs: [(row0, B, N, out fp32 [bf*N, H*hd] or None, need_lse, b_f32)] with bf = b_f32 or B.
+    Returns the list of lse tensors (None where not asked for)."""
+    assert hd == 64 and 1 <= len(segs) <= _lib.ATTN_SEGS_MAX and getattr(qkv16, "exp", 0) == 0
+    dev = qkv16.planes.device if isinstance(qkv16, Split16) else qkv16.base.planes.device
+    arr = (_lib.AttnSeg * len(segs))()
+    lses = []
+    for i, (row0, B, N, out, need_lse, b_f32) in enumerate(segs):
+        bf = b_f32 or B
+        assert out is not None or out16 is not None
+        if out is not None:
+            assert out.shape == (bf * N, H * hd) and out.is_contiguous()
+        lse = torch.empty((bf, H, N), device=dev, dtype=torch.float32) if need_lse else None
+        lses.append(lse)
+        arr[i].row0, arr[i].B, arr[i].N, arr[i].B_f32 = int(row0), int(B), int(N), int(b_f32)
+        arr[i].out, arr[i].lse = _p(out), _p(lse)
+    L().dupl_attention_fwd16_segs(qkv16.hi, qkv16.lo, out16.hi if out16 is not None else None,
+                                   out16.lo if out16 is not None else None, ctypes.cast(arr, ctypes.c_void_p), len(segs), H, hd,
+                                   float(scale), out16.exp if out16 is not None else 0, _stream())
+    return lses
+
+
 def attention_bwd16(qkv16, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, hd: int, scale: float,
                     amax_for_next: bool = False) -> Tensor:
     """Attention backward on the f16x3 split kernels (head dim 64, N <= 2048): qkv16 = the planes of the qkv GEMM output the

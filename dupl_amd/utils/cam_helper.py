@@ -40,9 +40,13 @@ def _ms_cam(P, inputs, scales, share=None):
         if share is not None:
             # scale 1.0 runs WITH activation saving and doubles as the training forward; the remaining scales share
             # one merged no-grad pass (engine.cam_logits_multi)
-            cam_aux_t, cam_t, share["enc"] = engine.cam_logits_shared(P, xs[0], b)
             share["x"] = xs[0][:b]
-            res = [(cam_aux_t, cam_t)] + (engine.cam_logits_multi(P, xs[1:]) if len(xs) > 1 else [])
+            if engine.MERGED_PASS and len(xs) > 1 and engine.partial_save_ok(P):
+                # round 5: every scale AND the training forward in one encoder pass (21 976 token rows at 448^2, 4 images)
+                res, share["enc"] = engine.cam_logits_shared_multi(P, xs, b)
+            else:
+                cam_aux_t, cam_t, share["enc"] = engine.cam_logits_shared(P, xs[0], b)
+                res = [(cam_aux_t, cam_t)] + (engine.cam_logits_multi(P, xs[1:]) if len(xs) > 1 else [])
         else:
             res = engine.cam_logits_multi(P, xs)
         lows_aux = [r[0] for r in res]

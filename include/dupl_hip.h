@@ -242,6 +242,19 @@ int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int3
  * the planes for all B; out_exp > 0: the output planes in format 1 (out * 2^out_exp, unscaled lo). */
 int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, float* out, void* out_hi, void* out_lo, float* lse, int32_t B,
                          int32_t N, int32_t H, int32_t hd, float scale, int32_t B_f32, int32_t out_exp, dupl_stream_t s);
+/* the same for up to DUPL_ATTN_SEGS_MAX batches that live in ONE token buffer (the merged ms-CAM / training pass of a step: all scales'
+ * rows concatenated), as ONE launch, longest batch first: segment i = B images of N tokens starting at token row row0 of the qkv planes
+ * (and of out_hi / out_lo); out / lse: this batch's own fp32 output ([B_f32*N][H*hd]) and lse ([B_f32][H][N]) or NULL (planes only).
+ * segs: HOST array (copied into the launch). */
+#define DUPL_ATTN_SEGS_MAX 4
+typedef struct dupl_attn_seg {
+    int64_t row0;
+    int32_t B, N, B_f32, reserved0;
+    float* out;
+    float* lse;
+} dupl_attn_seg;
+int dupl_attention_fwd16_segs(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, const dupl_attn_seg* segs, int32_t n,
+                              int32_t H, int32_t hd, float scale, int32_t out_exp, dupl_stream_t s);
 /* backward (what autograd derives for vit.py:123-135): dqkv [B*N][3*H*hd] fully written; delta: workspace [B][H][N]. */
 int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* delta, float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd,

@@ -1221,3 +1221,46 @@ def test_adamw_in_backward_is_bit_identical_to_a_plain_step(dev):
     assert a[6] and b[6], "the planes after the last step are the optimiser's in both forms"
     for name, x, y in zip(("losses", "parameters", "planes", "exp_avg", "exp_avg_sq"), a[:5], b[:5]):
         assert torch.equal(x, y), name
+
+
+def test_merged_encoder_pass_is_bit_identical_to_separate_passes(dev):
+    """engine.MERGED_PASS (round 5): the three ms-CAM scales and the training forward of a step as ONE encoder pass (token rows of all
+    batches concatenated, activations recorded for the un-flipped scale-1.0 rows only) against the round-4 form (scale 1.0 saved +
+    the other scales merged, two passes).  ViT-B/16 dual model at 96^2 (the tiny backbone has head dim 32 and never takes the
+    partial-save route), deterministic mode: CAMs, label maps, every loss and the whole flat gradient buffer are BIT-identical --
+    row-wise kernels, per-batch attention, and GEMMs whose per-element accumulation order does not depend on the row count."""
+    from dupl_amd import engine, trainer, ops
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from oracle import dupl_oracle as O
+    pp = O.make_siamese_params(O.VIT_BASE, 21, seed=5)
+    inputs, cls_label, img_box = O.synthetic_batch(2, 20, 96, seed=11)
+
+    def run(merged):
+        prev, prev_segs = engine.MERGED_PASS, engine.ATTN_SEGS
+        engine.MERGED_PASS = merged
+        engine.ATTN_SEGS = 1 << 30        # ... with the attention forward of all three batches as one segmented launch
+        ops.set_deterministic(1)
+        try:
+            model = siamese_network("deit_base_patch16_224", num_classes=21, pretrained=False, aux_layer=-3)
+            model.load_state_dict(pp, strict=True)
+            model.to(dev)
+            model.enable_dual_stream(True)
+            par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+            assert engine.partial_save_ok(model.branch1._P)
+            model.flat_storage.grad.zero_()
+            loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, 5000, trainer.StepArgs(),
+                                               cls_label_host=cls_label)
+            loss.sum().backward()
+            model.flat_storage.wait_streams()
+            torch.cuda.synchronize()
+            keep = {k: out[k].detach().clone() for k in ("loss", "cls_loss", "ptc_loss", "seg_loss", "sim_loss", "cams_1", "cams_aux_1",
+                                                          "cams_2", "cams_aux_2", "refined_1", "refined_2", "pseudo_label_aux_1")}
+            return keep, model.flat_storage.grad.clone()
+        finally:
+            engine.MERGED_PASS, engine.ATTN_SEGS = prev, prev_segs
+            ops.set_deterministic(0)
+    (ka, ga), (kb, gb) = run(True), run(False)
+    for k in ka:
+        assert torch.equal(ka[k], kb[k]), k
+    assert torch.equal(ga, gb)

@@ -25,14 +25,14 @@ def test_library_exports_every_declared_symbol():
     # the library refuses a mismatch, so a drifted mirror would fail every call; here it fails at build time, without a GPU)
     import subprocess, tempfile
     src = '#include <stdio.h>\n#include "dupl_hip.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", sizeof(dupl_gemm_desc), ' \
-          'sizeof(dupl_gemm16_desc), sizeof(dupl_split_desc), sizeof(dupl_split_item)); return 0; }\n'
+          'sizeof(dupl_gemm16_desc), sizeof(dupl_split_desc), sizeof(dupl_split_item)); printf("%zu\\n", sizeof(dupl_attn_seg)); return 0; }\n'
     with tempfile.TemporaryDirectory() as td:
         c, exe = os.path.join(td, "sz.c"), os.path.join(td, "sz")
         open(c, "w").write(src)
         subprocess.run(["gcc", "-std=c99", "-I", os.path.dirname(_lib.HEADER), c, "-o", exe], check=True)
         sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.Gemm16Desc), ctypes.sizeof(_lib.SplitDesc),
-                     ctypes.sizeof(_lib.SplitItem)], sizes
+                     ctypes.sizeof(_lib.SplitItem), ctypes.sizeof(_lib.AttnSeg)], sizes
     assert _lib.GemmDesc().struct_size == sizes[0] and _lib.Gemm16Desc().struct_size == sizes[1]
 
 
