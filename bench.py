@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the second measurement of the same workload on the exact-f32 MFMA kernels (f16x3 runs only)")
-    ap.add_argument("--pmc-profile", default=os.environ.get("DUPL_PMC_PROFILE", "profiles/r04_final_pmc_hbm.txt"),
+    ap.add_argument("--pmc-profile", default=os.environ.get("DUPL_PMC_PROFILE", "profiles/r05_final_pmc_hbm.txt"),
                     help="PMC summary (tools/profile_round.sh) roofline.traffic is read from; ignored (traffic = null) "
                          "unless its '# csrc_sha256:' header matches the kernel sources of THIS build")
     ap.add_argument("--no-share-encoder", action="store_true",
@@ -245,6 +245,42 @@ def pmc_traffic_per_launch(path, kernel_prefix="gemm_f32_kernel<false, false", g
         f"PMC FETCH_SIZE*2 + WRITE_SIZE per launch, {path} (tag {tag.get('tag', '?')}, git {tag.get('git_head', '?')[:10]})"
 
 
+# kernels of the PMC summary that make up a family of the roofline section (prefix match on the kernel name)
+FAMILY_KERNELS = {"fwd_f1": ("gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>", "gemm_f16x3_ring_kernel<2, 2, 4, 2, 2, 3, true>",
+                             "gemm_f16x3_pring_kernel<2, 2, 4, 2, 2, false, true"),
+                  "dgrad": ("gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, false, true", "gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 0, false, true"),
+                  "wgrad": ("gemm_f16x3_km_group_kernel", "gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, true, true",
+                            "gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 2, true, true")}
+
+
+def pmc_family_traffic(path, steps_profiled=None):
+    """{family: HBM-side MB per step} from a digest-matching PMC summary (FETCH_SIZE * 2 + WRITE_SIZE of the family's kernels, divided
+    by the steps the profiled command ran: `# steps:` header, default 4 = --steps 3 --warmup 1); {} if the summary is not usable."""
+    full = path if os.path.isabs(path) else os.path.join(ROOT, path)
+    try:
+        lines = open(full).read().splitlines()
+    except OSError:
+        return {}
+    tag = {}
+    for line in lines:
+        if line.startswith("# ") and ":" in line:
+            k, v = line[2:].split(":", 1)
+            tag[k.strip()] = v.strip()
+    if tag.get("csrc_sha256") != csrc_digest():
+        return {}
+    steps = steps_profiled or int(tag.get("steps", "4"))
+    out = {}
+    for fam, prefixes in FAMILY_KERNELS.items():
+        kib = 0.0
+        for line in lines:
+            if any(line.startswith(pf) for pf in prefixes):
+                parts = line.split()
+                kib += 2.0 * float(parts[-2]) + float(parts[-1])
+        if kib:
+            out[fam] = kib * 1024.0 / 1e6 / steps
+    return out
+
+
 class GemmTimer:
     """Event-pairs around every launch of the dominant kernel -- the k-contiguous x k-contiguous 'NT' GEMM that every
     forward Linear maps to: dupl_gemm_f16x3 (f16x3 mode) or the NT instantiation of dupl_gemm_f32 (f32 mode) -- on the
@@ -260,6 +296,7 @@ class GemmTimer:
         # pairs["f16x3"]; the two attention families are the split attention kernels (own launches, same MFMA, same peak)
         self.fam_pairs = {k: [] for k in self.FAMILIES}
         self.fam_flops = {k: 0.0 for k in self.FAMILIES}
+        self.fam_bytes = {k: 0.0 for k in self.FAMILIES}      # algorithmic operand + result bytes (GEMM families)
 
     def _timed_family(self, fam, fn, flops):
         s = torch.cuda.current_stream()
@@ -285,6 +322,7 @@ class GemmTimer:
         if family is not None:
             self.fam_pairs[family].append((e0, e1))
             self.fam_flops[family] += 2.0 * M * N * K * batch
+            self.fam_bytes[family] += 4.0 * (M * K + N * K + mn_tensors * M * N) * batch
         return r
 
     def install(self):
@@ -342,6 +380,7 @@ class GemmTimer:
             timer.bytes["f16x3"] += by
             timer.fam_pairs["wgrad"].append((e0, e1))
             timer.fam_flops["wgrad"] += fl
+            timer.fam_bytes["wgrad"] += by
             return r
 
         ops.gemm_raw, ops.linear16 = timed, timed16
@@ -360,6 +399,7 @@ class GemmTimer:
         self.bytes = {k: 0.0 for k in self.bytes}
         self.fam_pairs = {k: [] for k in self.FAMILIES}
         self.fam_flops = {k: 0.0 for k in self.FAMILIES}
+        self.fam_bytes = {k: 0.0 for k in self.FAMILIES}
 
     @staticmethod
     def _union_ms(pairs, base_event):
@@ -392,11 +432,14 @@ class GemmTimer:
                 t = [[a.elapsed_time(b) for a, b in v[p * n:(p + 1) * n]] for p in range(passes)]
                 ms = sum(min(col) for col in zip(*t))
                 fl = self.fam_flops[fam] / passes
+                by = self.fam_bytes[fam] / passes
             else:
                 n = len(v) // steps
                 ms = self._union_ms(v, base_event) / steps
                 fl = self.fam_flops[fam] / steps
+                by = self.fam_bytes[fam] / steps
             out[fam] = {"tflop_per_step": round(fl / 1e12, 3), "launches_per_step": n, "ms_per_step": round(ms, 3),
+                        "algorithmic_mb_per_step": round(by / 1e6, 1) if by else None,
                         "achieved": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
                         "frac": round(fl / (ms * 1e-3) / peak, 4) if ms > 0 else None}
         return out
@@ -608,6 +651,12 @@ def main():
                                 "family's intervals (a launch's interval also spans what the other student's kernels took from it)"}
         traffic, tnote = pmc_traffic_per_launch(args.pmc_profile, prefix, gemm_mode) if (dataset, batch) == ("voc", 4) else \
             (None, "the committed PMC passes are of the VOC 4 img/GPU workload")
+        # per family: fabric traffic of its kernels (PMC summary, per step) over its algorithmic bytes
+        if traffic and fam_single:
+            for fam, mb in pmc_family_traffic(args.pmc_profile).items():
+                if fam in fam_single and fam_single[fam].get("algorithmic_mb_per_step"):
+                    fam_single[fam]["traffic_mb_per_step"] = round(mb, 1)
+                    fam_single[fam]["traffic_over_algorithmic"] = round(mb / fam_single[fam]["algorithmic_mb_per_step"], 2)
         # top level = the configuration the timed region runs in: two student streams unless --single-stream
         top = dual if dual is not None else single
         roof = {"bound": "mfma", "kernel": kname, "achieved": top["achieved"],

@@ -29,7 +29,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_$TAG/c -o c -
 # the summary is tagged with the digest of the kernel sources it was measured on: bench.py quotes roofline.traffic from it
 # only while that digest equals the build's (a changed kernel + a forgotten re-profile gives traffic = null, not a stale number)
 SHA=$(cd $R && python -c "from dupl_amd.build import source_digest; print(source_digest())")
-{ echo "# tag: $TAG"; echo "# csrc_sha256: $SHA"; echo "# git_head: ${GIT_HEAD:-unknown}"; echo "# gemm_mode: ${DUPL_GEMM:-f16x3}"; echo "# workload: python bench.py --single-stream --steps 3 --warmup 1 (VOC 448^2, 4 img/GPU, phase B)";
+{ echo "# tag: $TAG"; echo "# steps: 4"; echo "# csrc_sha256: $SHA"; echo "# git_head: ${GIT_HEAD:-unknown}"; echo "# gemm_mode: ${DUPL_GEMM:-f16x3}"; echo "# workload: python bench.py --single-stream --steps 3 --warmup 1 (VOC 448^2, 4 img/GPU, phase B)";
   python $R/tools/rocpd_pmc.py $(find /tmp/prof_$TAG/b -name '*.db' | head -1) $(find /tmp/prof_$TAG/c -name '*.db' | head -1); } > $OUT/${TAG}_pmc_hbm.txt 2>&1
 rm -rf /tmp/prof_$TAG
 # the un-profiled default bench line goes last: its roofline.traffic is read from the PMC summary just produced
