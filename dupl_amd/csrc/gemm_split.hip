@@ -1750,7 +1750,42 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         const int nb22 = ((d->M + 255) / 256) * ((d->N + 255) / 256), nb21 = ((d->M + 255) / 256) * ((d->N + 127) / 128);
         int t = (g16_tile == 8 || g16_tile == 12 || g16_tile == 14) ? g16_tile : (nb22 >= g16_f1_big_from ? 8 : 12);
         if (d->K / TBK < 3 && t == 14) t = 12;
-        if (t == 8) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), blocks(256, 256), dim3(512), 0, s, *d, g16_group_ring);
+        if (t == 8) {
+            // One block per CU and launch: nb22 tiles take ceil(nb22 / 256) rounds, and a last round that holds a few tiles costs as
+            // much as a full one.  The merged ms-CAM / training pass of a step is exactly that case -- 21 976 rows = 86 row tiles, x
+            // {12, 9, 3} column tiles = 1 032 / 774 / 258 tiles = 4, 3, 1 full rounds + 8 / 6 / 2 tiles (rocprofv3, one stream: 340 us
+            // per launch where 6 280 + 15 696 rows took 290).  So: when the last round would be less than 30 % full, the rows of
+            // the full rounds go to this kernel and the remaining row tiles to the 256 x 128 kernel (rows are independent: two
+            // launches on the stream, each on its own row range of every operand).  Next to a second stream the tail is filled by
+            // the other student's blocks anyway; alone this is worth 9-22 % per launch.
+            const int cn = (d->N + 255) / 256, rm = (d->M + 255) / 256, cus = 256;
+            const int full = nb22 / cus, tail = nb22 - full * cus;
+            const int r_big = full > 0 ? (full * cus) / cn : 0;
+            if (g16_tile == 0 && full > 0 && tail > 0 && tail * 10 < cus * 3 && r_big > 0 && r_big < rm && !d->amax_out) {
+                const int M1 = r_big * 256;
+                dupl_gemm16_desc d1 = *d, d2 = *d;
+                d1.M = M1;
+                d2.M = d->M - M1;
+                auto adv = [&](const void* q, size_t elems, size_t bytes) { return q ? static_cast<const void*>(static_cast<const char*>(q) + elems * bytes) : nullptr; };
+                d2.A_hi = adv(d->A_hi, (size_t)M1 * d->lda, 2); d2.A_lo = adv(d->A_lo, (size_t)M1 * d->lda, 2);
+                d2.C = (float*)adv(d->C, (size_t)M1 * d->ldc, 4);
+                d2.C_hi = (void*)adv(d->C_hi, (size_t)M1 * d->ldo, 2); d2.C_lo = (void*)adv(d->C_lo, (size_t)M1 * d->ldo, 2);
+                d2.res = (const float*)adv(d->res, (size_t)M1 * d->ldr, 4);
+                d2.aux = (float*)adv(d->aux, (size_t)M1 * d->ldaux, 4);
+                if (d->c_rows > 0) {             // fp32 outputs for the first c_rows rows only
+                    if (d->c_rows <= M1) {       // ... all of them in part 1: part 2 writes planes only
+                        d2.c_rows = 0; d2.C = nullptr; d2.aux = nullptr; d2.flags &= ~DUPL_GEMM_STORE_PRE;
+                    } else { d1.c_rows = 0; d2.c_rows = d->c_rows - M1; }
+                }
+                if (d2.C || d2.C_hi) {
+                    hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), dim3((unsigned)(r_big * cn)), dim3(512), 0, s, d1, g16_group_ring);
+                    hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2, 3, true>),
+                                       dim3((unsigned)(((d2.M + 255) / 256) * ((d2.N + 127) / 128))), dim3(512), 0, s, d2, g16_group_ring);
+                    return dupl_launch_status();
+                }
+            }
+            hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), blocks(256, 256), dim3(512), 0, s, *d, g16_group_ring);
+        }
         else if (t == 12) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2, 3, true>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
         else
             hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2, false, true, 3>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);

@@ -129,9 +129,12 @@ SK_DGRAD_MAX_COLS = 1024
 ZERO_WS = os.environ.get("DUPL_ZERO_WS", "1") != "0"
 # AdamW writes the operand planes of the parameters it updates (no split pass over all weights before the next forward)
 FUSED_PLANES = os.environ.get("DUPL_ADAMW_PLANES", "1") != "0"
-# a training step's ms-CAM scales and its training forward as ONE encoder pass (cam_logits_shared_multi); 0: scale 1.0 (saved) and
-# the remaining scales as two passes (round 4)
-MERGED_PASS = os.environ.get("DUPL_MERGED_PASS", "1") != "0"
+# a training step's ms-CAM scales and its training forward as ONE encoder pass (cam_logits_shared_multi) while the pass has at most
+# this many token rows; above (and with 0): scale 1.0 (saved) and the remaining scales as two passes (round 4).  Measured, same box:
+# 2 img/GPU (10 988 rows) 29.46 vs 30.29 ms per step merged (one stream: 37.0 vs 39.4); 4 img/GPU (21 976 rows) 53.7 vs 52.6 (63.0 vs
+# 61.5) -- at 21 976 rows the widest activation of a block (the GELU output planes, 270 MB) no longer fits the 256 MB Infinity
+# Cache between the GEMM that writes it and the one that reads it
+MERGED_PASS = int(os.environ.get("DUPL_MERGED_PASS", "16384"))
 # the attention forward of all batches of a merged pass as ONE launch (ops.attention_fwd16_segs) while it has at most this many
 # 128-query blocks (0: always one launch per batch).  Measured, two student streams, same box: 2 img/GPU (1 104 blocks) 28.87 vs
 # 29.27 ms per step with the single launch; 4 img/GPU (2 208 blocks) 52.07 vs 51.80 -- a grid that holds every block slot of the chip

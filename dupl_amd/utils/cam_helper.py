@@ -41,7 +41,8 @@ def _ms_cam(P, inputs, scales, share=None):
             # scale 1.0 runs WITH activation saving and doubles as the training forward; the remaining scales share
             # one merged no-grad pass (engine.cam_logits_multi)
             share["x"] = xs[0][:b]
-            if engine.MERGED_PASS and len(xs) > 1 and engine.partial_save_ok(P):
+            rows_all = sum(x_.shape[0] * ((x_.shape[2] // patch) * (x_.shape[3] // patch) + 1) for x_ in xs)
+            if len(xs) > 1 and rows_all <= engine.MERGED_PASS and engine.partial_save_ok(P):
                 # round 5: every scale AND the training forward in one encoder pass (21 976 token rows at 448^2, 4 images)
                 res, share["enc"] = engine.cam_logits_shared_multi(P, xs, b)
             else:

@@ -1238,7 +1238,7 @@ def test_merged_encoder_pass_is_bit_identical_to_separate_passes(dev):
 
     def run(merged):
         prev, prev_segs = engine.MERGED_PASS, engine.ATTN_SEGS
-        engine.MERGED_PASS = merged
+        engine.MERGED_PASS = (1 << 30) if merged else 0
         engine.ATTN_SEGS = 1 << 30        # ... with the attention forward of all three batches as one segmented launch
         ops.set_deterministic(1)
         try:
