@@ -24,3 +24,58 @@ def assert_labels_equal_up_to_ties(got, ref, margin, name, tol=TIE_TOL, max_frac
     assert worst < tol, f"{name}: a mismatching pixel has decision margin {worst:.3e} >= {tol:.0e}: not a tie"
     assert n <= max(2, int(max_frac * ref.numel())), f"{name}: {n} mismatches is more than round-off ties explain"
     return n, worst
+
+
+def decoder_relu_flips(model, pp, pc, x_dev):
+    """({"branchK.": (flipped conv6 decisions, flipped conv7 decisions, largest |oracle pre-activation| / layer max among them)},
+    [the product's masks (B, 512, h, w) in the order the oracle applies its ReLUs: student 1 conv6, conv7, student 2 conv6, conv7]):
+    the ReLU masks of the product's LargeFOV forward against the oracle's (conv_head.py:32-41 on the oracle's own x4)."""
+    import torch.nn.functional as F
+    from dupl_amd import engine
+    out, masks = {}, []
+    for s_, net in enumerate((model.branch1, model.branch2)):
+        br = f"branch{s_ + 1}."
+        with torch.no_grad():
+            _, sv = engine.network_forward(net._P, x_dev, save=True)
+        torch.cuda.synchronize()
+        x4 = pc[f"fmap_{s_ + 1}"].float()
+        B, _, h, w = x4.shape
+        W6, W7 = pp[br + "decoder.conv6.weight"], pp[br + "decoder.conv7.weight"]
+        pre6 = F.conv2d(x4, W6, padding=5, dilation=5)
+        pre7 = F.conv2d(F.relu(pre6), W7, padding=5, dilation=5)
+        res = []
+        worst = 0.0
+        for pre, got in ((pre6, sv.h6), (pre7, sv.h7)):
+            g = got.view(B, h * w, -1).permute(0, 2, 1).reshape(B, -1, h, w).cpu() > 0
+            masks.append(g)
+            f = g != (pre > 0)
+            res.append(int(f.sum()))
+            if res[-1]:
+                worst = max(worst, float(pre.abs()[f].max() / pre.abs().max()))
+        out[br] = (res[0], res[1], worst)
+    return out, masks
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def oracle_relu_masks(masks):
+    """Run the oracle with the PRODUCT's LargeFOV ReLU decisions imposed: inside the block torch.nn.functional.relu multiplies a 4-D
+    input whose shape matches the next mask by that mask (the oracle's four LargeFOV ReLUs of the main forward, in call order:
+    student 1 conv6, conv7, student 2 conv6, conv7) and is the ordinary ReLU otherwise.  Yields the one-element list [masks used]."""
+    import torch.nn.functional as F
+    used, orig = [0], F.relu
+
+    def relu_with_product_mask(x, *a, **kw):
+        i = used[0]
+        if i < len(masks) and x.dim() == 4 and tuple(x.shape) == tuple(masks[i].shape):
+            used[0] += 1
+            return x * masks[i].to(x.dtype)
+        return orig(x, *a, **kw)
+
+    F.relu = relu_with_product_mask
+    try:
+        yield used
+    finally:
+        F.relu = orig

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from parity_util import assert_labels_equal_up_to_ties
+from parity_util import assert_labels_equal_up_to_ties, decoder_relu_flips as _decoder_relu_flips, oracle_relu_masks
 
 pytestmark = pytest.mark.gpu
 
@@ -627,25 +627,12 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     if nflip:
         # the proof: the oracle run AGAIN with the product's ReLU decisions imposed on its LargeFOV (everything else untouched) must
         # put every tensor back under the strict bar -- then the flipped decisions are the whole difference
-        import torch.nn.functional as F
-        used, orig = [0], F.relu
-
-        def relu_with_product_mask(x, *a, **kw):       # the oracle's LargeFOV ReLUs of the main forward, in call order
-            i = used[0]
-            if i < len(masks) and x.dim() == 4 and tuple(x.shape) == tuple(masks[i].shape):
-                used[0] += 1
-                return x * masks[i].to(x.dtype)
-            return orig(x, *a, **kw)
-
         leaf2 = {k: v.clone().requires_grad_(k in watch) for k, v in pp.items()}
-        F.relu = relu_with_product_mask
-        try:
+        with oracle_relu_masks(masks) as used:
             if case == "voc_C":
                 random.seed(77)
             ref2, _ = O.train_step_losses(leaf2, inputs, cls_label, img_box, n_iter, cfg, oargs, inputs_aug=aug)
             ref2.sum().backward()
-        finally:
-            F.relu = orig
         assert used[0] == len(masks), "the oracle did not pass through its four LargeFOV ReLUs in the expected order"
         for k in watch:
             got = model.flat_storage.view(0 if k.startswith("branch1.") else 1, k.split(".", 1)[1], grad=True).cpu()
@@ -655,36 +642,6 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
               f"{errs[order[-1]]:.2e} ({order[-1]}), bar {bar:.0e}")
     bad = [(k, errs[k]) for k in order if not errs[k] < bar]
     assert not bad, f"{len(bad)} gradient tensors above {bar:.0e}: {bad[:8]}"
-
-
-def _decoder_relu_flips(model, pp, pc, x_dev):
-    """({"branchK.": (flipped conv6 decisions, flipped conv7 decisions, largest |oracle pre-activation| / layer max among them)},
-    [the product's masks (B, 512, h, w) in the order the oracle applies its ReLUs: student 1 conv6, conv7, student 2 conv6, conv7]):
-    the ReLU masks of the product's LargeFOV forward against the oracle's (conv_head.py:32-41 on the oracle's own x4)."""
-    import torch.nn.functional as F
-    from dupl_amd import engine
-    out, masks = {}, []
-    for s_, net in enumerate((model.branch1, model.branch2)):
-        br = f"branch{s_ + 1}."
-        with torch.no_grad():
-            _, sv = engine.network_forward(net._P, x_dev, save=True)
-        torch.cuda.synchronize()
-        x4 = pc[f"fmap_{s_ + 1}"].float()
-        B, _, h, w = x4.shape
-        W6, W7 = pp[br + "decoder.conv6.weight"], pp[br + "decoder.conv7.weight"]
-        pre6 = F.conv2d(x4, W6, padding=5, dilation=5)
-        pre7 = F.conv2d(F.relu(pre6), W7, padding=5, dilation=5)
-        res = []
-        worst = 0.0
-        for pre, got in ((pre6, sv.h6), (pre7, sv.h7)):
-            g = got.view(B, h * w, -1).permute(0, 2, 1).reshape(B, -1, h, w).cpu() > 0
-            masks.append(g)
-            f = g != (pre > 0)
-            res.append(int(f.sum()))
-            if res[-1]:
-                worst = max(worst, float(pre.abs()[f].max() / pre.abs().max()))
-        out[br] = (res[0], res[1], worst)
-    return out, masks
 
 
 @pytest.mark.parametrize("b,H,W", [(1, 96, 160), (3, 128, 96), (2, 80, 80)])

@@ -217,10 +217,37 @@ def test_full_size_two_steps_voc_b_bs4_vs_oracle(dev):
             order = sorted(errs, key=errs.get)
             print(f"two-step voc_B_bs4, step 2 gradients at the product's step-1 parameters: {len(errs)} tensors, median "
                   f"{errs[order[len(order) // 2]]:.2e}, worst {errs[order[-1]]:.2e} ({order[-1]})")
-            # decoder ReLU decisions at round-off level can move a dW6 / dW7 row by ~1/1568 (test_full_size_vitb_step_vs_oracle
-            # proves that case by case); here the bar for the decoder tensors is that proven ceiling, the strict one elsewhere
+            # Strict bar on every tensor.  The LargeFOV ReLUs are decisions (a pre-activation at round-off level falls on either side of
+            # 0 in two fp32 implementations; one flipped (token, channel) moves a dW6 / dW7 row by ~1 / 3136 and everything below
+            # through dtf): a tensor above the bar is accepted only with the proof of test_full_size_vitb_step_vs_oracle -- the
+            # product's ReLU masks at THESE parameters (a second model loaded with them) differ from the oracle's only where the
+            # oracle's pre-activation is < 1e-4 of the layer maximum, and the oracle re-run with the product's decisions imposed
+            # puts every tensor back under the strict bar.
+            bar = 2e-4
+            if any(not errs[k] < bar for k in order):
+                from parity_util import decoder_relu_flips, oracle_relu_masks
+                probe = siamese_network("deit_base_patch16_224", num_classes=NC, pretrained=False, aux_layer=-3)
+                probe.load_state_dict(before, strict=True)
+                probe.to(dev)
+                flips, masks = decoder_relu_flips(probe, before, pc, inputs.to(dev))
+                del probe
+                nflip = 0
+                for br, (n6, n7, worst) in flips.items():
+                    print(f"two-step {br} decoder ReLU decisions that differ from the oracle's: conv6 {n6}, conv7 {n7}; largest |oracle "
+                          f"pre-activation| among them {worst:.2e} of the layer maximum (bar 1e-4)")
+                    assert worst < 1e-4, "a ReLU decision differs where the oracle's pre-activation is NOT at round-off level"
+                    nflip += n6 + n7
+                assert nflip > 0, ("gradients above the bar without a flipped ReLU decision", [(k, errs[k]) for k in order[-4:]])
+                leaf2 = {k: v.clone().requires_grad_(k in watch) for k, v in before.items()}
+                with oracle_relu_masks(masks) as used:
+                    ref2, _ = O.train_step_losses(leaf2, inputs, cls_label, img_box, n_iter, cfg, oargs)
+                    ref2.sum().backward()
+                assert used[0] == len(masks)
+                errs = {k: float((g_prod[k] - leaf2[k].grad).abs().max() / leaf2[k].grad.abs().max().clamp_min(1e-30)) for k in watch}
+                order = sorted(errs, key=errs.get)
+                print(f"two-step voc_B_bs4, step 2 gradients vs the oracle with the product's {nflip} flipped ReLU decision(s) imposed: worst "
+                      f"{errs[order[-1]]:.2e} ({order[-1]})")
             for k in order:
-                bar = 2e-3 if ".decoder." in k else 2e-4
                 assert errs[k] < bar, (k, errs[k])
         # the update: schedule position 5000 + it (poly decay), AdamW's own bias-correction count it + 1 (a fresh optimiser)
         host = {k: v.clone() for k, v in before.items()}
