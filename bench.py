@@ -329,6 +329,7 @@ class GemmTimer:
         from dupl_amd import ops
         self._orig, self._orig16 = ops.gemm_raw, ops.linear16
         self._orig_af, self._orig_ab = ops.attention_fwd16, ops.attention_bwd16
+        self._orig_afs = ops.attention_fwd16_segs
         self._orig_wg = ops.wgrad16_group
         timer = self
 
@@ -383,14 +384,20 @@ class GemmTimer:
             timer.fam_bytes["wgrad"] += by
             return r
 
+        def timed_afs(qkv16, segs, H, hd, scale, *a, **kw):     # several batches in one launch: the same 4 N^2 hd per (image, head)
+            return timer._timed_family("attention_fwd", lambda: timer._orig_afs(qkv16, segs, H, hd, scale, *a, **kw),
+                                       sum(4.0 * sg[1] * H * sg[2] * sg[2] * hd for sg in segs))
+
         ops.gemm_raw, ops.linear16 = timed, timed16
         ops.attention_fwd16, ops.attention_bwd16 = timed_af, timed_ab
+        ops.attention_fwd16_segs = timed_afs
         ops.wgrad16_group = timed_wg
 
     def remove(self):
         from dupl_amd import ops
         ops.gemm_raw, ops.linear16 = self._orig, self._orig16
         ops.attention_fwd16, ops.attention_bwd16 = self._orig_af, self._orig_ab
+        ops.attention_fwd16_segs = self._orig_afs
         ops.wgrad16_group = self._orig_wg
 
     def reset(self):
