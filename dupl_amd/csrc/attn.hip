@@ -431,29 +431,27 @@ constexpr int g_attn_remap = 1;   // XCD-aware block order (whole heads per XCD)
 
 extern "C" int dupl_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H, int32_t hd,
                                   float scale, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!qkv || !out || B <= 0 || N <= 0 || H <= 0 || (hd != 32 && hd != 64)) return DUPL_ERR_ARG;
     dim3 grid((N + 127) / 128, H, B), block(ANT);
-    if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale, g_attn_remap);
-    else hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale, g_attn_remap);
+    if (hd == 64) DUPL_LAUNCH(attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale, g_attn_remap);
+    else DUPL_LAUNCH(attn_fwd_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, out, lse, N, H, scale, g_attn_remap);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta,
                                   float* dqkv, int32_t B, int32_t N, int32_t H, int32_t hd, float scale, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || N <= 0 || H <= 0 || (hd != 32 && hd != 64))
         return DUPL_ERR_ARG;
     const long total = (long)B * N * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, out, dout,
+    DUPL_LAUNCH(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, out, dout,
                        delta, B, N, H, hd);
     dim3 grid((N + 127) / 128, H, B), block(ANT);
     if (hd == 64) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
+        DUPL_LAUNCH(attn_bwd_dq_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
+        DUPL_LAUNCH(attn_bwd_dkv_kernel<64>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
+        DUPL_LAUNCH(attn_bwd_dq_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
+        DUPL_LAUNCH(attn_bwd_dkv_kernel<32>, grid, block, 0, (hipStream_t)s, qkv, dout, lse, delta, dqkv, N, H, scale, g_attn_remap);
     }
     return dupl_launch_status();
 }

@@ -427,7 +427,7 @@ static int attn_fwd16_launch(const void* qkv_hi, const void* qkv_lo, void* out_h
         total += ((q.N + 127) / 128) * H * q.B;
     }
     g.first[n] = total;
-    hipLaunchKernelGGL(attn_fwd16_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi, (const __half*)qkv_lo,
+    DUPL_LAUNCH(attn_fwd16_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)s, (const __half*)qkv_hi, (const __half*)qkv_lo,
                        (__half*)out_hi, (__half*)out_lo, g, H, scale, g_attn16_remap, out_exp ? ldexpf(1.f, out_exp) : 0.f);
     return dupl_launch_status();
 }
@@ -435,7 +435,6 @@ static int attn_fwd16_launch(const void* qkv_hi, const void* qkv_lo, void* out_h
 extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, float* out, void* out_hi, void* out_lo, float* lse,
                                     int32_t B, int32_t N, int32_t H, int32_t hd, float scale, int32_t B_f32, int32_t out_exp,
                                     dupl_stream_t s) {
-    (void)hipGetLastError();
     if (B_f32 < 0 || B_f32 > B || (B_f32 != 0 && B_f32 < B && !out_hi) || (!out && !out_hi)) return DUPL_ERR_ARG;
     dupl_attn_seg q;
     q.row0 = 0; q.B = B; q.N = N; q.B_f32 = B_f32; q.out = out; q.lse = lse;
@@ -444,6 +443,5 @@ extern "C" int dupl_attention_fwd16(const void* qkv_hi, const void* qkv_lo, floa
 
 extern "C" int dupl_attention_fwd16_segs(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, const dupl_attn_seg* segs,
                                          int32_t n, int32_t H, int32_t hd, float scale, int32_t out_exp, dupl_stream_t s) {
-    (void)hipGetLastError();
     return attn_fwd16_launch(qkv_hi, qkv_lo, out_hi, out_lo, segs, n, H, hd, scale, out_exp, s);
 }

@@ -469,16 +469,15 @@ constexpr int g_attnb16_remap = 1;     // XCD-aware workgroup order
 extern "C" int dupl_attention_bwd16(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const void* do_hi,
                                     const void* do_lo, const float* do_slot, const float* lse, float* delta, float* dqkv, int32_t B,
                                     int32_t N, int32_t H, int32_t hd, float scale, void* amax_out, dupl_stream_t stream) {
-    (void)hipGetLastError();
     unsigned int* ax = static_cast<unsigned int*>(amax_out);
     if (!qkv_hi || !qkv_lo || !out || !dout || !do_hi || !do_lo || !do_slot || !lse || !delta || !dqkv || B <= 0 || N <= 0 ||
         N > MAXN || H <= 0 || hd != HD)
         return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * N * H;
-    hipLaunchKernelGGL(delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, delta, B, N, H);
+    DUPL_LAUNCH(delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, delta, B, N, H);
     const unsigned blocks = 3u * (unsigned)(((N + 127) / 128) * H * B);
-    hipLaunchKernelGGL(attn_bwd16_all_kernel, dim3(blocks), dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo,
+    DUPL_LAUNCH(attn_bwd16_all_kernel, dim3(blocks), dim3(256), 0, s, (const __half*)qkv_hi, (const __half*)qkv_lo,
                        (const __half*)do_hi, (const __half*)do_lo, lse, delta, do_slot, dqkv, ax, N, H, B, scale, g_attnb16_remap);
     return dupl_launch_status();
 }

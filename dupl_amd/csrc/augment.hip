@@ -158,60 +158,54 @@ __global__ void finish_kernel(const uint8_t* __restrict__ img, float* __restrict
 }  // namespace
 
 extern "C" int dupl_aug_to_u8(const float* x, uint8_t* out, int64_t n, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !out || n <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(to_u8_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, out, (long)n);
+    DUPL_LAUNCH(to_u8_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, out, (long)n);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_aug_lut_op(uint8_t* img, int32_t H, int32_t W, int32_t mode, uint32_t* hist_scratch, uint8_t* lut_scratch,
                                dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!img || !hist_scratch || !lut_scratch || H <= 0 || W <= 0 || mode < 0 || mode > 1) return DUPL_ERR_ARG;
     const int HW = H * W;
     if (hipMemsetAsync(hist_scratch, 0, 3 * 256 * sizeof(uint32_t), (hipStream_t)s) != hipSuccess) return DUPL_ERR_LAUNCH;
     int gx = (HW + 256 * 16 - 1) / (256 * 16);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(hist_kernel, dim3(gx, 3), dim3(256), 0, (hipStream_t)s, img, hist_scratch, HW);
-    hipLaunchKernelGGL(lut_kernel, dim3(3), dim3(256), 0, (hipStream_t)s, hist_scratch, lut_scratch, mode);
-    hipLaunchKernelGGL(lut_apply_kernel, dim3(ew_grid(HW), 3), dim3(256), 0, (hipStream_t)s, img, lut_scratch, HW);
+    DUPL_LAUNCH(hist_kernel, dim3(gx, 3), dim3(256), 0, (hipStream_t)s, img, hist_scratch, HW);
+    DUPL_LAUNCH(lut_kernel, dim3(3), dim3(256), 0, (hipStream_t)s, hist_scratch, lut_scratch, mode);
+    DUPL_LAUNCH(lut_apply_kernel, dim3(ew_grid(HW), 3), dim3(256), 0, (hipStream_t)s, img, lut_scratch, HW);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_aug_posterize(uint8_t* img, int64_t n, int32_t bits, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!img || n <= 0 || bits < 1 || bits > 8) return DUPL_ERR_ARG;
     const int mask = ~((1 << (8 - bits)) - 1) & 0xFF;
-    hipLaunchKernelGGL(and_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, img, mask, (long)n);
+    DUPL_LAUNCH(and_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, img, mask, (long)n);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_aug_enhance(uint8_t* img, int32_t H, int32_t W, int32_t mode, float factor, uint64_t* sum_scratch,
                                 dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!img || H <= 0 || W <= 0 || mode < 0 || mode > 2 || (mode == 1 && !sum_scratch)) return DUPL_ERR_ARG;
     const int HW = H * W;
     if (mode == 1) {
         if (hipMemsetAsync(sum_scratch, 0, sizeof(uint64_t), (hipStream_t)s) != hipSuccess) return DUPL_ERR_LAUNCH;
         int gx = (HW + 256 * 8 - 1) / (256 * 8);
         if (gx > 128) gx = 128;
-        hipLaunchKernelGGL(luma_sum_kernel, dim3(gx), dim3(256), 0, (hipStream_t)s, img, (unsigned long long*)sum_scratch, HW);
+        DUPL_LAUNCH(luma_sum_kernel, dim3(gx), dim3(256), 0, (hipStream_t)s, img, (unsigned long long*)sum_scratch, HW);
     }
-    hipLaunchKernelGGL(enhance_kernel, dim3(ew_grid(HW)), dim3(256), 0, (hipStream_t)s, img,
+    DUPL_LAUNCH(enhance_kernel, dim3(ew_grid(HW)), dim3(256), 0, (hipStream_t)s, img,
                        (const unsigned long long*)sum_scratch, HW, factor, mode);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_aug_sharpness(const uint8_t* in, uint8_t* out, int32_t H, int32_t W, float factor, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!in || !out || in == out || H <= 0 || W <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(sharpness_kernel, dim3(ew_grid(3L * H * W)), dim3(256), 0, (hipStream_t)s, in, out, H, W, factor);
+    DUPL_LAUNCH(sharpness_kernel, dim3(ew_grid(3L * H * W)), dim3(256), 0, (hipStream_t)s, in, out, H, W, factor);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_aug_finish(const uint8_t* img, float* out, int32_t H, int32_t W, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!img || !out || H <= 0 || W <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(finish_kernel, dim3(ew_grid(3L * H * W)), dim3(256), 0, (hipStream_t)s, img, out, H, W);
+    DUPL_LAUNCH(finish_kernel, dim3(ew_grid(3L * H * W)), dim3(256), 0, (hipStream_t)s, img, out, H, W);
     return dupl_launch_status();
 }

@@ -346,10 +346,9 @@ inline int ew_grid(long n) {
 
 extern "C" int dupl_resize_bilinear(const float* in, float* out, int32_t B, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
                                     int32_t Wo, int32_t flip_cat, int32_t align_corners, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!in || !out || B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return DUPL_ERR_ARG;
     const long total = (long)B * C * Ho * Wo;
-    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, in, out, B, C, Hi, Wi, Ho,
+    DUPL_LAUNCH(resize_bilinear_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, in, out, B, C, Hi, Wi, Ho,
                        Wo, flip_cat, align_corners);
     return dupl_launch_status();
 }
@@ -360,7 +359,6 @@ extern "C" int dupl_resize_bilinear(const float* in, float* out, int32_t B, int3
 extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const int32_t* ws, int32_t nscale, int32_t row_off,
                              int32_t ldc, float* cam, float* mm, int32_t B, int32_t C, int32_t H, int32_t W, int32_t impl,
                              int32_t band_blocks, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!lows || !hs || !ws || nscale <= 0 || nscale > 4 || !cam || !mm || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldc < C)
         return DUPL_ERR_ARG;
     if (impl < 0 || impl > 1 || band_blocks < 0 || band_blocks > (1 << 20)) return DUPL_ERR_ARG;
@@ -373,7 +371,7 @@ extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const 
     }
     d.nscale = nscale; d.row_off = row_off; d.ldc = ldc;
     const int planes = B * C;
-    hipLaunchKernelGGL(minmax_init_kernel, dim3((planes + 255) / 256), dim3(256), 0, (hipStream_t)s, mm, planes);
+    DUPL_LAUNCH(minmax_init_kernel, dim3((planes + 255) / 256), dim3(256), 0, (hipStream_t)s, mm, planes);
     bool ws_ok = true;             // tap columns travel as 16-bit pairs
     for (int i = 0; i < nscale; ++i) ws_ok = ws_ok && ws[i] < 32768;
     if (g_cam_fuse_impl == 1 && !(W & 3) && W <= 1024 && ws_ok && !(reinterpret_cast<uintptr_t>(cam) & 15)) {
@@ -389,9 +387,9 @@ extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const 
                 const dim3 grid((H + band - 1) / band, planes);
 #define CAM_BAND(NS_)                                                                                                            \
     if (W <= 512)                                                                                                                \
-        hipLaunchKernelGGL((cam_fuse_band_kernel<NS_, 2>), grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); \
+        DUPL_LAUNCH((cam_fuse_band_kernel<NS_, 2>), grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band); \
     else                                                                                                                         \
-        hipLaunchKernelGGL((cam_fuse_band_kernel<NS_, 4>), grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band)
+        DUPL_LAUNCH((cam_fuse_band_kernel<NS_, 4>), grid, dim3(256), need, (hipStream_t)s, d, cam, mm, B, C, H, W, band)
                 switch (nscale) {
                     case 1: CAM_BAND(1); break;
                     case 2: CAM_BAND(2); break;
@@ -405,41 +403,38 @@ extern "C" int dupl_cam_fuse(const float* const* lows, const int32_t* hs, const 
     }
     int gx = (H * W + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(cam_fuse_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)s, d, cam, mm, B, C, H, W);
+    DUPL_LAUNCH(cam_fuse_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)s, d, cam, mm, B, C, H, W);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_cam_minmax_normalise(float* cam, float* mm, int32_t planes, int32_t HW, int32_t have_minmax,
                                          dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!cam || !mm || planes <= 0 || HW <= 0) return DUPL_ERR_ARG;
     int gx = (HW + 1023) / 1024;
     if (gx > 64) gx = 64;
     if (!have_minmax) {
-        hipLaunchKernelGGL(minmax_init_kernel, dim3((planes + 255) / 256), dim3(256), 0, (hipStream_t)s, mm, planes);
-        hipLaunchKernelGGL(plane_minmax_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)s, cam, mm, HW);
+        DUPL_LAUNCH(minmax_init_kernel, dim3((planes + 255) / 256), dim3(256), 0, (hipStream_t)s, mm, planes);
+        DUPL_LAUNCH(plane_minmax_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)s, cam, mm, HW);
     }
-    hipLaunchKernelGGL(cam_normalise_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)s, cam, mm, HW);
+    DUPL_LAUNCH(cam_normalise_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)s, cam, mm, HW);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_cam_to_label(const float* cam, const float* cls_label, const int32_t* img_box, const float* high_thre,
                                  float bkg_thre, float low_thre, int32_t ignore_mid, int32_t ignore_index, int64_t* label,
                                  float* valid_cam, int32_t b, int32_t C, int32_t h, int32_t w, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!cam || !cls_label || !label || b <= 0 || C <= 0 || h <= 0 || w <= 0) return DUPL_ERR_ARG;
     if (img_box && ignore_mid && !high_thre) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(cam_to_label_kernel, dim3(ew_grid((long)b * h * w)), dim3(256), 0, (hipStream_t)s, cam, cls_label,
+    DUPL_LAUNCH(cam_to_label_kernel, dim3(ew_grid((long)b * h * w)), dim3(256), 0, (hipStream_t)s, cam, cls_label,
                        img_box, high_thre, bkg_thre, low_thre, ignore_mid, ignore_index, (long long*)label, valid_cam, b, C, h, w);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_denormalize_img(const float* x, float* out, int32_t B, int32_t HW, const float* mean_std, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !out || B <= 0 || HW <= 0) return DUPL_ERR_ARG;
     MeanStd ms = {{123.675f, 116.28f, 103.53f}, {58.395f, 57.12f, 57.375f}};     // imutils.py:17 defaults
     if (mean_std)
         for (int c = 0; c < 3; ++c) { ms.mean[c] = mean_std[c]; ms.stdv[c] = mean_std[3 + c]; }
-    hipLaunchKernelGGL(denormalize_kernel, dim3(ew_grid((long)B * 3 * HW)), dim3(256), 0, (hipStream_t)s, x, out, B, HW, ms);
+    DUPL_LAUNCH(denormalize_kernel, dim3(ew_grid((long)B * 3 * HW)), dim3(256), 0, (hipStream_t)s, x, out, B, HW, ms);
     return dupl_launch_status();
 }

@@ -56,18 +56,16 @@ inline int ew_grid(long n) {
 
 extern "C" int dupl_im2col_dil3(const float* x, float* col, int32_t B, int32_t h, int32_t w, int32_t Cin, int32_t dil, int64_t ld,
                                 int64_t img_stride, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !col || B <= 0 || h <= 0 || w <= 0 || Cin <= 0 || dil <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(im2col_dil3_kernel, dim3(ew_grid((long)B * h * w * Cin)), dim3(256), 0, (hipStream_t)s, x, col, B, h, w,
+    DUPL_LAUNCH(im2col_dil3_kernel, dim3(ew_grid((long)B * h * w * Cin)), dim3(256), 0, (hipStream_t)s, x, col, B, h, w,
                        Cin, dil, (long)ld, (long)img_stride);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_col2im_dil3(const float* dcol, float* dx, int32_t B, int32_t h, int32_t w, int32_t Cin, int32_t dil, int64_t ld,
                                 int64_t img_stride, int32_t accumulate, const float* relu_of, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dcol || !dx || B <= 0 || h <= 0 || w <= 0 || Cin <= 0 || dil <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(col2im_dil3_kernel, dim3(ew_grid((long)B * h * w * Cin)), dim3(256), 0, (hipStream_t)s, dcol, dx, B, h, w,
+    DUPL_LAUNCH(col2im_dil3_kernel, dim3(ew_grid((long)B * h * w * Cin)), dim3(256), 0, (hipStream_t)s, dcol, dx, B, h, w,
                        Cin, dil, (long)ld, (long)img_stride, accumulate, relu_of);
     return dupl_launch_status();
 }

@@ -127,46 +127,41 @@ inline int ew_grid(long n) {
 
 extern "C" int dupl_upsample_argmax(const float* logits, int64_t* out, int32_t B, int32_t C, int32_t h, int32_t w, int32_t H,
                                     int32_t W, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!logits || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(upsample_argmax_kernel, dim3(ew_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)s, logits,
+    DUPL_LAUNCH(upsample_argmax_kernel, dim3(ew_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)s, logits,
                        (long long*)out, B, C, h, w, H, W);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_msc_seg_accum(const float* segs, float* acc, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W,
                                   int32_t mode, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!segs || !acc || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(msc_seg_accum_kernel, dim3(ew_grid((long)C * H * W)), dim3(256), 0, (hipStream_t)s, segs, acc, C, h, w,
+    DUPL_LAUNCH(msc_seg_accum_kernel, dim3(ew_grid((long)C * H * W)), dim3(256), 0, (hipStream_t)s, segs, acc, C, h, w,
                        H, W, mode);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_argmax_channels(const float* x, int64_t* out, int32_t B, int32_t C, int64_t HW, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !out || B <= 0 || C <= 0 || HW <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(argmax_channels_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, (hipStream_t)s, x, (long long*)out,
+    DUPL_LAUNCH(argmax_channels_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, (hipStream_t)s, x, (long long*)out,
                        B, C, (long)HW);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_confusion_accum(const int64_t* gt, const int64_t* pred, int64_t n, int32_t num_classes, int64_t* hist,
                                     dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!gt || !pred || !hist || n <= 0 || num_classes <= 0 || num_classes > 4096) return DUPL_ERR_ARG;
     int grid = (int)((n + 256L * 16 - 1) / (256L * 16));
     if (grid > 512) grid = 512;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(confusion_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, (const long long*)gt, (const long long*)pred,
+    DUPL_LAUNCH(confusion_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, (const long long*)gt, (const long long*)pred,
                        (long)n, num_classes, (unsigned long long*)hist);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_multilabel_f1_accum(const float* logits, const float* label, int32_t B, int32_t C, float* sum,
                                         dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!logits || !label || !sum || B <= 0 || C <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(multilabel_f1_kernel, dim3(B), dim3(64), 0, (hipStream_t)s, logits, label, C, sum);
+    DUPL_LAUNCH(multilabel_f1_kernel, dim3(B), dim3(64), 0, (hipStream_t)s, logits, label, C, sum);
     return dupl_launch_status();
 }

@@ -251,7 +251,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const dupl_gemm_desc p, co
 }  // namespace
 
 extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!d || d->struct_size != sizeof(dupl_gemm_desc)) return DUPL_ERR_ARG;       // a caller built against another header
     if (!d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->zdiv <= 0)
         return DUPL_ERR_ARG;
@@ -304,15 +303,15 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     const bool kfull = (d->K % BK) == 0;   // split-K chunks are multiples of BK, so only the global tail matters
 #define DUPL_GEMM_LAUNCH(AM, BNC)                                                                                  \
     do {                                                                                                           \
-        if (n64 && fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 1, 1>), grid, block, 0, s, *d, g_group_m); \
-        else if (n64 && fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 2, 1>), grid, block, 0, s, *d, g_group_m);     \
-        else if (n64) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 0, 1>), grid, block, 0, s, *d, g_group_m);             \
-        else if (small && fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 1>), grid, block, 0, s, *d, g_group_m);  \
-        else if (small && fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 2>), grid, block, 0, s, *d, g_group_m);      \
-        else if (small) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 64, 0>), grid, block, 0, s, *d, g_group_m);              \
-        else if (fast && kfull) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 1>), grid, block, 0, s, *d, g_group_m);     \
-        else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 2>), grid, block, 0, s, *d, g_group_m);              \
-        else hipLaunchKernelGGL((gemm_f32_kernel<AM, BNC, 128, 0>), grid, block, 0, s, *d, g_group_m);                        \
+        if (n64 && fast && kfull) DUPL_LAUNCH((gemm_f32_kernel<AM, BNC, 64, 1, 1>), grid, block, 0, s, *d, g_group_m); \
+        else if (n64 && fast) DUPL_LAUNCH((gemm_f32_kernel<AM, BNC, 64, 2, 1>), grid, block, 0, s, *d, g_group_m);     \
+        else if (n64) DUPL_LAUNCH((gemm_f32_kernel<AM, BNC, 64, 0, 1>), grid, block, 0, s, *d, g_group_m);             \
+        else if (small && fast && kfull) DUPL_LAUNCH((gemm_f32_kernel<AM, BNC, 64, 1>), grid, block, 0, s, *d, g_group_m);  \
+        else if (small && fast) DUPL_LAUNCH((gemm_f32_kernel<AM, BNC, 64, 2>), grid, block, 0, s, *d, g_group_m);      \
+        else if (small) DUPL_LAUNCH((gemm_f32_kernel<AM, BNC, 64, 0>), grid, block, 0, s, *d, g_group_m);              \
+        else if (fast && kfull) DUPL_LAUNCH((gemm_f32_kernel<AM, BNC, 128, 1>), grid, block, 0, s, *d, g_group_m);     \
+        else if (fast) DUPL_LAUNCH((gemm_f32_kernel<AM, BNC, 128, 2>), grid, block, 0, s, *d, g_group_m);              \
+        else DUPL_LAUNCH((gemm_f32_kernel<AM, BNC, 128, 0>), grid, block, 0, s, *d, g_group_m);                        \
     } while (0)
     if (!amc && !bnc) DUPL_GEMM_LAUNCH(false, false);
     else if (!amc && bnc) DUPL_GEMM_LAUNCH(false, true);

@@ -1575,32 +1575,29 @@ constexpr int G16_GROUP_RING = 2;   // row tiles (256 rows) per group of the rin
 constexpr int G16_F1_BIG_FROM = 96; // format 1: 256 x 256 tiles from this many of them
 
 extern "C" int dupl_split_f16x2(const float* x, void* hi, void* lo, int64_t n, dupl_stream_t stream) {
-    (void)hipGetLastError();
     if (!x || !hi || !lo || n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(hi) & 7) ||
         (reinterpret_cast<uintptr_t>(lo) & 7))
         return DUPL_ERR_ARG;
     const long n4 = n / 4;
     long g = (n4 + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(split_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4, 1.f);
+    DUPL_LAUNCH(split_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4, 1.f);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_split_f16x2b(const float* x, void* hi, void* lo, int64_t n, int32_t scale_exp, dupl_stream_t stream) {
-    (void)hipGetLastError();
     if (!x || !hi || !lo || n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(hi) & 7) ||
         (reinterpret_cast<uintptr_t>(lo) & 7) || scale_exp < 0 || scale_exp > 15)
         return DUPL_ERR_ARG;
     const long n4 = n / 4;
     long g = (n4 + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(split_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4,
+    DUPL_LAUNCH(split_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (__half*)hi, (__half*)lo, n4,
                        ldexpf(1.f, scale_exp));
     return dupl_launch_status();
 }
 
 extern "C" int dupl_gemm_f16x3_group(const dupl_gemm16_desc* descs, int32_t n, dupl_stream_t stream) {
-    (void)hipGetLastError();
     if (!descs || n < 1 || n > DUPL_GEMM16_GROUP_MAX) return DUPL_ERR_ARG;
     g16_group_args g;
     g.n = n;
@@ -1624,13 +1621,12 @@ extern "C" int dupl_gemm_f16x3_group(const dupl_gemm16_desc* descs, int32_t n, d
         if (d.group) group = d.group;
     }
     g.first[n] = total;
-    hipLaunchKernelGGL((gemm_f16x3_km_group_kernel<2, 2, 4, 2, 2>), dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), 0, (hipStream_t)stream, g,
+    DUPL_LAUNCH((gemm_f16x3_km_group_kernel<2, 2, 4, 2, 2>), dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), 0, (hipStream_t)stream, g,
                        group ? group : G16_GROUP_RING);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) {
-    (void)hipGetLastError();
     if (!d || d->struct_size != sizeof(dupl_gemm16_desc)) return DUPL_ERR_ARG;      // a caller built against another header
     if (!d->A_hi || !d->A_lo || !d->B_hi || !d->B_lo || d->M <= 0 || d->N <= 0 || d->K <= 0) return DUPL_ERR_ARG;
     if ((d->K % TBK) || (d->lda % 8) || (d->ldb % 8)) return DUPL_ERR_ARG;       // whole 16-byte chunks, whole k-tiles
@@ -1732,14 +1728,14 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
             // a data gradient with a LINEAR epilogue (dx = alpha dy . W, nothing else) into a zero-filled dx: stream-K pieces meet in
             // fp32 atomics, so that the N = 768 outputs (78 tiles of 256 x 128 at 4 images, 42 at 2) run on every CU
             if (!d->b_layout || d->deterministic) return DUPL_ERR_ARG;      // (the caller takes the one-block-per-tile form then)
-            hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, false, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, dsk, g16_group_ring);
+            DUPL_LAUNCH((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, false, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, dsk, g16_group_ring);
         } else if (accum) {
             if (!(d->a_layout && d->b_layout)) return DUPL_ERR_ARG;            // the weight gradient: both operands token-major
-            if (sk) hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, true, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, dsk, g16_group_ring);
-            else hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 2, true, true>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
+            if (sk) DUPL_LAUNCH((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, true, 1, true, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, dsk, g16_group_ring);
+            else DUPL_LAUNCH((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 2, true, true>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
         } else {
             if (d->a_layout || !d->b_layout) return DUPL_ERR_ARG;              // the data gradient: dy k-contiguous, W k-major
-            hipLaunchKernelGGL((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 0, false, true>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
+            DUPL_LAUNCH((gemm_f16x3_km_kernel<2, 2, 4, 2, 2, false, 0, false, true>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
         }
         return dupl_launch_status();
     }
@@ -1778,23 +1774,23 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
                     } else { d1.c_rows = 0; d2.c_rows = d->c_rows - M1; }
                 }
                 if (d2.C || d2.C_hi) {
-                    hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), dim3((unsigned)(r_big * cn)), dim3(512), 0, s, d1, g16_group_ring);
-                    hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2, 3, true>),
+                    DUPL_LAUNCH((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), dim3((unsigned)(r_big * cn)), dim3(512), 0, s, d1, g16_group_ring);
+                    DUPL_LAUNCH((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2, 3, true>),
                                        dim3((unsigned)(((d2.M + 255) / 256) * ((d2.N + 127) / 128))), dim3(512), 0, s, d2, g16_group_ring);
                     return dupl_launch_status();
                 }
             }
-            hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), blocks(256, 256), dim3(512), 0, s, *d, g16_group_ring);
+            DUPL_LAUNCH((gemm_f16x3_ring_kernel<4, 2, 2, 4, 2, 2, true>), blocks(256, 256), dim3(512), 0, s, *d, g16_group_ring);
         }
-        else if (t == 12) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2, 3, true>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
+        else if (t == 12) DUPL_LAUNCH((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2, 3, true>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
         else
-            hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2, false, true, 3>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
+            DUPL_LAUNCH((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2, false, true, 3>), persist_grid(nb21), dim3(512), 0, s, *d, g16_group_ring);
         return dupl_launch_status();
     }
     if (tile == 10 && (accum || d->K / TBK < 3)) tile = 6;      // the persistent kernel has no split-K and a 3-stage prologue
     if (tile == 11 && (!accum || d->deterministic || d->K / TBK < 8)) tile = accum ? 5 : 6;   // stream-K: atomics, pieces >= 3 k-steps
     if (tile == 11) {
-        hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d,
+        DUPL_LAUNCH((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2, true>), dim3((unsigned)g16_persist_blocks), dim3(512), 0, s, *d,
                            g16_group_ring);
         return dupl_launch_status();
     }
@@ -1806,13 +1802,13 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         const int tx = (nblk + 7) / 8, bmax = g16_persist_blocks / 8;
         const int rounds = (tx + bmax - 1) / bmax;
         const int grid = 8 * ((tx + rounds - 1) / rounds);
-        hipLaunchKernelGGL((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2>), dim3((unsigned)grid), dim3(512), 0, s, *d, g16_group_ring);
+        DUPL_LAUNCH((gemm_f16x3_pring_kernel<2, 2, 4, 2, 2>), dim3((unsigned)grid), dim3(512), 0, s, *d, g16_group_ring);
         return dupl_launch_status();
     }
     if (tile == 8 || tile == 9 || tile == 12 || tile == 14) tile = 5;      // single-accumulator tiles: format 1 operands only (above)
-    if (tile == 6) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
-    else if (tile == 7) hipLaunchKernelGGL((gemm_f16x3_ring_kernel<4, 2, 2, 2, 1>), blocks(256, 128), dim3(256), 0, s, *d, g16_group_ring);
-    else if (tile == 3) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 2, 2>), blocks(128, 64), dim3(256), 0, s, *d, g16_group_m);
-    else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 4, 4>), blocks(128, 128), dim3(512), 0, s, *d, g16_group_m);
+    if (tile == 6) DUPL_LAUNCH((gemm_f16x3_ring_kernel<2, 2, 4, 2, 2>), blocks(256, 128), dim3(512), 0, s, *d, g16_group_ring);
+    else if (tile == 7) DUPL_LAUNCH((gemm_f16x3_ring_kernel<4, 2, 2, 2, 1>), blocks(256, 128), dim3(256), 0, s, *d, g16_group_ring);
+    else if (tile == 3) DUPL_LAUNCH((gemm_f16x3_kernel<2, 1, 2, 2, 2>), blocks(128, 64), dim3(256), 0, s, *d, g16_group_m);
+    else DUPL_LAUNCH((gemm_f16x3_kernel<2, 1, 2, 4, 4>), blocks(128, 128), dim3(512), 0, s, *d, g16_group_m);
     return dupl_launch_status();
 }

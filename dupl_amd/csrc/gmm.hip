@@ -371,7 +371,6 @@ extern "C" int dupl_gmm_noise_filter(const float* ce_map, float* label, float* x
                                      int32_t min_count, float valid_thre, float gamma, float reg_covar, float em_tol,
                                      int32_t em_iters, double u0, double u1, double u2, int32_t seeding,
                                      const uint32_t* mt_raw_host, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!ce_map || !label || !xs_scratch || !lab_scratch || !stats || B <= 0 || HW <= 0 || em_iters < 0 ||
         !(u0 >= 0.0 && u0 < 1.0) || !(u1 >= 0.0 && u1 < 1.0) || !(u2 >= 0.0 && u2 < 1.0) || (seeding != 0 && seeding != 1) ||
         (seeding == 1 && !mt_raw_host))
@@ -389,7 +388,7 @@ extern "C" int dupl_gmm_noise_filter(const float* ce_map, float* label, float* x
     p.em_iters = em_iters;
     p.kmeans_iters = 300;   // sklearn KMeans default max_iter
     p.u0 = u0; p.u1 = u1; p.u2 = u2;
-    hipLaunchKernelGGL(gmm_filter_kernel, dim3(B), dim3(GT), 0, (hipStream_t)s, ce_map, label, xs_scratch, lab_scratch,
+    DUPL_LAUNCH(gmm_filter_kernel, dim3(B), dim3(GT), 0, (hipStream_t)s, ce_map, label, xs_scratch, lab_scratch,
                        stats, HW, p);
     return dupl_launch_status();
 }

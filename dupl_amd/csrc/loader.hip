@@ -110,10 +110,9 @@ __global__ __launch_bounds__(256) void normalize_hwc_kernel(const uint8_t* __res
 
 extern "C" int dupl_loader_resample_h(const uint8_t* in, uint8_t* out, const int32_t* coef, const int32_t* bounds, int32_t ksize,
                                       int32_t h, int32_t w, int32_t w2, dupl_stream_t s) {
-    (void)hipGetLastError();
     if (!in || !out || !coef || !bounds || ksize <= 0 || h <= 0 || w <= 0 || w2 <= 0) return DUPL_ERR_ARG;
     const long n = (long)h * w2;
-    hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, out, coef, bounds,
+    DUPL_LAUNCH(resample_h_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, out, coef, bounds,
                        ksize, h, w, w2);
     return dupl_launch_status();
 }
@@ -121,20 +120,18 @@ extern "C" int dupl_loader_resample_h(const uint8_t* in, uint8_t* out, const int
 extern "C" int dupl_loader_resample_v_crop(const uint8_t* tmp, uint8_t* out, const int32_t* coef, const int32_t* bounds,
                                            int32_t ksize, int32_t w2, int32_t h2, int32_t flip, int32_t h_pad, int32_t w_pad,
                                            int32_t h_start, int32_t w_start, int32_t crop, dupl_stream_t s) {
-    (void)hipGetLastError();
     if (!tmp || !out || !coef || !bounds || ksize <= 0 || w2 <= 0 || h2 <= 0 || crop <= 0 || h_pad < 0 || w_pad < 0 ||
         h_start < 0 || w_start < 0)
         return DUPL_ERR_ARG;
     const long n = (long)crop * crop;
-    hipLaunchKernelGGL(resample_v_crop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, tmp, out, coef,
+    DUPL_LAUNCH(resample_v_crop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, tmp, out, coef,
                        bounds, ksize, w2, h2, flip ? 1 : 0, h_pad, w_pad, h_start, w_start, crop);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_loader_normalize(const uint8_t* in, float* out, int32_t H, int32_t W, int32_t mode, dupl_stream_t s) {
-    (void)hipGetLastError();
     if (!in || !out || H <= 0 || W <= 0 || mode < 0 || mode > 1) return DUPL_ERR_ARG;
     const long n = (long)H * W;
-    hipLaunchKernelGGL(normalize_hwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, out, n, mode);
+    DUPL_LAUNCH(normalize_hwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, out, n, mode);
     return dupl_launch_status();
 }

@@ -472,30 +472,27 @@ inline int ew_grid(long n) {
 
 extern "C" int dupl_ptc_reduce(const float* cosm, const int64_t* label, const int64_t* mask, int32_t ignore_index, float* sums,
                                int32_t b, int32_t hw, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!cosm || (!label && !mask) || !sums || b <= 0 || hw <= 0) return DUPL_ERR_ARG;
     int gx = hw < 96 ? hw : 96;              // rows of the (hw, hw) matrix per image are dealt to the blocks (~8 rows each at 28 x 28)
-    hipLaunchKernelGGL(ptc_reduce_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)s, cosm, (const long long*)label,
+    DUPL_LAUNCH(ptc_reduce_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)s, cosm, (const long long*)label,
                        (const long long*)mask, ignore_index, sums, hw);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_ptc_bwd_mask(float* cos_signed, const int64_t* label, const int64_t* mask, int32_t ignore_index,
                                  const float* sums, const float* gscale, int32_t b, int32_t hw, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!cos_signed || (!label && !mask) || !sums || !gscale || b <= 0 || hw <= 0) return DUPL_ERR_ARG;
     int gx = (int)(((long)hw * hw + 1023) / 1024);
     if (gx > 512) gx = 512;
-    hipLaunchKernelGGL(ptc_bwd_mask_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)s, cos_signed, (const long long*)label,
+    DUPL_LAUNCH(ptc_bwd_mask_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)s, cos_signed, (const long long*)label,
                        (const long long*)mask, ignore_index, sums, gscale, hw);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_l2norm_rows_fwd(const float* x, float* xhat, float* norm, int64_t rows, int32_t c, int64_t ldx,
                                     int32_t rows_per_img, int64_t img_stride, float eps, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !xhat || !norm || rows <= 0 || c <= 0 || rows_per_img <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, x, xhat, norm, (long)rows,
+    DUPL_LAUNCH(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, x, xhat, norm, (long)rows,
                        c, (long)ldx, rows_per_img, (long)img_stride, eps);
     return dupl_launch_status();
 }
@@ -503,9 +500,8 @@ extern "C" int dupl_l2norm_rows_fwd(const float* x, float* xhat, float* norm, in
 extern "C" int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const float* norm, float* dx, int64_t rows, int32_t c,
                                     int64_t ldx, int32_t rows_per_img, int64_t img_stride, float eps, int32_t accumulate,
                                     dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dxhat || !xhat || !norm || !dx || rows <= 0 || c <= 0 || rows_per_img <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, dxhat, xhat, norm, dx,
+    DUPL_LAUNCH(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, dxhat, xhat, norm, dx,
                        (long)rows, c, (long)ldx, rows_per_img, (long)img_stride, eps, accumulate);
     return dupl_launch_status();
 }
@@ -513,10 +509,9 @@ extern "C" int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const
 extern "C" int dupl_seg_loss_fwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* sums,
                                  int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip,
                                  dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!logits || !label || !sums || b <= 0 || C1 <= 0 || h <= 0 || w <= 0 || H < h || W < w) return DUPL_ERR_ARG;
     dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
-    hipLaunchKernelGGL(seg_loss_kernel<0>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index, sums,
+    DUPL_LAUNCH(seg_loss_kernel<0>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index, sums,
                        (const float*)nullptr, (float*)nullptr, C1, h, w, H, W, flip, 1);
     return dupl_launch_status();
 }
@@ -524,10 +519,9 @@ extern "C" int dupl_seg_loss_fwd(const float* logits, const void* label, int32_t
 extern "C" int dupl_seg_ce_map(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* ce_map,
                                int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip,
                                dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!logits || !label || !ce_map || b <= 0 || C1 <= 0 || h <= 0 || w <= 0 || H < h || W < w) return DUPL_ERR_ARG;
     dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
-    hipLaunchKernelGGL(seg_loss_kernel<2>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index,
+    DUPL_LAUNCH(seg_loss_kernel<2>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index,
                        (float*)nullptr, (const float*)nullptr, ce_map, C1, h, w, H, W, flip, 1);
     return dupl_launch_status();
 }
@@ -535,19 +529,18 @@ extern "C" int dupl_seg_ce_map(const float* logits, const void* label, int32_t i
 extern "C" int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, const float* sums,
                                  const float* gscale, float* dlogits, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H,
                                  int32_t W, int32_t flip, int32_t balanced, int32_t deterministic, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!logits || !label || !sums || !gscale || !dlogits || b <= 0 || C1 <= 0 || H < h || W < w) return DUPL_ERR_ARG;
     if (deterministic) {
         int nthr = 256;                                        // <= 64 KB of dynamic LDS: [threads][C1 + 1] floats
         while (nthr > 64 && (size_t)nthr * (C1 + 1) * sizeof(float) > 64 * 1024) nthr >>= 1;
         if ((size_t)nthr * (C1 + 1) * sizeof(float) > 64 * 1024) return DUPL_ERR_ARG;
-        hipLaunchKernelGGL(seg_loss_bwd_gather_kernel, dim3(h * w, b), dim3(nthr), (size_t)nthr * (C1 + 1) * sizeof(float),
+        DUPL_LAUNCH(seg_loss_bwd_gather_kernel, dim3(h * w, b), dim3(nthr), (size_t)nthr * (C1 + 1) * sizeof(float),
                            (hipStream_t)s, logits, label, is_i64, ignore_index, sums, gscale, dlogits, C1, h, w, H, W, flip,
                            balanced);
         return dupl_launch_status();
     }
     dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
-    hipLaunchKernelGGL(seg_loss_kernel<1>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index,
+    DUPL_LAUNCH(seg_loss_kernel<1>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index,
                        const_cast<float*>(sums), gscale, dlogits, C1, h, w, H, W, flip, balanced);
     return dupl_launch_status();
 }
@@ -555,25 +548,22 @@ extern "C" int dupl_seg_loss_bwd(const float* logits, const void* label, int32_t
 extern "C" int dupl_seg_pseudo_label(const float* logits, const float* other_label, int32_t ignore_index, float conf_thr,
                                      int64_t* out_label, float* count, int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H,
                                      int32_t W, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!logits || !other_label || !out_label || !count || b <= 0 || C1 <= 0 || h <= 0 || w <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(seg_pseudo_label_kernel, dim3((H * W + 255) / 256, b), dim3(256), 0, (hipStream_t)s, logits, other_label,
+    DUPL_LAUNCH(seg_pseudo_label_kernel, dim3((H * W + 255) / 256, b), dim3(256), 0, (hipStream_t)s, logits, other_label,
                        ignore_index, conf_thr, (long long*)out_label, count, C1, h, w, H, W);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_mask_fill(float* label, const uint8_t* mask, float value, int64_t n, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!label || !mask || n <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(mask_fill_kernel, dim3(ew_grid((long)n)), dim3(256), 0, (hipStream_t)s, label, mask, value, (long)n);
+    DUPL_LAUNCH(mask_fill_kernel, dim3(ew_grid((long)n)), dim3(256), 0, (hipStream_t)s, label, mask, value, (long)n);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_cos_sim_fwd(const float* a, const float* b, float* out, float* stats, int32_t B, int32_t n, int32_t c,
                                 int64_t ld, int64_t img_stride, float eps, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!a || !b || !out || !stats || B <= 0 || n <= 0 || c <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(cos_sim_fwd_kernel, dim3((c + 63) / 64, B), dim3(64 * CS_RG), 0, (hipStream_t)s, a, b, out, stats, n, c, (long)ld,
+    DUPL_LAUNCH(cos_sim_fwd_kernel, dim3((c + 63) / 64, B), dim3(64 * CS_RG), 0, (hipStream_t)s, a, b, out, stats, n, c, (long)ld,
                        (long)img_stride, eps);
     return dupl_launch_status();
 }
@@ -581,24 +571,21 @@ extern "C" int dupl_cos_sim_fwd(const float* a, const float* b, float* out, floa
 extern "C" int dupl_cos_sim_bwd(const float* a, const float* b, const float* stats, const float* g, float gmul, float* db,
                                 int32_t B, int32_t n, int32_t c, int64_t ld, int64_t img_stride, float eps, int32_t accumulate,
                                 dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!a || !b || !stats || !g || !db || B <= 0 || n <= 0 || c <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(cos_sim_bwd_kernel, dim3(ew_grid((long)B * n * c)), dim3(256), 0, (hipStream_t)s, a, b, stats, g, gmul, db,
+    DUPL_LAUNCH(cos_sim_bwd_kernel, dim3(ew_grid((long)B * n * c)), dim3(256), 0, (hipStream_t)s, a, b, stats, g, gmul, db,
                        B, n, c, (long)ld, (long)img_stride, eps, accumulate);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_mean_accum(const float* x, float* loss, int64_t n, float mul, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !loss || n <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(mean_accum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, x, loss, (long)n, mul);
+    DUPL_LAUNCH(mean_accum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, x, loss, (long)n, mul);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_multilabel_soft_margin(const float* logits, const float* target, float* loss, float* dlogits,
                                            const float* gscale, int32_t b, int32_t C, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!logits || !target || b <= 0 || C <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(msm_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, logits, target, loss, dlogits, gscale, b, C);
+    DUPL_LAUNCH(msm_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, logits, target, loss, dlogits, gscale, b, C);
     return dupl_launch_status();
 }

@@ -438,14 +438,13 @@ extern "C" int dupl_layernorm_fwd(const float* x, const float* gamma, const floa
 extern "C" int dupl_layernorm_fwd16(const float* x, const float* gamma, const float* beta, float* y, void* y_hi, void* y_lo,
                                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, int64_t f32_rows,
                                     int32_t plane_exp, dupl_stream_t s) {
-    (void)hipGetLastError();
     if (plane_exp < 0 || plane_exp > 15) return DUPL_ERR_ARG;
     const float plane_scale = plane_exp ? ldexpf(1.f, plane_exp) : 0.f;  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !gamma || !beta || (!y && !y_hi) || ((y_hi == nullptr) != (y_lo == nullptr)) || rows <= 0 || D <= 0 || (D & 3) ||
         D > LN_MAXC_LIMIT * 256 || f32_rows < 0 || f32_rows > rows || (f32_rows && !y_hi))
         return DUPL_ERR_ARG;
     const int grid = (int)((rows + 3) / 4);
-#define LN_FWD(MC) hipLaunchKernelGGL(layernorm_fwd_kernel<MC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, gamma, beta, y, \
+#define LN_FWD(MC) DUPL_LAUNCH(layernorm_fwd_kernel<MC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, gamma, beta, y, \
                                       mean, rstd, (long)rows, D, eps, (__half*)y_hi, (__half*)y_lo, (long)f32_rows, plane_scale)
     if (D <= 256) LN_FWD(1);
     else if (D <= 768) LN_FWD(3);
@@ -466,7 +465,6 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
                                   const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                                   int64_t rows, int32_t D, void* amax_out, float* partials, int64_t partial_rows,
                                   int32_t rows_per_wave, float* dy_clear, int32_t deterministic, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0 || (D & 3) || D > LN_MAXC_LIMIT * 256)
         return DUPL_ERR_ARG;
     const bool want_dgb = dgamma || dbeta;
@@ -481,10 +479,10 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
     const bool det = deterministic && want_dgb && !two_stage;
     float* dg_k = det ? nullptr : dgamma;
     float* db_k = det ? nullptr : dbeta;
-#define LN_BWD(MC) hipLaunchKernelGGL(layernorm_bwd_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
+#define LN_BWD(MC) DUPL_LAUNCH(layernorm_bwd_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
                                       dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D, (unsigned int*)amax_out, rpw, \
                                       two_stage ? partials : nullptr)
-#define LN_BWD4(MC) hipLaunchKernelGGL(layernorm_bwd4_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
+#define LN_BWD4(MC) DUPL_LAUNCH(layernorm_bwd4_kernel<MC>, dim3(grid), dim3(256), (2 * D + 1) * sizeof(float), (hipStream_t)s, \
                                        dy, x, gamma, mean, rstd, dres, dx, dg_k, db_k, (long)rows, D, (unsigned int*)amax_out,        \
                                        two_stage ? partials : nullptr, in_kernel_clear ? dy_clear : nullptr)
     // four rows per wave (the default): the variant that keeps all four in flight; wide rows (D > 1024: 8 float4 per lane and row)
@@ -504,48 +502,44 @@ extern "C" int dupl_layernorm_bwd(const float* dy, const float* x, const float* 
     if (two_stage) {
         int gy = deterministic ? 1 : (grid + 63) / 64;
         if (gy > 16) gy = 16;
-        hipLaunchKernelGGL(ln_dgb_reduce_kernel, dim3((2 * D + 63) / 64, gy), dim3(256), 0, (hipStream_t)s, partials, 4 * grid, D,
+        DUPL_LAUNCH(ln_dgb_reduce_kernel, dim3((2 * D + 63) / 64, gy), dim3(256), 0, (hipStream_t)s, partials, 4 * grid, D,
                            dgamma, dbeta);
     }
     if (det)
-        hipLaunchKernelGGL(ln_dgb_det_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)s, dy, x, mean, rstd, dgamma, dbeta,
+        DUPL_LAUNCH(ln_dgb_det_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)s, dy, x, mean, rstd, dgamma, dbeta,
                            (long)rows, D);
     if (dy_clear && !in_kernel_clear)
-        hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, dy_clear, 0.f, (long)rows * D);
+        DUPL_LAUNCH(fill_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, dy_clear, 0.f, (long)rows * D);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_colsum(const float* x, float* out, int64_t M, int32_t N, int32_t ldx, int32_t accumulate,
                            int32_t deterministic, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !out || M <= 0 || N <= 0) return DUPL_ERR_ARG;
-    if (!accumulate) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, out, 0.f, (long)N);
+    if (!accumulate) DUPL_LAUNCH(fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, out, 0.f, (long)N);
     long gy = (M + 63) / 64;       // 16 rows per thread-row-group pass: enough blocks to fill the chip on B*N ~ 3000 rows
     if (gy > 256) gy = 256;
     if (gy < 1) gy = 1;
     if (deterministic) gy = 1;      // one block per 64 columns: a single, fixed-order addition per output
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (int)gy), dim3(256), 0, (hipStream_t)s, x, out, (long)M, N, ldx);
+    DUPL_LAUNCH(colsum_kernel, dim3((N + 63) / 64, (int)gy), dim3(256), 0, (hipStream_t)s, x, out, (long)M, N, ldx);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_fill(float* p, float v, int64_t n, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!p || n < 0) return DUPL_ERR_ARG;
     if (n == 0) return DUPL_OK;
-    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, p, v, (long)n);
+    DUPL_LAUNCH(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, p, v, (long)n);
     return dupl_launch_status();
 }
 extern "C" int dupl_axpy(float* y, const float* x, float a, int64_t n, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!y || !x || n < 0) return DUPL_ERR_ARG;
     if (n == 0) return DUPL_OK;
-    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, y, x, a, (long)n);
+    DUPL_LAUNCH(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, y, x, a, (long)n);
     return dupl_launch_status();
 }
 extern "C" int dupl_scale(float* y, float a, int64_t n, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!y || n < 0) return DUPL_ERR_ARG;
     if (n == 0) return DUPL_OK;
-    hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, y, a, (long)n);
+    DUPL_LAUNCH(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, y, a, (long)n);
     return dupl_launch_status();
 }

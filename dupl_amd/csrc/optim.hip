@@ -57,7 +57,6 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 extern "C" int dupl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                           float wd, float bc1, float bc2_sqrt, void* p_hi, void* p_lo, int32_t plane_exp, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!p || !g || !m || !v || n <= 0) return DUPL_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
          reinterpret_cast<uintptr_t>(v)) & 15)
@@ -69,10 +68,10 @@ extern "C" int dupl_adamw(float* p, const float* g, float* m, float* v, int64_t 
     if (grid < 1) grid = 1;
     const float ps = plane_exp ? ldexpf(1.f, plane_exp) : 0.f;
     if (p_hi)
-        hipLaunchKernelGGL(adamw_kernel<true>, dim3((int)grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, 1.f - lr * wd, beta1,
+        DUPL_LAUNCH(adamw_kernel<true>, dim3((int)grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, 1.f - lr * wd, beta1,
                            beta2, eps, lr / bc1, bc2_sqrt, (__half*)p_hi, (__half*)p_lo, ps);
     else
-        hipLaunchKernelGGL(adamw_kernel<false>, dim3((int)grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, 1.f - lr * wd, beta1,
+        DUPL_LAUNCH(adamw_kernel<false>, dim3((int)grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, 1.f - lr * wd, beta1,
                            beta2, eps, lr / bc1, bc2_sqrt, (__half*)nullptr, (__half*)nullptr, 0.f);
     return dupl_launch_status();
 }

@@ -207,10 +207,9 @@ __global__ void refine_merge_kernel(const float* __restrict__ lh, const float* _
 
 extern "C" int dupl_par_affinity(const float* imgs, float* aff, const int32_t* dilations, int32_t ndil, const float* pos_term,
                                  int32_t B, int32_t h, int32_t w, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!imgs || !aff || !dilations || !pos_term || ndil <= 0 || ndil * 8 > NN || B <= 0 || h <= 0 || w <= 0) return DUPL_ERR_ARG;
     const ParTables tb = make_tables(dilations, ndil);
-    hipLaunchKernelGGL(par_affinity_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)s, imgs, aff, tb, pos_term,
+    DUPL_LAUNCH(par_affinity_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)s, imgs, aff, tb, pos_term,
                        ndil * 8, h, w);
     return dupl_launch_status();
 }
@@ -218,11 +217,10 @@ extern "C" int dupl_par_affinity(const float* imgs, float* aff, const int32_t* d
 extern "C" int dupl_par_propagate(const float* aff, const float* in, float* out, const int32_t* job_img, const int32_t* job_K,
                                   const int32_t* dilations, int32_t ndil, int32_t njobs, int32_t Kmax, int32_t h, int32_t w,
                                   dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!aff || !in || !out || !job_img || !job_K || !dilations || ndil <= 0 || ndil * 8 > NN || njobs <= 0 || Kmax <= 0)
         return DUPL_ERR_ARG;
     const ParTables tb = make_tables(dilations, ndil);
-    hipLaunchKernelGGL(par_propagate_kernel, dim3((h * w + 255) / 256, (Kmax + 3) / 4, njobs), dim3(256), 0, (hipStream_t)s, aff,
+    DUPL_LAUNCH(par_propagate_kernel, dim3((h * w + 255) / 256, (Kmax + 3) / 4, njobs), dim3(256), 0, (hipStream_t)s, aff,
                        in, out, job_img, job_K, tb, ndil * 8, Kmax, h, w);
     return dupl_launch_status();
 }
@@ -230,11 +228,10 @@ extern "C" int dupl_par_propagate(const float* aff, const float* in, float* out,
 extern "C" int dupl_refine_pre(const float* cams, const float* thr_map, const float* thr, const int32_t* job_img,
                                const int32_t* job_K, const int32_t* keys, int32_t njobs, int32_t Kmax, float* masks, int32_t C,
                                int32_t H, int32_t W, int32_t h, int32_t w, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!cams || (!thr_map && !thr) || !job_img || !job_K || !keys || !masks || njobs <= 0 || Kmax <= 0 || h <= 0 || w <= 0 ||
         h > H || w > W)
         return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(refine_pre_kernel, dim3((h * w + 255) / 256, njobs), dim3(256), 0, (hipStream_t)s, cams,
+    DUPL_LAUNCH(refine_pre_kernel, dim3((h * w + 255) / 256, njobs), dim3(256), 0, (hipStream_t)s, cams,
                        thr_map, thr, job_img, job_K, keys, Kmax, masks, C, H, W, h, w);
     return dupl_launch_status();
 }
@@ -242,20 +239,18 @@ extern "C" int dupl_refine_pre(const float* cams, const float* thr_map, const fl
 extern "C" int dupl_refine_post(const float* masks, const int32_t* job_img, const int32_t* job_K, const int32_t* keys,
                                 int32_t njobs, int32_t Kmax, const int32_t* box, float ignore_index, float* label, int32_t h,
                                 int32_t w, int32_t H, int32_t W, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!masks || !job_img || !job_K || !keys || !box || !label || njobs <= 0 || Kmax <= 0 || h <= 0 || w <= 0 || H < h || W < w)
         return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(refine_post_kernel, dim3((int)(((long)H * W + 255) / 256), njobs), dim3(256), 0, (hipStream_t)s, masks,
+    DUPL_LAUNCH(refine_post_kernel, dim3((int)(((long)H * W + 255) / 256), njobs), dim3(256), 0, (hipStream_t)s, masks,
                        job_img, job_K, keys, Kmax, box, ignore_index, label, h, w, H, W);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_refine_merge(const float* lab_h, const float* lab_l, float* out, float ignore_index, int64_t n,
                                  dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!lab_h || !lab_l || !out || n <= 0) return DUPL_ERR_ARG;
     long g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(refine_merge_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, lab_h, lab_l, out, ignore_index, (long)n);
+    DUPL_LAUNCH(refine_merge_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, lab_h, lab_l, out, ignore_index, (long)n);
     return dupl_launch_status();
 }

@@ -164,36 +164,32 @@ float gaussian_box_radius(float radius, int passes) {
 
 extern "C" int dupl_photo_enhance(uint8_t* img, int32_t H, int32_t W, int32_t mode, float factor, uint64_t* sum_scratch,
                                   dupl_stream_t s) {
-    (void)hipGetLastError();
     if (!img || H <= 0 || W <= 0 || mode < 0 || mode > 2 || (mode == 1 && !sum_scratch)) return DUPL_ERR_ARG;
     const long n = (long)H * W;
     if (mode == 1) {
         if (hipMemsetAsync(sum_scratch, 0, sizeof(uint64_t), (hipStream_t)s) != hipSuccess) return DUPL_ERR_LAUNCH;
         int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
         if (gx > 128) gx = 128;
-        hipLaunchKernelGGL(luma_sum_hwc_kernel, dim3(gx), dim3(256), 0, (hipStream_t)s, img, (unsigned long long*)sum_scratch, n);
+        DUPL_LAUNCH(luma_sum_hwc_kernel, dim3(gx), dim3(256), 0, (hipStream_t)s, img, (unsigned long long*)sum_scratch, n);
     }
-    hipLaunchKernelGGL(enhance_hwc_kernel, dim3(px_grid(n)), dim3(256), 0, (hipStream_t)s, img,
+    DUPL_LAUNCH(enhance_hwc_kernel, dim3(px_grid(n)), dim3(256), 0, (hipStream_t)s, img,
                        (const unsigned long long*)sum_scratch, n, factor, mode);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_photo_hue(uint8_t* img, int64_t n_px, int32_t shift, dupl_stream_t s) {
-    (void)hipGetLastError();
     if (!img || n_px <= 0 || shift < 0 || shift > 255) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(hue_hwc_kernel, dim3(px_grid(n_px)), dim3(256), 0, (hipStream_t)s, img, (long)n_px, shift);
+    DUPL_LAUNCH(hue_hwc_kernel, dim3(px_grid(n_px)), dim3(256), 0, (hipStream_t)s, img, (long)n_px, shift);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_photo_grayscale(uint8_t* img, int64_t n_px, dupl_stream_t s) {
-    (void)hipGetLastError();
     if (!img || n_px <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(gray_hwc_kernel, dim3(px_grid(n_px)), dim3(256), 0, (hipStream_t)s, img, (long)n_px);
+    DUPL_LAUNCH(gray_hwc_kernel, dim3(px_grid(n_px)), dim3(256), 0, (hipStream_t)s, img, (long)n_px);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_photo_gaussian_blur(uint8_t* img, uint8_t* tmp, int32_t H, int32_t W, float radius, dupl_stream_t s) {
-    (void)hipGetLastError();
     if (!img || !tmp || img == tmp || H <= 0 || W <= 0 || !(radius >= 0.f) || radius > 4096.f) return DUPL_ERR_ARG;
     if (radius == 0.f) return DUPL_OK;                          // ImageFilter.GaussianBlur.filter: radius 0 returns a copy
     const float fr = gaussian_box_radius(radius, 3);
@@ -206,7 +202,7 @@ extern "C" int dupl_photo_gaussian_blur(uint8_t* img, uint8_t* tmp, int32_t H, i
     uint8_t* a = img;
     uint8_t* b = tmp;
     for (int pass = 0; pass < 6; ++pass) {                      // 3 x horizontal, then 3 x vertical; ends in `img`
-        hipLaunchKernelGGL(box_pass_kernel, dim3(px_grid(total)), dim3(256), 0, (hipStream_t)s, a, b, H, W, r, ww, fw,
+        DUPL_LAUNCH(box_pass_kernel, dim3(px_grid(total)), dim3(256), 0, (hipStream_t)s, a, b, H, W, r, ww, fw,
                            pass >= 3 ? 1 : 0);
         uint8_t* t = a;
         a = b;

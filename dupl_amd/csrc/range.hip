@@ -52,10 +52,9 @@ __global__ __launch_bounds__(256) void param_bounds_kernel(const float* __restri
 }  // namespace
 
 extern "C" int dupl_param_bounds(const float* base, const dupl_bound_desc* table_dev, int32_t n, float* out, dupl_stream_t stream) {
-    (void)hipGetLastError();
     if (!base || !table_dev || !out || n <= 0) return DUPL_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(out, 0, sizeof(float) * 2 * (size_t)n, s) != hipSuccess) return DUPL_ERR_LAUNCH;
-    hipLaunchKernelGGL(param_bounds_kernel, dim3((unsigned)n, 32), dim3(256), 0, s, base, table_dev, out);
+    DUPL_LAUNCH(param_bounds_kernel, dim3((unsigned)n, 32), dim3(256), 0, s, base, table_dev, out);
     return dupl_launch_status();
 }

@@ -164,7 +164,6 @@ __global__ __launch_bounds__(256) void split_rt_multi_kernel(const split_multi_a
 }  // namespace
 
 extern "C" int dupl_split_prepare_multi(const dupl_split_item* items, int32_t n, dupl_stream_t stream) {
-    (void)hipGetLastError();
     if (!items || n < 1 || n > DUPL_SPLIT_MULTI_MAX) return DUPL_ERR_ARG;
     split_multi_args a;
     a.n = n;
@@ -181,12 +180,11 @@ extern "C" int dupl_split_prepare_multi(const dupl_split_item* items, int32_t n,
         total += ((d.C + 63) / 64) * ((Rt + 63) / 64);
     }
     a.first[n] = total;
-    hipLaunchKernelGGL(split_rt_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
+    DUPL_LAUNCH(split_rt_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_split_prepare(const dupl_split_desc* d, dupl_stream_t stream) {
-    (void)hipGetLastError();
     if (!d || d->struct_size != sizeof(dupl_split_desc)) return DUPL_ERR_ARG;
     const float* x = d->x;
     const int ld = d->ld, R = d->R, C = d->C, Rp = d->Rp, target_exp = d->target_exp, amax_mode = d->amax_mode;
@@ -207,16 +205,16 @@ extern "C" int dupl_split_prepare(const dupl_split_desc* d, dupl_stream_t stream
         long g = (n4 + 2047) / 2048;           // >= 8 float4 per thread, at most one block per CU
         if (g > 256) g = 256;
         if (g < 1) g = 1;
-        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, s, x, n4, reinterpret_cast<unsigned int*>(slot) + 2);
+        DUPL_LAUNCH(amax_kernel, dim3((unsigned)g), dim3(256), 0, s, x, n4, reinterpret_cast<unsigned int*>(slot) + 2);
     }
     int Rt = hiT ? Rp : R;
     if (d->rows_zero_to > Rt) Rt = d->rows_zero_to;
     const dim3 grid((C + 63) / 64, (Rt + 63) / 64);
     if (d->fmt == 1)
-        hipLaunchKernelGGL(split_rt_kernel<true>, grid, dim3(256), 0, s, x, ld, R, C, slot, (unsigned int*)d->next_bits, (__half*)hi,
+        DUPL_LAUNCH(split_rt_kernel<true>, grid, dim3(256), 0, s, x, ld, R, C, slot, (unsigned int*)d->next_bits, (__half*)hi,
                            (__half*)lo, (__half*)hiT, (__half*)loT, Rp, target_exp, d->colsum_accum, d->rows_zero_to);
     else
-        hipLaunchKernelGGL(split_rt_kernel<false>, grid, dim3(256), 0, s, x, ld, R, C, slot, (unsigned int*)d->next_bits, (__half*)hi,
+        DUPL_LAUNCH(split_rt_kernel<false>, grid, dim3(256), 0, s, x, ld, R, C, slot, (unsigned int*)d->next_bits, (__half*)hi,
                            (__half*)lo, (__half*)hiT, (__half*)loT, Rp, target_exp, d->colsum_accum, d->rows_zero_to);
     return dupl_launch_status();
 }

@@ -199,70 +199,62 @@ inline int ew_grid(long n, int per = 256) {
 }  // namespace
 
 extern "C" int dupl_patch_im2row(const float* x, float* rows, int32_t B, int32_t H, int32_t W, int32_t P, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!x || !rows || B <= 0 || P <= 0 || (P & 3) || H < P || W < P) return DUPL_ERR_ARG;
     const long total = (long)B * (H / P) * (W / P) * 3 * P * P / 4;
     const int vec = ((W & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    hipLaunchKernelGGL(patch_im2row_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, x, rows, B, H, W, P, vec);
+    DUPL_LAUNCH(patch_im2row_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, x, rows, B, H, W, P, vec);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_pos_embed_resize(const float* pos_embed, float* out, int32_t g, int32_t h, int32_t w, int32_t D,
                                      dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!pos_embed || !out || g <= 0 || h <= 0 || w <= 0 || D <= 0) return DUPL_ERR_ARG;
     const long total = (long)(1 + h * w) * D;
-    hipLaunchKernelGGL(pos_embed_resize_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, pos_embed, out, g, h, w, D);
+    DUPL_LAUNCH(pos_embed_resize_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, pos_embed, out, g, h, w, D);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_assemble_tokens(const float* patch, const float* cls, const float* pos, float* tokens, int32_t B,
                                     int32_t n, int32_t D, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!patch || !cls || !pos || !tokens || B <= 0 || n <= 0 || D <= 0 || (D & 3)) return DUPL_ERR_ARG;
     const long total = (long)B * (n + 1) * D / 4;
-    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, patch, cls, pos, tokens, B, n, D);
+    DUPL_LAUNCH(assemble_tokens_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, patch, cls, pos, tokens, B, n, D);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_assemble_tokens_bwd(const float* dtok, float* dpatch, float* dcls, int32_t B, int32_t n, int32_t D,
                                         dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dtok || !dpatch || !dcls || B <= 0 || n <= 0 || D <= 0 || (D & 3)) return DUPL_ERR_ARG;
     const long total = (long)B * n * D / 4;
-    hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, dtok, dpatch, dcls, B, n, D);
+    DUPL_LAUNCH(assemble_tokens_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)s, dtok, dpatch, dcls, B, n, D);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_gmp_fwd(const float* tokens, float* out, int32_t* idx, int32_t B, int32_t n, int32_t D, dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!tokens || !out || !idx || B <= 0 || n <= 0 || D <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(gmp_fwd_kernel, dim3((D + 63) / 64, B), dim3(1024), 0, (hipStream_t)s, tokens, out, idx, n, D);
+    DUPL_LAUNCH(gmp_fwd_kernel, dim3((D + 63) / 64, B), dim3(1024), 0, (hipStream_t)s, tokens, out, idx, n, D);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_gmp_bwd(const float* dout, const int32_t* idx, float* dtokens, int32_t B, int32_t n, int32_t D,
                             dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dout || !idx || !dtokens || B <= 0 || n <= 0 || D <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(gmp_bwd_kernel, dim3(ew_grid((long)B * D)), dim3(256), 0, (hipStream_t)s, dout, idx, dtokens, B, n, D);
+    DUPL_LAUNCH(gmp_bwd_kernel, dim3(ew_grid((long)B * D)), dim3(256), 0, (hipStream_t)s, dout, idx, dtokens, B, n, D);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_tokens_to_nchw(const float* tokens, float* out, int32_t B, int32_t n, int32_t D, int32_t skip_cls,
                                    dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!tokens || !out || B <= 0 || n <= 0 || D <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3((n + 31) / 32, (D + 31) / 32, B), dim3(256), 0, (hipStream_t)s, tokens, out,
+    DUPL_LAUNCH(tokens_to_nchw_kernel, dim3((n + 31) / 32, (D + 31) / 32, B), dim3(256), 0, (hipStream_t)s, tokens, out,
                        n, D, skip_cls ? 1 : 0);
     return dupl_launch_status();
 }
 
 extern "C" int dupl_nchw_to_tokens_add(const float* dnchw, float* dtokens, int32_t B, int32_t n, int32_t D, int32_t skip_cls,
                                        dupl_stream_t s) {
-    (void)hipGetLastError();  // drop stale non-sticky errors of other runtime users (e.g. hipErrorNotReady)
     if (!dnchw || !dtokens || B <= 0 || n <= 0 || D <= 0) return DUPL_ERR_ARG;
-    hipLaunchKernelGGL(nchw_to_tokens_add_kernel, dim3((n + 31) / 32, (D + 31) / 32, B), dim3(256), 0, (hipStream_t)s, dnchw,
+    DUPL_LAUNCH(nchw_to_tokens_add_kernel, dim3((n + 31) / 32, (D + 31) / 32, B), dim3(256), 0, (hipStream_t)s, dnchw,
                        dtokens, n, D, skip_cls ? 1 : 0);
     return dupl_launch_status();
 }

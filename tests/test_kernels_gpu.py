@@ -1463,3 +1463,28 @@ def test_grouped_weight_gradients(dev, tokens, D):
         print(f"grouped wgrad {tuple(ref.shape)} x {tokens}: f16x3 {e16:.2e}  f32 {e32:.2e}")
         assert e16 <= e32 + 2e-7
         assert torch.equal(outs[0][i], outs[1][i]) and torch.equal(outs[0][i], outs[2][i]), "the grouped launch must be bit-reproducible"
+
+
+def test_library_neither_swallows_nor_inherits_the_runtimes_last_error(dev):
+    """every entry point used to begin with `(void)hipGetLastError()` (dropping whatever error another user of the
+    runtime had pending) and to judge its own launches by `hipGetLastError()` afterwards.  Launches now go through hipLaunchKernel,
+    whose return value is the launch's own status: with a stale error planted in the runtime's per-thread slot (hipSetDevice on a
+    device that does not exist) a library call still succeeds, does its work, and leaves that error where it was."""
+    import ctypes
+    from dupl_amd import ops
+    x = torch.empty(4096, device=dev, dtype=torch.float32)
+    torch.cuda.synchronize()
+    path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln), None)
+    assert path is not None
+    hip = ctypes.CDLL(path)
+    hip.hipGetLastError()                                   # start clean
+    stale = hip.hipSetDevice(12345)
+    assert stale != 0 and hip.hipPeekAtLastError() == stale
+    try:
+        rc = ops.L().dupl_fill.raw(x.data_ptr(), ctypes.c_float(3.5), x.numel(), ops._stream())
+        assert rc == 0, "a stale runtime error was blamed on this launch"
+        assert hip.hipPeekAtLastError() == stale, "the library swallowed another user's pending error"
+    finally:
+        hip.hipGetLastError()                               # clear it before torch's own launch checks see it
+    torch.cuda.synchronize()
+    assert bool((x == 3.5).all())
