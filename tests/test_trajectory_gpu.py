@@ -224,7 +224,8 @@ def test_full_size_two_steps_voc_b_bs4_vs_oracle(dev):
             # oracle's pre-activation is < 1e-4 of the layer maximum, and the oracle re-run with the product's decisions imposed
             # puts every tensor back under the strict bar.
             bar = 2e-4
-            if any(not errs[k] < bar for k in order):
+            forced = os.environ.get("DUPL_TEST_FORCE_TIE_PROOF") == "1"      # exercise the proof path although no tensor is above the bar
+            if forced or any(not errs[k] < bar for k in order):
                 from parity_util import decoder_relu_flips, oracle_relu_masks
                 probe = siamese_network("deit_base_patch16_224", num_classes=NC, pretrained=False, aux_layer=-3)
                 probe.load_state_dict(before, strict=True)
@@ -237,7 +238,7 @@ def test_full_size_two_steps_voc_b_bs4_vs_oracle(dev):
                           f"pre-activation| among them {worst:.2e} of the layer maximum (bar 1e-4)")
                     assert worst < 1e-4, "a ReLU decision differs where the oracle's pre-activation is NOT at round-off level"
                     nflip += n6 + n7
-                assert nflip > 0, ("gradients above the bar without a flipped ReLU decision", [(k, errs[k]) for k in order[-4:]])
+                assert nflip > 0 or forced, ("gradients above the bar without a flipped ReLU decision", [(k, errs[k]) for k in order[-4:]])
                 leaf2 = {k: v.clone().requires_grad_(k in watch) for k, v in before.items()}
                 with oracle_relu_masks(masks) as used:
                     ref2, _ = O.train_step_losses(leaf2, inputs, cls_label, img_box, n_iter, cfg, oargs)
