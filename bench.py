@@ -514,8 +514,29 @@ class Workload:
 
     def step(self, i):
         # phase C: the strongly augmented view (train_final_voc.py:191) is computed inside the step, on the device
-        return self._trainer.train_step(self.ddp, self.optim, self.par, self.inputs, self.cls_label, self.img_box,
-                                        self.n_iter + i, self.sargs, cls_label_host=self.cls_host)
+        out = self._trainer.train_step(self.ddp, self.optim, self.par, self.inputs, self.cls_label, self.img_box,
+                                       self.n_iter + i, self.sargs, cls_label_host=self.cls_host)
+        self._armed_last = bool(getattr(self.optim, "_was_armed_exchange", False))
+        return out
+
+    def _ranks_seen(self, dist):
+        """{"world": dist.get_world_size(), "devices": [...one id per rank...], "distinct_devices": n}."""
+        import socket
+        props = torch.cuda.get_device_properties(self.dev)
+        ident = None
+        try:
+            ident = str(props.uuid)
+        except Exception:
+            pass
+        if not ident or set(ident.replace("-", "")) <= {"0"}:
+            if hasattr(props, "pci_bus_id"):
+                ident = "pci-%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+            else:
+                ident = f"device-index-{self.dev.index}"
+        me = f"{socket.gethostname()}/{ident}"
+        got = [None] * self.world
+        dist.all_gather_object(got, me)
+        return {"world": int(dist.get_world_size()), "devices": got, "distinct_devices": len(set(got))}
 
     def barrier(self):
         if self.world > 1:
@@ -557,10 +578,18 @@ class Workload:
             self.step(args.warmup + args.steps)
             torch.cuda.synchronize()
             red.profile = False
-            ex = red.pop_stats()["exposed_ms"]
-            e = torch.tensor([sum(ex)], device=self.dev, dtype=torch.float64)
+            stp = red.pop_stats()
+            ex = stp["exposed_ms"]
+            e = torch.tensor([sum(ex), stp["stall_ms"]], device=self.dev, dtype=torch.float64)
             dist.all_reduce(e, op=dist.ReduceOp.MAX)
-            comm["comm_exposed_ms"] = round(float(e.item()), 3)
+            comm["comm_exposed_ms"] = round(float(e[0].item()), 3)
+            # how long the student streams stood in the waits of the pieces taken in DURING the backward pass (sum over both streams,
+            # max over ranks): an upper bound of what those waits cost -- the other student's kernels run meanwhile
+            comm["comm_stall_ms_in_backward"] = round(float(e[1].item()), 3)
+            comm["optimizer_in_exchange"] = bool(self._armed_last)     # the AdamW launches rode behind each piece's all-reduce
+            # WHO took part: the process group's size and the distinct devices behind it (an all-gather of every rank's device
+            # UUID / PCI address + host) -- the first multi-GPU run proves that N ranks sat on N distinct GPUs
+            comm["ranks_seen"] = self._ranks_seen(dist)
             # self-validation of the exchange (the first real multi-GPU run must prove itself): every rank started from
             # rank 0's broadcast and applied the same averaged gradients, so the parameter buffers must be bit-identical --
             # two order-sensitive 64-bit checksums of the raw bits, compared over all ranks

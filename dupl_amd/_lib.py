@@ -152,6 +152,20 @@ class _Lib:
             fn.restype = ctypes.c_int
             # getters return a value, everything else a status (0 = ok) that is checked on every call
             setattr(self, name, fn if name in ("dupl_abi_version", "dupl_layernorm_bwd_blocks") else self._checked(name, fn))
+        # Build identity (ABI 4): the digest of the kernel sources is baked into the library at build time.  The GPU box runs a
+        # PREBUILT, git-ignored .so that travels with the tree: if the sources next to it are not the ones it was built from, refuse
+        # it here rather than measure (or test) one set of kernels under the name of another.
+        buf = ctypes.create_string_buffer(80)
+        if self.cdll.dupl_build_digest(buf, 80) != 0:
+            raise ImportError(f"{LIB_PATH}: dupl_build_digest failed")
+        self.build_digest = buf.value.decode()
+        from .build import source_digest, _sources
+        if _sources() and os.environ.get("DUPL_SKIP_DIGEST_CHECK", "0") != "1":
+            have = source_digest()
+            if have != self.build_digest:
+                raise ImportError(
+                    f"{LIB_PATH} was built from kernel sources with digest {self.build_digest[:16]}, the sources in this tree have "
+                    f"{have[:16]}: rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
 
     @staticmethod
     def _checked(name, fn):

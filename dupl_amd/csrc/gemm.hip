@@ -321,4 +321,4 @@ extern "C" int dupl_gemm_f32(const dupl_gemm_desc* d, dupl_stream_t stream) {
     return dupl_launch_status();
 }
 
-extern "C" int dupl_abi_version(void) { return 3; }
+extern "C" int dupl_abi_version(void) { return 4; }

@@ -29,21 +29,32 @@ from .engine import SEG_BACKBONE, SEG_DECODER, FlatStorage
 
 
 class GradReducer:
-    """Bucketed all-reduce (sum then / world) over the trainable gradient range of each student."""
+    """Bucketed all-reduce (sum then / world) over the trainable gradient range of each student.
+
+    Round 6: a reduced piece can be CONSUMED as soon as its all-reduce has completed -- `consumer(student, lo, hi, 1 / world)`
+    (the optimiser, PolyWarmupAdamW.begin_step) waits for the piece's collective on the student's stream, folds the 1 / world
+    into its gradient read (dupl_adamw's grad_scale: the same single rounding the scale launch made, written back, so .grad holds
+    the mean like torch DDP's) and updates that range right there, under the other student's backward.  A piece is taken in ONE
+    event after it was issued (its all-reduce has had a whole bucket's backward to finish, so the wait does not stall the stream);
+    only the last bucket's reduce + update and the stem / LayerNorm ranges are left for the end of the pass.  Without a consumer
+    the pieces are waited for and scaled at finish(), as before."""
 
     def __init__(self, store: FlatStorage, process_group=None, bucket_mb: float = 128.0, blocks_per_bucket: int = 2):
         self.store = store
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket_elems = max(1, int(bucket_mb * 1024 * 1024 / 4))
-        self._pending: List = []
+        self._pending: List = []       # [work, tensor, student, lo, hi] in issue order
+        self.consumer = None           # callable(student, lo, hi, inv) -> bool (True: it scaled + used grad[lo:hi])
         # per-step exchange accounting (bench.py: comm_exposed_ms / allreduce_bytes): bytes handed to all_reduce since the
         # last pop_stats(), and -- when `profile` is on -- how long the stream that finalises the step is blocked in the
-        # waits of finish() AFTER all compute of the step has drained (what the overlap failed to hide)
+        # waits of finish() AFTER all compute of the step has drained (what the overlap failed to hide), plus how long the student
+        # streams stood in the waits of the pieces taken in during the backward (`stall`)
         self.profile = False
         self._bytes = 0
         self._calls = 0
         self._exposed = []       # (event, event) pairs on CUDA, float ms on CPU tensors
+        self._stall = []
         # layer-granular plan: per student [(lo, hi, trigger event)], in the order the backward finalises them
         self.plan = [store.grad_buckets(s, blocks_per_bucket) for s in range(store.n_students)]
         self._issued = [set() for _ in range(store.n_students)]
@@ -66,25 +77,60 @@ class GradReducer:
             # re-checks synchronously before the next forward instead of `period` steps later.
             self.store.mark_dirty(rewritten=True)
 
-    def _issue(self, lo: int, hi: int):
+    def _issue(self, student: int, lo: int, hi: int):
         """all-reduce grad[lo:hi] in pieces of at most bucket_elems (returns immediately)."""
         while lo < hi:
             n = min(self.bucket_elems, hi - lo)
             t = self.store.grad[lo:lo + n]
             work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._pending.append((work, t))
+            self._pending.append([work, t, student, lo, lo + n])
             self._bytes += 4 * n
             self._calls += 1
             lo += n
 
+    def _retire(self, entry):
+        """The piece's collective is complete in the order of the current stream: hand it to the consumer, or average it."""
+        _, t, student, lo, hi = entry
+        inv = 1.0 / self.world
+        if self.consumer is not None and self.consumer(student, lo, hi, inv):
+            return
+        if t.is_cuda:
+            from . import ops
+            ops.scale_(t, inv)
+        else:
+            t.mul_(inv)
+
+    def _take_in(self, student: int, upto: int):
+        """Wait for (stream-level on RCCL, host-level on gloo) and retire this student's pieces among the first `upto` pending."""
+        keep, mine = [], []
+        for i, e in enumerate(self._pending):
+            (mine if (i < upto and e[2] == student) else keep).append(e)
+        if not mine:
+            return
+        self._pending = keep
+        for e in mine:
+            if self.profile and e[1].is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                e[0].wait()
+                e1.record()
+                self._stall.append((e0, e1))
+            else:
+                e[0].wait()
+            self._retire(e)
+
     def grad_ready(self, student: int, event):
-        """network_backward reports `event` ("heads", a block index, "stem"): issue the buckets it finalises."""
+        """network_backward reports `event` ("heads", a block index, "stem"): issue the buckets it finalises; with a consumer, take
+        in the pieces of this student that were issued at EARLIER events (on the current stream = the student's)."""
         if self.world == 1:
             return
+        before = len(self._pending)
         for idx, (lo, hi, trig) in enumerate(self.plan[student]):
             if trig == event and idx not in self._issued[student]:
                 self._issued[student].add(idx)
-                self._issue(lo, hi)
+                self._issue(student, lo, hi)
+        if self.consumer is not None:
+            self._take_in(student, before)
 
     def reduce_student_async(self, student: int):
         """Issue every bucket of one student that has not been issued yet (returns immediately)."""
@@ -93,53 +139,54 @@ class GradReducer:
         for idx, (lo, hi, _) in enumerate(self.plan[student]):
             if idx not in self._issued[student]:
                 self._issued[student].add(idx)
-                self._issue(lo, hi)
+                self._issue(student, lo, hi)
 
     def finish(self):
-        """Wait for the issued buckets (stream-level on RCCL, host-level on gloo) and average."""
+        """Wait for the pieces still pending (stream-level on RCCL, host-level on gloo) and retire them."""
+        for s in self._issued:
+            s.clear()
         if not self._pending:
             return
-        inv = 1.0 / self.world
         cuda = self._pending[0][1].is_cuda
+        if cuda and (self.profile or self.consumer is not None):
+            # the consumer updates parameters on THIS stream: everything the students still have queued comes first (and in profile
+            # mode the interval below is then communication only)
+            self.store.wait_streams()
         if self.profile:
             import time
             if cuda:
-                # drain the student streams first so that the interval below is communication only
-                self.store.wait_streams()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             else:
                 t0 = time.perf_counter()
-        for work, _ in self._pending:
-            work.wait()
+        for e in self._pending:
+            e[0].wait()
         if self.profile:
             if cuda:
                 e1.record()
                 self._exposed.append((e0, e1))
             else:
                 self._exposed.append((time.perf_counter() - t0) * 1e3)
-        for _, t in self._pending:
-            if t.is_cuda:
-                from . import ops
-                ops.scale_(t, inv)
-            else:
-                t.mul_(inv)
-        self._pending.clear()
-        for s in self._issued:
-            s.clear()
+        pend, self._pending = self._pending, []
+        for e in pend:
+            self._retire(e)
 
     def pop_stats(self):
-        """{allreduce_bytes, allreduce_calls, exposed_ms (list, one per finish() while profile was on)} since the last
-        call; synchronises the device when CUDA events are pending."""
-        exp = []
-        for e in self._exposed:
-            if isinstance(e, tuple):
-                e[1].synchronize()
-                exp.append(e[0].elapsed_time(e[1]))
-            else:
-                exp.append(e)
-        out = {"allreduce_bytes": self._bytes, "allreduce_calls": self._calls, "exposed_ms": exp}
-        self._bytes, self._calls, self._exposed = 0, 0, []
+        """{allreduce_bytes, allreduce_calls, exposed_ms (list, one per finish() while profile was on), stall_ms (sum of the student
+        streams' waits on pieces taken in during the backward)} since the last call; synchronises the device when CUDA events are
+        pending."""
+        def ms(lst):
+            out = []
+            for e in lst:
+                if isinstance(e, tuple):
+                    e[1].synchronize()
+                    out.append(e[0].elapsed_time(e[1]))
+                else:
+                    out.append(e)
+            return out
+        out = {"allreduce_bytes": self._bytes, "allreduce_calls": self._calls, "exposed_ms": ms(self._exposed),
+               "stall_ms": float(sum(ms(self._stall)))}
+        self._bytes, self._calls, self._exposed, self._stall = 0, 0, [], []
         return out
 
     def reduce_all(self):

@@ -172,6 +172,9 @@ class FlatStorage:
         # sticky "this segment has received a gradient at least once" flags == torch's `p.grad is None` skip
         self.seg_has_grad = [[False] * 5 for _ in range(n_students)]
         self.streams: List = []     # side streams the students run on (siamese_network.enable_dual_stream)
+        # launch tuning of this model's split GEMMs (dupl_gemm16_desc.tile / concurrency / persist_blocks / group / sk_slices): the
+        # model's own copy of the caller-side defaults -- enable_dual_stream of one model does not retune another
+        self.gemm16_tuning = dict(ops.GEMM16_TUNING)
         # f16x3 operand planes of the parameters (ops.Split16 format, csrc/gemm_split.hip): [2, n_students * numel] fp16,
         # refreshed per student when its key (torch version counter of the flat buffer, `dirty` bumped by raw-pointer
         # writers such as the optimiser kernel, buffer address) changes
@@ -551,6 +554,11 @@ class RangeGuard:
 
 
 
+def _lin16(P: "StudentParams", *a, **kw):
+    """ops.linear16 with the launch tuning of the model that owns P (FlatStorage.gemm16_tuning: per model, not process-wide)."""
+    return ops.linear16(*a, tuning=P.store.gemm16_tuning, **kw)
+
+
 class StudentParams:
     """Read-only bundle of one student's parameter / gradient views used by the engine."""
 
@@ -702,7 +710,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0, who
         if guard["patch"]:
             e = ea(guard, "patch")
             rows16 = ops.split16(ops.patch_im2row(x, cfg.patch), exp=e)
-            patch, _ = ops.linear16(rows16, P.w16("encoder.patch_embed.proj.weight", D, bool(e)), W["encoder.patch_embed.proj.bias"])
+            patch, _ = _lin16(P, rows16, P.w16("encoder.patch_embed.proj.weight", D, bool(e)), W["encoder.patch_embed.proj.bias"])
             del rows16
         else:
             patch = ops.linear(ops.patch_im2row(x, cfg.patch), W["encoder.patch_embed.proj.weight"], W["encoder.patch_embed.proj.bias"])
@@ -736,7 +744,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0, who
         # out-of-range verdict) and the f32 attention backward of sequences beyond 2 048 tokens
         need_qkv32 = (not attn16) or (save and groups[0][2] > 2048)       # (only batch 0 is ever back-propagated)
         if g["qkv"]:
-            qkv, qkv16 = ops.linear16(ln1_16, P.w16(p + "attn.qkv.weight", 3 * D, bool(ln1_16.exp)), W[p + "attn.qkv.bias"],
+            qkv, qkv16 = _lin16(P, ln1_16, P.w16(p + "attn.qkv.weight", 3 * D, bool(ln1_16.exp)), W[p + "attn.qkv.bias"],
                                       want_f32=need_qkv32, want16=attn16)
         else:
             qkv = ops.linear(ln1, W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"])
@@ -776,7 +784,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0, who
         qkv16_keep = qkv16 if (save and attn16) else None
         del qkv16
         if g["proj"]:
-            x_mid, _ = ops.linear16(att16, P.w16(p + "attn.proj.weight", D, bool(att16.exp)), W[p + "attn.proj.bias"], res=t)
+            x_mid, _ = _lin16(P, att16, P.w16(p + "attn.proj.weight", D, bool(att16.exp)), W[p + "attn.proj.bias"], res=t)
         else:
             x_mid = ops.linear(att, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], res=t)
         att_keep = att16 if (km["proj"] and att16 is not None and att16.exp > 0) else None
@@ -789,7 +797,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0, who
             # the planes of h1 in the format fc2 takes; format 1 planes can only come out of a format 1 GEMM
             e2 = ea(g, "fc2") if ln2_16.exp else 0
             km["fc2"] = km["fc2"] and e2 > 0
-            h1, h1_16 = ops.linear16(ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio, bool(ln2_16.exp)), W[p + "mlp.fc1.bias"],
+            h1, h1_16 = _lin16(P, ln2_16, P.w16(p + "mlp.fc1.weight", D * cfg.mlp_ratio, bool(ln2_16.exp)), W[p + "mlp.fc1.bias"],
                                      gelu=True, store_pre=pre1, want_f32=(save and not km["fc2"]) or not g["fc2"], want16=g["fc2"],
                                      c_rows=save_rows, out_exp=e2)
         else:
@@ -800,7 +808,7 @@ def _encoder_forward16(P: StudentParams, xs, save: bool, save_rows: int = 0, who
         h1_keep = h1_16 if km["fc2"] else None
         del ln2_16
         if g["fc2"]:
-            x_out, _ = ops.linear16(h1_16, P.w16(p + "mlp.fc2.weight", D, bool(h1_16.exp)), W[p + "mlp.fc2.bias"], res=x_mid)
+            x_out, _ = _lin16(P, h1_16, P.w16(p + "mlp.fc2.weight", D, bool(h1_16.exp)), W[p + "mlp.fc2.bias"], res=x_mid)
         else:
             x_out = ops.linear(h1, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"], res=x_mid)
         del h1_16
@@ -965,6 +973,12 @@ def cam_logits_shared_multi(P: StudentParams, xs, b: int):
     C = P.num_classes - 1
     n0 = (xs[0].shape[2] // P.cfg.patch) * (xs[0].shape[3] // P.cfg.patch) + 1
     rows = (xs[0].shape[0] // 2) * n0
+    P.store.ensure_w16(P.student)         # (takes in the range guard's verdicts: the check below must see what the pass will run with)
+    if not partial_save_ok(P):
+        # a site is routed to the f32 kernels: they need fp32 inputs for ALL rows -- the two-pass form (scale 1.0 saved whole, the
+        # other scales merged) computes the same values
+        cam_aux_t, cam_t, cache = cam_logits_shared(P, xs[0], b)
+        return [(cam_aux_t, cam_t)] + (cam_logits_multi(P, xs[1:]) if len(xs) > 1 else []), cache
     outs, tf, aux = _encoder_forward16(P, list(xs), save=True, save_rows=rows, whole=True)
     enc = outs[0][2]
     cam = ops.linear(tf, P.w["classifier.weight"].view(C, -1))
@@ -1006,13 +1020,13 @@ def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
         P.store.ensure_w16(P.student)
         guard = P.store.guard.sites(P.student)
     if f16 and guard["conv6"]:
-        h6, _ = ops.linear16(ops.split16(col6), P.w16("decoder.conv6.weight", dd), relu=True)
+        h6, _ = _lin16(P, ops.split16(col6), P.w16("decoder.conv6.weight", dd), relu=True)
     else:
         h6 = ops.linear(col6, P.w["decoder.conv6.weight"].view(dd, -1), relu=True)
     col7 = torch.empty((B * n, 9 * dd), device=x.device, dtype=torch.float32)
     ops.L().dupl_im2col_dil3(h6.data_ptr(), col7.data_ptr(), B, h, w, dd, dil, dd, n * dd, ops._stream())
     if f16 and guard["conv7"]:
-        h7, _ = ops.linear16(ops.split16(col7), P.w16("decoder.conv7.weight", dd), relu=True)
+        h7, _ = _lin16(P, ops.split16(col7), P.w16("decoder.conv7.weight", dd), relu=True)
     else:
         h7 = ops.linear(col7, P.w["decoder.conv7.weight"].view(dd, -1), relu=True)
     seg_tok = ops.linear(h7, P.w["decoder.conv8.weight"].view(P.num_classes, dd))
@@ -1070,7 +1084,7 @@ def _linear_backward16_km(P: StudentParams, dy: Tensor, x16, name: str, dgelu_of
         # the weight gradient joins the block's grouped launch (network_backward: ops.wgrad16_group); dy16 stays alive until then
         wgrads.append((dy16, x16, gw.view(N, -1), alpha))
     else:
-        ops.linear16(dy16, x16, out=gw.view(N, -1), accumulate=True, alpha=alpha, a_kmajor=True, b_kmajor=True, k_pad=Kp)
+        _lin16(P, dy16, x16, out=gw.view(N, -1), accumulate=True, alpha=alpha, a_kmajor=True, b_kmajor=True, k_pad=Kp)
     if not fuse_bias:
         ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
     W16 = P.w16(name + ".weight", N, True)
@@ -1079,9 +1093,9 @@ def _linear_backward16_km(P: StudentParams, dy: Tensor, x16, name: str, dgelu_of
         # outputs (768 columns = 78 tiles of 256 x 128 at 4 images, 42 at 2) then occupy every CU
         # cleared again by the LayerNorm backward that consumes it (DUPL_ZERO_WS=0: a fresh tensor and a fill launch per use)
         dx = ops.zero_workspace(M, W16.cols, dy.device) if ZERO_WS else ops.zeros((M, W16.cols), dy.device)
-        ops.linear16(dy16.rows_slice(0, M), W16, out=dx, accumulate=True, alpha=alpha, b_kmajor=True)
+        _lin16(P, dy16.rows_slice(0, M), W16, out=dx, accumulate=True, alpha=alpha, b_kmajor=True)
         return dx
-    dx, _ = ops.linear16(dy16.rows_slice(0, M), W16, alpha=alpha, dgelu_of=dgelu_of, amax_for_next=dx_feeds_split, b_kmajor=True)
+    dx, _ = _lin16(P, dy16.rows_slice(0, M), W16, alpha=alpha, dgelu_of=dgelu_of, amax_for_next=dx_feeds_split, b_kmajor=True)
     return dx
 
 
@@ -1098,11 +1112,11 @@ def _linear_backward16(P: StudentParams, dy: Tensor, x: Tensor, name: str, dgelu
     if xT16 is None:         # (the transformer blocks prepare x^T and W^T of all four Linears in one launch: _block_operands16)
         _, xT16, _ = ops.split_prepare(x, scaled=False, want_rm=False, want_T=True, rows_pad=Mp)
     gw = P.g[name + ".weight"]
-    ops.linear16(dyT16, xT16, out=gw.view(N, -1), accumulate=True, alpha=alpha)
+    _lin16(P, dyT16, xT16, out=gw.view(N, -1), accumulate=True, alpha=alpha)
     if has_bias and not fuse_bias:
         ops.colsum(dy, P.g[name + ".bias"], accumulate=True)
     # dx_feeds_split: dx is the next Linear's dy -> its max-abs comes out of this epilogue (ops.reserve_amax)
-    dx, _ = ops.linear16(dy16, P.w16T(name + ".weight", N), alpha=alpha, dgelu_of=dgelu_of, amax_for_next=dx_feeds_split)
+    dx, _ = _lin16(P, dy16, P.w16T(name + ".weight", N), alpha=alpha, dgelu_of=dgelu_of, amax_for_next=dx_feeds_split)
     return dx
 
 
@@ -1257,7 +1271,7 @@ def encoder_backward(P: StudentParams, enc: "EncoderSaved", dtf: Tensor, dta: Op
         if wg:
             # (measured and dropped: this launch on a side stream of its student, to share the chip with the narrow data-gradient
             # launches of the next block -- 55.2 vs 54.4 ms at 4 img/GPU, 33.8 vs 32.6 at 2, same box: DESIGN 6)
-            ops.wgrad16_group(wg)
+            ops.wgrad16_group(wg, tuning=P.store.gemm16_tuning)
         del wg
         enc.blocks[i] = None  # release activations as we go
         if on_ready is not None:

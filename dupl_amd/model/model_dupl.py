@@ -359,9 +359,13 @@ def _cu_masked_streams(dev, spec: str):
             raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
         out.append(torch.cuda.ExternalStream(h.value, device=dev))
     assert len(out) == 2
-    lo, hi = (int(v) for v in spec.split(",")[0].split(":"))
-    ops.GEMM16_TUNING["persist_blocks"] = int(os.environ.get("DUPL_PERSIST_BLOCKS", (hi - lo) // 8 * 8))
     return out
+
+
+def _cu_mask_persist_blocks(spec: str) -> int:
+    """Persistent-grid size for CU-masked student streams (the width of the first mask)."""
+    lo, hi = (int(v) for v in spec.split(",")[0].split(":"))
+    return int(os.environ.get("DUPL_PERSIST_BLOCKS", (hi - lo) // 8 * 8))
 
 
 class siamese_network(nn.Module):
@@ -412,17 +416,16 @@ class siamese_network(nn.Module):
                 _STREAM_PAIRS[dev] = (_cu_masked_streams(dev, spec) if spec else
                                       [torch.cuda.Stream(device=dev) for _ in range(2)])
             self._store.streams = list(_STREAM_PAIRS[dev])
+        tn = self._store.gemm16_tuning       # THIS model's launch tuning (engine.FlatStorage.gemm16_tuning): nothing process-wide
         if not on:
             self._store.streams = []
-            # the CU-mask experiment (DUPL_CU_MASK) sizes the persistent grids for its masks: a single-stream model (a validation
-            # pass, a second model of the process) must not inherit that
-            from .. import ops as _ops
-            _ops.GEMM16_TUNING["persist_blocks"] = int(os.environ.get("DUPL_PERSIST_BLOCKS", 0))
-        # the split GEMM picks its tile for the number of launches that share the chip (dupl_gemm16_desc.concurrency, a per-call
-        # field: ops.GEMM16_TUNING is this Python caller's default for it)
-        from .. import ops
+        # the CU-mask experiment (DUPL_CU_MASK) sizes the persistent grids for its masks; a single-stream model does not inherit that
+        spec = os.environ.get("DUPL_CU_MASK", "")
+        tn["persist_blocks"] = (_cu_mask_persist_blocks(spec) if (on and spec and self._store.streams)
+                                else int(os.environ.get("DUPL_PERSIST_BLOCKS", 0)))
+        # the split GEMM picks its tile for the number of launches that share the chip (dupl_gemm16_desc.concurrency, a per-call field)
         if self._store.data.is_cuda:
-            ops.GEMM16_TUNING["concurrency"] = 2 if (on and self._store.streams) else 1
+            tn["concurrency"] = 2 if (on and self._store.streams) else 1
         return self
 
     def ms_cam_and_forward(self, inputs, scales, inputs_aug=None):

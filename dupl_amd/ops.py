@@ -131,8 +131,9 @@ class W16:
 
 
 # Launch tuning of the split GEMM (dupl_gemm16_desc.tile / concurrency / persist_blocks / group): per-call fields of the
-# descriptor since ABI 2 -- this module-level dict is the PYTHON caller's default for them, not library state.
-# concurrency: streams that issue split GEMMs at a time (siamese_network.enable_dual_stream sets 2); tile: DUPL_GEMM16_TILE.
+# descriptor since ABI 2.  This module-level dict holds the DEFAULTS (environment) for direct callers of linear16 (tests, tools); a
+# model carries its own copy (engine.FlatStorage.gemm16_tuning, handed to linear16 as `tuning`) -- model code never writes here.
+# concurrency: streams that issue split GEMMs at a time (siamese_network.enable_dual_stream sets 2 on ITS model); tile: DUPL_GEMM16_TILE.
 import os as _os
 GEMM16_TUNING = {"tile": int(_os.environ.get("DUPL_GEMM16_TILE", "0")), "concurrency": 1,
                  "persist_blocks": int(_os.environ.get("DUPL_PERSIST_BLOCKS", "0")), "group": 0,
@@ -292,7 +293,7 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
              want_f32: bool = True, out16: Optional[Split16] = None, want16: bool = False, device=None,
              alpha: Optional[int] = None, accumulate: bool = False, dgelu_of: Optional[Tensor] = None,
              relumask_of: Optional[Tensor] = None, c_rows: int = 0, amax_for_next: bool = False, out_exp: int = 0,
-             a_kmajor: bool = False, b_kmajor: bool = False, k_pad: int = 0, post_exp: int = 0):
+             a_kmajor: bool = False, b_kmajor: bool = False, k_pad: int = 0, post_exp: int = 0, tuning: Optional[dict] = None):
     """y = act(alpha * x W^T + bias) (+ res) on the f16x3 split GEMM.  x: Split16 / Split16View [M, K]; W: Split16 [N, K].
     alpha: device pointer of a float (inverse scale of scaled gradient planes).  accumulate: out += alpha * x W^T (weight
     gradients; split-K).  dgelu_of / relumask_of: multiply by gelu'(pre) / (post > 0) (data gradients through an activation).
@@ -355,9 +356,10 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
         alpha.check()
     d.alpha_dev = int(alpha) if alpha is not None else None
     d.c_rows = int(c_rows)
-    d.tile, d.concurrency = GEMM16_TUNING["tile"], GEMM16_TUNING["concurrency"]
-    d.persist_blocks, d.group = GEMM16_TUNING["persist_blocks"], GEMM16_TUNING["group"]
-    d.sk_slices = GEMM16_TUNING["sk_slices"]
+    tn = tuning if tuning is not None else GEMM16_TUNING     # (engine.py passes its model's FlatStorage.gemm16_tuning)
+    d.tile, d.concurrency = tn["tile"], tn["concurrency"]
+    d.persist_blocks, d.group = tn["persist_blocks"], tn["group"]
+    d.sk_slices = tn["sk_slices"]
     tok = None
     if amax_for_next and y is not None and not accumulate and not c_rows:
         d.amax_out, tok = reserve_amax(dev)
@@ -369,7 +371,7 @@ def linear16(x, W: Split16, bias: Optional[Tensor] = None, *, gelu: bool = False
     return y, y16
 
 
-def wgrad16_group(items):
+def wgrad16_group(items, tuning: Optional[dict] = None):
     """Several weight gradients dW_i += alpha_i dy_i^T x_i in ONE launch (dupl_gemm_f16x3_group: a whole 256 x 128 tile per block over
     the whole token axis, no split-K, no atomics -- the same bits in deterministic mode).  items: [(dy16 Split16 [Kp, n_out] scaled
     format 1 planes with zero rows up to Kp, x16 Split16 / view [rows, n_in] format 1 planes, out fp32 [n_out, n_in], alpha)]."""
@@ -391,7 +393,7 @@ def wgrad16_group(items):
         d.fmt, d.post_scale = 1, 2.0 ** -(getattr(dy16, "exp", 0) + getattr(x16, "exp", 0))
         d.a_layout, d.b_layout = 1, 1
         d.ka_valid, d.kb_valid = Kp, min(x16.rows, Kp)
-        d.group = GEMM16_TUNING["group"]
+        d.group = (tuning if tuning is not None else GEMM16_TUNING)["group"]
         descs.append(d)
     for i in range(0, len(descs), _lib.GEMM16_GROUP_MAX):
         chunk = descs[i:i + _lib.GEMM16_GROUP_MAX]

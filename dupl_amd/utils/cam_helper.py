@@ -42,6 +42,11 @@ def _ms_cam(P, inputs, scales, share=None):
             # one merged no-grad pass (engine.cam_logits_multi)
             share["x"] = xs[0][:b]
             rows_all = sum(x_.shape[0] * ((x_.shape[2] // patch) * (x_.shape[3] // patch) + 1) for x_ in xs)
+            if engine.GEMM_MODE == "f16x3":
+                # the range guard's verdicts are taken in where the operand planes are brought up to date: do that BEFORE the route is
+                # chosen from them (a site that turns f32-routed at this step -- a harvest, a rewritten parameter -- would otherwise
+                # meet a merged pass that can no longer save a row prefix)
+                P.store.ensure_w16(P.student)
             if len(xs) > 1 and rows_all <= engine.MERGED_PASS and engine.partial_save_ok(P):
                 # round 5: every scale AND the training forward in one encoder pass (21 976 token rows at 448^2, 4 images)
                 res, share["enc"] = engine.cam_logits_shared_multi(P, xs, b)

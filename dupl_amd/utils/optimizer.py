@@ -19,14 +19,15 @@ from ..engine import FlatStorage, SEG_BACKBONE
 ADAMW_IN_BACKWARD = os.environ.get("DUPL_ADAMW_IN_BWD", "1") != "0"
 
 
-def adamw_segment(p, g, m, v, step, lr, beta1, beta2, eps, wd, planes=None):
+def adamw_segment(p, g, m, v, step, lr, beta1, beta2, eps, wd, planes=None, grad_scale: float = 1.0):
     """One fused AdamW update of flat fp32 tensors (torch.optim.AdamW single-tensor semantics).  planes = (hi pointer, lo pointer,
-    plane exponent): the updated values are also written as the f16x3 operand planes of the next forward."""
+    plane exponent): the updated values are also written as the f16x3 operand planes of the next forward.  grad_scale != 1: the
+    gradient is taken as g * grad_scale (one rounding) and written back so (the 1 / world of a data-parallel exchange)."""
     bc1 = 1.0 - beta1 ** step
     bc2_sqrt = math.sqrt(1.0 - beta2 ** step)
     hi, lo, e = planes if planes is not None else (None, None, 0)
     ops.L().dupl_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
-                       float(beta2), float(eps), float(wd), float(bc1), float(bc2_sqrt), hi, lo, e, ops._stream())
+                       float(beta2), float(eps), float(wd), float(bc1), float(bc2_sqrt), hi, lo, e, float(grad_scale), ops._stream())
 
 
 class PolyWarmupAdamW(torch.optim.Optimizer):
@@ -78,18 +79,24 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
         student's MFMA-bound backward instead of alone on the chip after it (1.1 ms of a 52 ms step).  step() then updates what is
         left (the stem, the LayerNorm segment) and does the bookkeeping.  The result is bit-identical to a plain step(): the same
         element-wise kernel with the same scalars over a partition of the same ranges.
-        Not armed (returns False; step() does everything) under a gradient exchange: a rank's gradient is only final after the
-        all-reduce (ddp.GradReducer), and when DUPL_ADAMW_IN_BWD=0."""
-        self._armed = None
+        Under a gradient exchange (ddp.DistributedDataParallel, world > 1; round 6) a rank's gradient is only final after its
+        all-reduce: the reducer hands every piece to `_on_bucket_reduced` once its collective has completed (one event after it
+        was issued, on the student's stream), the 1 / world goes into the kernel's gradient read (grad_scale: the rounding of the
+        scale launch it replaces, written back) -- only the last bucket's reduce + update stay behind the backward pass.
+        EXACTLY ONE backward pass between begin_step and step(): a second one (gradient accumulation) would meet ranges that are
+        already updated -- it raises.  zero_grad() disarms (a backward pass that raised, a step that was skipped).
+        Not armed (returns False; step() does everything) when DUPL_ADAMW_IN_BWD=0 or the model is not this optimiser's."""
+        self._disarm()
+        self._was_armed_exchange = False
         if not ADAMW_IN_BACKWARD or self._flat is None:
             return False
         core = model.module if hasattr(model, "module") else model
-        if core is not model and getattr(getattr(model, "reducer", None), "world", 1) > 1:
-            return False
+        reducer = getattr(model, "reducer", None) if core is not model else None
         store = self._flat[0]
         nets = [core.branch1, core.branch2] if hasattr(core, "branch1") else [core]
         if getattr(core, "flat_storage", getattr(core, "_store", None)) is not store:
             return False
+        exchange = reducer is not None and getattr(reducer, "world", 1) > 1
         for net in nets:
             if self._on_grad_ready not in net._grad_ready_hooks:
                 net._grad_ready_hooks.append(self._on_grad_ready)
@@ -97,14 +104,48 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
         self._armed = {"with_planes": [store.planes_current(s) for s in range(store.n_students)],
                        "done": [[] for _ in range(store.n_students)],            # (lo, hi) flat ranges already updated this step
                        "stepped": [set() for _ in range(store.n_students)],      # segments whose step count was advanced
-                       "plan": [store.grad_buckets(s) for s in range(store.n_students)]}
+                       "plan": [store.grad_buckets(s) for s in range(store.n_students)],
+                       "events": set(),                                          # (student, event) seen: one backward pass per step
+                       "exchange": exchange, "reducer": reducer if exchange else None}
+        if exchange:
+            reducer.consumer = self._on_bucket_reduced
+        self._was_armed_exchange = exchange      # (bench.py reports whether the update rode in the exchange)
         return True
 
-    def _update_range(self, s: int, lo: int, hi: int):
+    def _disarm(self):
+        arm = getattr(self, "_armed", None)
+        self._armed = None
+        if arm is not None and arm.get("reducer") is not None and arm["reducer"].consumer == self._on_bucket_reduced:
+            arm["reducer"].consumer = None
+        return arm
+
+    def _on_bucket_reduced(self, s: int, lo: int, hi: int, inv: float) -> bool:
+        """ddp.GradReducer consumer: grad[lo:hi) of student s holds the SUM over ranks, complete in the order of the current stream.
+        Update it with the gradient read as sum * inv (and written back as that mean).  Returns True: nothing left to scale."""
+        arm = getattr(self, "_armed", None)
+        if arm is None or not arm["exchange"]:
+            return False
+        store = self._flat[0]
+        base = s * store.student_numel
+        b0, b1 = base + store.seg_bounds[SEG_BACKBONE][0], base + store.seg_bounds[SEG_BACKBONE][1]
+        n0, n1 = base + store.seg_bounds[SEG_NORM][0], base + store.seg_bounds[SEG_NORM][1]
+        if lo < b1 and hi > b0:
+            store.seg_has_grad[s][SEG_BACKBONE] = True     # as in _on_grad_ready: P.mark_grad comes at the very end of the pass
+        if lo < n1 and hi > n0:
+            store.seg_has_grad[s][SEG_NORM] = True         # (the norm range is only issued by the "stem" event: final by then)
+        with torch.no_grad():
+            self._update_range(s, lo, hi, grad_scale=inv)
+        return True
+
+    def _update_range(self, s: int, lo: int, hi: int, grad_scale: float = 1.0):
         """AdamW over the flat range [lo, hi) of student s (absolute offsets), segment by segment, on the current stream."""
         store, m, v, steps = self._flat
         arm = self._armed
         base = s * store.student_numel
+        for a_, b_ in arm["done"][s]:
+            if a_ < hi and lo < b_:
+                raise RuntimeError("PolyWarmupAdamW: a gradient range came back final twice between begin_step() and step() -- "
+                                   "exactly one backward pass per armed step (call step(), or zero_grad(), in between)")
         for seg in range(1, 5):
             if seg not in self._seg_group or not store.seg_has_grad[s][seg]:
                 continue
@@ -119,17 +160,24 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
             b1, b2 = grp["betas"]
             sl = slice(a, b)
             adamw_segment(store.data[sl], store.grad[sl], m[sl], v[sl], steps[s][seg], grp["lr"], b1, b2, grp["eps"],
-                          grp["weight_decay"], planes=store.plane_pointers(a, seg) if arm["with_planes"][s] else None)
+                          grp["weight_decay"], planes=store.plane_pointers(a, seg) if arm["with_planes"][s] else None,
+                          grad_scale=grad_scale)
             arm["done"][s].append((a, b))
 
     def _on_grad_ready(self, net, event):
         """network_backward's on_ready (last pending backward of this student, on its stream): update the buckets `event` finalises.
         The stem / LayerNorm buckets wait for step(): SEG_BACKBONE / SEG_NORM are marked as having gradients at the very end."""
         arm = getattr(self, "_armed", None)
-        if arm is None or event == "stem":
+        if arm is None:
+            return
+        s = net._student
+        if (s, event) in arm["events"]:
+            raise RuntimeError("PolyWarmupAdamW: a second backward pass between begin_step() and step() (gradient accumulation is "
+                               "not supported with the update in the backward pass: call begin_step() before the LAST backward only)")
+        arm["events"].add((s, event))
+        if arm["exchange"] or event == "stem":       # under an exchange the reducer hands the reduced pieces to _on_bucket_reduced
             return
         store = self._flat[0]
-        s = net._student
         if event != "heads":
             store.seg_has_grad[s][SEG_BACKBONE] = True     # a transformer block was back-propagated (P.mark_grad comes at the end)
         with torch.no_grad():
@@ -138,6 +186,7 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
                     self._update_range(s, lo, hi)
 
     def zero_grad(self, set_to_none: bool = False):
+        self._disarm()       # a step that was armed but never taken (backward raised, non-finite loss skipped): nothing stays hooked
         if self._flat is not None:
             self._flat[0].wait_streams()
             ops.fill_(self._flat[0].grad, 0.0)   # keep the .grad views alive: one fused fill
@@ -165,8 +214,7 @@ class PolyWarmupAdamW(torch.optim.Optimizer):
         store.wait_streams()     # the students' backward passes may still be running on their own streams
         # a student whose operand planes are current gets them rewritten by the update itself (no split pass over the weights
         # before the next forward); segments without gradients keep their values, hence their planes
-        arm = getattr(self, "_armed", None)
-        self._armed = None
+        arm = self._disarm()
         with_planes = arm["with_planes"] if arm is not None else [store.planes_current(s) for s in range(store.n_students)]
         for s in range(store.n_students):
             base = s * store.student_numel

@@ -24,8 +24,13 @@ typedef void* dupl_stream_t;
 
 /* library info: returns the ABI version (2: descriptors carry struct_size, tuning knobs travel in the descriptors, one entry point
  * per operation; 3: the loss-sum buffers of dupl_ptc_reduce / dupl_seg_loss_fwd are DUPL_LOSS_SUMS_FLOATS floats, the determinism
- * switch is per call -- see INTEGRATION.md).  Infrastructure, no reference counterpart. */
+ * switch is per call; 4: dupl_build_digest, dupl_adamw's grad_scale, the fused loss total (dupl_loss_total) -- see INTEGRATION.md).
+ * Infrastructure, no reference counterpart. */
 int dupl_abi_version(void);
+/* build identity: the sha256 (64 hex digits + NUL into out[cap], cap >= 65) of the kernel sources this library was compiled from
+ * (every .hip / .h under csrc/ and include/dupl_hip.h), baked in at build time (dupl_amd/build.py).  The Python stub refuses a library whose
+ * digest differs from the sources it finds next to it; bench.py tags its roofline line with this value.  Infrastructure. */
+int dupl_build_digest(char* out, int32_t cap);
 /* DETERMINISM is a per-call argument since ABI 3 (the library holds no mode: re-entrant per stream and per caller).  Every entry
  * point that otherwise accumulates with fp32 atomics takes `deterministic` (a descriptor field or a trailing argument): != 0 =
  * that accumulation runs in a fixed order, so that two identical steps give bit-identical gradients (torch.use_deterministic_
@@ -435,9 +440,12 @@ int dupl_col2im_dil3(const float* dcol, float* dx, int32_t B, int32_t h, int32_t
 /* PolyWarmupAdamW.step -> torch.optim.AdamW.step (utils/optimizer.py:38-68) fused over one flat fp32 segment (16-byte
  * aligned); bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t) (host, double).  p_hi / p_lo (both or neither; 8-byte aligned): the updated
  * parameters are also written as the f16x3 operand planes of the next forward -- format 0 (plane_exp 0) or format 1 (p * 2^plane_exp,
- * unscaled lo), bit-identical to dupl_split_f16x2 / dupl_split_f16x2b of the updated segment */
-int dupl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-               float eps, float wd, float bc1, float bc2_sqrt, void* p_hi, void* p_lo, int32_t plane_exp, dupl_stream_t s);
+ * unscaled lo), bit-identical to dupl_split_f16x2 / dupl_split_f16x2b of the updated segment.
+ * grad_scale (> 0; ABI 4): the gradient is taken as g * grad_scale -- one rounding, written back to g -- i.e. DDP's division by
+ * the world size (train_final_voc.py:153-155) folded into the update of a range whose all-reduce has completed; 1 = g is read only */
+int dupl_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float wd, float bc1, float bc2_sqrt, void* p_hi, void* p_lo, int32_t plane_exp, float grad_scale,
+               dupl_stream_t s);
 /* optimizer.zero_grad() (train_final_voc.py:470) and buffer initialisation: p[0..n) = v */
 int dupl_fill(float* p, float v, int64_t n, dupl_stream_t s);
 /* y += a*x: the aux-branch gradient joining the residual stream (autograd of vit.py:316-326) */

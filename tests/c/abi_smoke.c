@@ -20,7 +20,7 @@
 static float frand(unsigned* s) { *s = *s * 1664525u + 1013904223u; return ((*s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
 
 int main(void) {
-    if (dupl_abi_version() != 3) return 1;
+    if (dupl_abi_version() != 4) return 1;
     const int M = 197, N = 96, K = 72;
     unsigned seed = 7;
     float *hA = malloc(sizeof(float) * M * K), *hB = malloc(sizeof(float) * N * K), *hb = malloc(sizeof(float) * N);

@@ -259,3 +259,79 @@ def test_grad_bucket_bookkeeping_world8_gloo():
         assert p.exitcode == 0
     for rank, ok in res:
         assert all(ok.values()), (rank, ok)
+
+
+def _consumer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dupl_amd.model.model_dupl import siamese_network
+        from dupl_amd.ddp import DistributedDataParallel
+        from dupl_amd.synthetic import hash_normal
+        m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+        ddp = DistributedDataParallel(m)
+        red, st = ddp.reducer, m.flat_storage
+        ok = {}
+        st.grad.copy_(hash_normal(f"grad_rank{rank}", (st.grad.numel(),), std=1.0, seed=3))
+        taken = []                       # (student, lo, hi, number of events reported so far)
+        n_events = [0]
+
+        def consumer(student, lo, hi, inv):
+            taken.append((student, lo, hi, n_events[0]))
+            st.grad[lo:hi].mul_(inv)     # what dupl_adamw's grad_scale does: the mean, written back
+            return True
+        red.consumer = consumer
+        issued_at = {}
+        events = ["heads", 2, 0, "stem"]      # tiny backbone: depth 4, two blocks per bucket
+        order = [(0, e) for e in events[:2]] + [(1, e) for e in events[:3]] + [(0, e) for e in events[2:]] + [(1, events[3])]
+        for s, ev in order:
+            n_events[0] += 1
+            before = {(e[2], e[3], e[4]) for e in red._pending}
+            red.grad_ready(s, ev)
+            for e in red._pending:
+                issued_at.setdefault((e[2], e[3], e[4]), n_events[0])
+            # pieces of THIS student issued at earlier events are gone from the pending list, the other student's are untouched
+            ok[f"lag_{s}_{ev}"] = all(k[0] != s for k in before & {(e[2], e[3], e[4]) for e in red._pending})
+        n_left = len(red._pending)
+        ok["last_pieces_wait_for_finish"] = n_left >= 2
+        n_events[0] += 1
+        red.finish()
+        ok["all_taken"] = not red._pending and not any(red._issued)
+        # every piece was consumed exactly once, strictly after the event that issued it
+        ok["once"] = len({t[:3] for t in taken}) == len(taken) == sum(len(p) for p in red.plan)
+        ok["after_issue"] = all(t[3] > issued_at[t[:3]] for t in taken)
+        expect = sum(hash_normal(f"grad_rank{r}", (st.grad.numel(),), std=1.0, seed=3) for r in range(world)) / world
+        for s in (0, 1):
+            lo, hi = st.trainable_range(s)
+            ok[f"mean_{s}"] = bool(torch.allclose(st.grad[lo:hi], expect[lo:hi], atol=1e-6))
+        # a consumer that declines (returns False) leaves the averaging to the reducer
+        st.grad.copy_(hash_normal(f"grad_rank{rank}", (st.grad.numel(),), std=1.0, seed=3))
+        red.consumer = lambda *a: False
+        for s, ev in order:
+            red.grad_ready(s, ev)
+        red.finish()
+        for s in (0, 1):
+            lo, hi = st.trainable_range(s)
+            ok[f"declined_mean_{s}"] = bool(torch.allclose(st.grad[lo:hi], expect[lo:hi], atol=1e-6))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduced_pieces_are_consumed_one_event_later_world2_gloo():
+    """ddp.GradReducer.consumer (round 6: the optimiser's update rides in the exchange): a piece is handed over exactly once, only
+    after a LATER event of its own student (or at finish()), never touching the other student's pending pieces, and the buffer
+    ends as the mean over ranks whether the consumer scales (returns True) or declines."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_consumer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok in res:
+        assert all(ok.values()), (rank, ok)

@@ -72,6 +72,30 @@ def gemm_mode(request):
 @pytest.mark.parametrize("dual", [False, True], ids=["one-stream", "two-streams"])
 @pytest.mark.parametrize("tag", ["A", "B"])
 def test_tiny_train_step_matches_reference(dev, golden_dir, tag, dual, gemm_mode):
+    _tiny_step_check(dev, golden_dir, tag, dual)
+
+
+@pytest.mark.parametrize("switch", ["FMT1", "KM_BWD", "SK_DGRAD", "WGRAD_GROUP", "ZERO_WS", "BLOCK_OPERANDS_MULTI", "KM_BWD+BLOCK_OPERANDS_MULTI"])
+@pytest.mark.parametrize("gemm_mode", ["f16x3"], indirect=True)
+def test_tiny_train_step_with_an_engine_switch_off(dev, golden_dir, gemm_mode, switch):
+    """every env-switched alternate path of engine.py has its OFF branch under the same reference golden as the
+    default (phase B, two student streams): DUPL_FMT1=0 (format 0 planes everywhere, two accumulator sets), DUPL_KM_BWD=0 (the
+    transposed-planes backward; also what a site takes whose planes are not format 1), DUPL_SK_DGRAD=0 (whole-tile data gradients),
+    DUPL_WGRAD_GROUP=0 (one weight-gradient launch per Linear), DUPL_ZERO_WS=0 (a fresh zero-filled dx per stream-K launch),
+    DUPL_BLOCK_OPERANDS_MULTI=0 (one operand split per launch)."""
+    from dupl_amd import engine
+    names = switch.split("+")
+    prev = {n: getattr(engine, n) for n in names}
+    try:
+        for n in names:
+            setattr(engine, n, False)
+        _tiny_step_check(dev, golden_dir, "B", True)
+    finally:
+        for n, v in prev.items():
+            setattr(engine, n, v)
+
+
+def _tiny_step_check(dev, golden_dir, tag, dual):
     from dupl_amd.model.model_dupl import siamese_network
     from dupl_amd.model.PAR import PAR
     from dupl_amd import trainer
@@ -1224,3 +1248,65 @@ def test_merged_encoder_pass_is_bit_identical_to_separate_passes(dev):
     for k in ka:
         assert torch.equal(ka[k], kb[k]), k
     assert torch.equal(ga, gb)
+
+
+def test_merged_pass_survives_a_range_verdict_that_flips_at_this_step(dev):
+    """the merged ms-CAM / training pass is chosen from the range guard's verdicts -- which are refreshed where the
+    operand planes are (FlatStorage.ensure_w16: a harvest step, a rewritten parameter).  A site that turns f32-routed exactly then
+    used to meet `assert not (save and len(xs) > 1 and not save_rows)`.  ViT-B/16 dual model at 96^2, deterministic mode: one clean
+    step through the merged pass, then LayerNorm gamma = 3e3 is planted in place (block 5, student 1) and the next step must take
+    the two-pass form on its own and give the bits of a model that was loaded with the planted parameters from the start; calling
+    the merged entry point directly degrades the same way."""
+    from dupl_amd import engine, trainer, ops
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from oracle import dupl_oracle as O
+    pp = O.make_siamese_params(O.VIT_BASE, 21, seed=5)
+    inputs, cls_label, img_box = O.synthetic_batch(2, 20, 96, seed=11)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    prev = engine.MERGED_PASS
+    engine.MERGED_PASS = 1 << 30
+    ops.set_deterministic(1)
+
+    def step(model):
+        model.flat_storage.grad.zero_()
+        loss, out = trainer.compute_losses(model, par, inputs.to(dev), cls_label.to(dev), img_box, 5000, trainer.StepArgs(),
+                                           cls_label_host=cls_label)
+        loss.sum().backward()
+        model.flat_storage.wait_streams()
+        torch.cuda.synchronize()
+        return out["loss"].detach().clone(), out["cams_1"].detach().clone(), model.flat_storage.grad.clone()
+
+    def make(params):
+        m = siamese_network("deit_base_patch16_224", num_classes=21, pretrained=False, aux_layer=-3)
+        m.load_state_dict(params, strict=True)
+        m.to(dev)
+        m.enable_dual_stream(True)
+        return m
+    try:
+        model = make(pp)
+        assert engine.partial_save_ok(model.branch1._P)
+        step(model)                                                      # clean step: the merged pass
+        with torch.no_grad():
+            model.branch1.encoder.blocks[5].norm1.weight[100] = 3.0e3    # torch-visible rewrite: re-checked at the next ensure_w16
+        assert engine.partial_save_ok(model.branch1._P), "the stale verdicts still say 'planes everywhere' -- that is the trap"
+        got = step(model)                                                # used to raise AssertionError in _encoder_forward16
+        assert not engine.partial_save_ok(model.branch1._P) and engine.partial_save_ok(model.branch2._P)
+        sites = model.flat_storage.guard.sites(0)
+        assert not sites["blocks"][5]["qkv"]
+        planted = {k: v.clone() for k, v in pp.items()}
+        planted["branch1.encoder.blocks.5.norm1.weight"][100] = 3.0e3
+        ref = step(make(planted))
+        for a, b, name in zip(got, ref, ("loss", "cams_1", "grad")):
+            assert torch.equal(a, b), name
+        # the merged entry point itself, asked for a pass it cannot save a prefix of
+        P = model.branch1._P
+        x = inputs.to(dev)
+        xs = [ops.resize_bilinear(x, 96, 96, flip_cat=True), ops.resize_bilinear(x, 48, 48, flip_cat=True)]
+        with torch.no_grad():
+            res, cache = engine.cam_logits_shared_multi(P, xs, 2)
+            want_aux, want_cam, _ = engine.cam_logits_shared(P, xs[0], 2)
+        assert len(res) == 2 and torch.equal(res[0][0], want_aux) and torch.equal(res[0][1], want_cam) and cache[2].B == 2
+    finally:
+        engine.MERGED_PASS = prev
+        ops.set_deterministic(0)

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     cdll = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(cdll, name), f"{name} declared in include/dupl_hip.h but not exported"
-    assert _lib.lib().dupl_abi_version() == 3
+    assert _lib.lib().dupl_abi_version() == 4
     # the ctypes mirrors have the size the C compiler gives the structs of the header (every descriptor carries struct_size and
     # the library refuses a mismatch, so a drifted mirror would fail every call; here it fails at build time, without a GPU)
     import subprocess, tempfile
@@ -347,3 +347,18 @@ def test_bench_gpus_n_never_silently_runs_one_rank():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_library_carries_the_digest_of_its_sources_and_a_stale_one_is_refused(monkeypatch):
+    """the prebuilt, git-ignored libdupl_hip.so travels to the GPU box with the tree.  Its build identity is
+    baked in (dupl_build_digest, written by dupl_amd/build.py) and the ctypes stub compares it with the sources next to it: a
+    library built from other kernel sources does not load."""
+    from dupl_amd import _lib, build
+    L = _lib.lib()
+    assert L.build_digest == build.source_digest() and len(L.build_digest) == 64
+    import ctypes
+    small = ctypes.create_string_buffer(16)
+    assert L.cdll.dupl_build_digest(small, 16) == -1          # a buffer that cannot hold it is refused, not overrun
+    monkeypatch.setattr(build, "source_digest", lambda: "0" * 64)
+    with pytest.raises(ImportError, match="rebuild"):
+        _lib._Lib()

@@ -188,15 +188,15 @@ for n_iter in (5000, 9000):          # phase B: one forward per student; phase C
                     work.wait()                                      # the side stream waits for RCCL's stream ONLY ...
                     nccl_snaps.append(t.clone())                     # ... and sees what the collective saw
                 return work
-            def spy(lo, hi, issue=issue, store=m.flat_storage):
+            def spy(student, lo, hi, issue=issue, store=m.flat_storage):
                 snaps.append((lo, hi, store.grad[lo:hi].clone()))   # stream-ordered snapshot at issue time
                 dist.all_reduce = ar_spy
                 try:
                     if DELAY == 2:
                         with torch.cuda.stream(broken):              # negative control: RCCL ordered after an EMPTY stream
-                            issue(lo, hi)
+                            issue(student, lo, hi)
                     else:
-                        issue(lo, hi)
+                        issue(student, lo, hi)
                 finally:
                     dist.all_reduce = real_ar
                 if DELAY:
@@ -393,6 +393,129 @@ print("DDP2_OK", rank)
     assert r.returncode == 0 and out.count("DDP2_OK") == 2 and out.count("DDP2_REL_ERR") == 8, out[-5000:]
 
 
+@pytest.mark.parametrize("mode", ["gloo2", "rccl1"])
+def test_ddp_two_ranks_optimizer_rides_in_the_exchange_gloo(dev, tmp_path, mode):
+    """World > 1 as overlapped as world 1 (round 6): with begin_step armed under a gradient exchange every reduced piece is
+    updated as soon as its all-reduce has completed (one event later, on the student's stream), 1 / world folded into the
+    kernel's gradient read -- no scale launch.  Two real ranks on cuda:0 over gloo, deterministic mode, phases B and C, two
+    steps: parameters, moments AND the gradients left in the buffer (the mean) must equal the plain run (reduce everything,
+    scale, then one step) BIT FOR BIT, on both ranks; the plain run must have used the scale launches, the overlapped one none.
+    mode rccl1: the same on the RCCL backend (one rank, the exchange path forced with world = 2, a ~10 ms spin kernel queued on the
+    student stream after every hand-off): there work.wait() is a STREAM-level dependency, which is what the 8-GPU run will use."""
+    script = tmp_path / "ddp2opt.py"
+    script.write_text(r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DUPL_ROOT"])
+from oracle import dupl_oracle as O
+import dupl_amd
+from dupl_amd import ops, trainer
+from dupl_amd.model.model_dupl import siamese_network
+from dupl_amd.model.PAR import PAR
+from dupl_amd.ddp import DistributedDataParallel
+from dupl_amd.utils import optimizer as OPT
+rank = int(os.environ["RANK"])
+MODE = os.environ["DUPL_TEST_MODE"]
+torch.cuda.set_device(0)
+dist.init_process_group("gloo" if MODE == "gloo2" else "nccl")
+dev = torch.device("cuda:0")
+dupl_amd.set_deterministic(True)
+pp = O.make_siamese_params(O.VIT_TINY, 21, seed=2)
+par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+n_scale = [0]
+_scale = ops.scale_
+def counting_scale(t, a):
+    n_scale[0] += 1
+    return _scale(t, a)
+ops.scale_ = counting_scale
+
+def batch(r, n_iter, k):
+    x, c, box = O.synthetic_batch(2, 20, 64, seed=5 + r + 7 * k)
+    aug = None
+    if n_iter >= 8000:
+        a, _, _ = O.synthetic_batch(2, 20, 64, seed=19 + r + 7 * k)
+        aug = torch.flip(0.7 * x + 0.3 * a, dims=[3]).contiguous().to(dev)
+    return x.to(dev), c, box, aug
+
+def run(n_iter, in_backward):
+    OPT.ADAMW_IN_BACKWARD = in_backward
+    m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    m.load_state_dict(pp); m.to(dev); m.enable_dual_stream(True)
+    w = DistributedDataParallel(m, device_ids=[0])
+    if MODE == "rccl1":
+        w.reducer.world = 2          # force the exchange path: all_reduce(SUM) over 1 rank, then * 1/2
+        issue = w.reducer._issue
+        def slow_issue(student, lo, hi):
+            issue(student, lo, hi)
+            torch.cuda._sleep(20_000_000)      # the student stream stalls after the hand-off: later waits / updates queue behind it
+        w.reducer._issue = slow_issue
+    g = m.get_param_groups()
+    opt = OPT.PolyWarmupAdamW(params=[{"params": g[i], "lr": 6e-3 * (1 if i < 2 else 10), "weight_decay": 0.01} for i in range(4)],
+                              lr=6e-3, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=2, max_iter=100, warmup_ratio=1e-2,
+                              power=0.9).bind(m.flat_storage)
+    n_scale[0] = 0
+    taken = [0]
+    if in_backward:
+        orig = opt._on_bucket_reduced
+        def spy(s, lo, hi, inv):
+            taken[0] += 1
+            assert inv == 0.5
+            return orig(s, lo, hi, inv)
+        opt._on_bucket_reduced = spy
+    for k in range(2):
+        x, c, box, aug = batch(rank, n_iter, k)
+        trainer.train_step(w, opt, par, x, c.to(dev), box, n_iter + k, trainer.StepArgs(), c, inputs_aug=aug)
+    m.flat_storage.wait_streams(); torch.cuda.synchronize()
+    st = m.flat_storage
+    return st.data.clone(), st.grad.clone(), opt._flat[1].clone(), opt._flat[2].clone(), n_scale[0], taken[0], w.reducer._calls
+
+for n_iter in (5000, 9000):
+    pa, ga, ma, va, sc_a, tk_a, calls_a = run(n_iter, True)
+    pb, gb, mb, vb, sc_b, tk_b, calls_b = run(n_iter, False)
+    assert tk_a >= 2 * 2 * 4 and sc_a == 0, (tk_a, sc_a)        # every piece went through the optimiser, no scale launch
+    assert tk_b == 0 and sc_b == calls_b > 0, (tk_b, sc_b, calls_b)
+    assert calls_a == calls_b
+    for name, a, b in (("param", pa, pb), ("grad", ga, gb), ("exp_avg", ma, mb), ("exp_avg_sq", va, vb)):
+        assert torch.equal(a, b), (name, n_iter, float((a - b).abs().max()))
+    assert not torch.equal(pa.cpu()[: 1000], torch.zeros(1000))
+    # both ranks hold the same parameters after the steps
+    if MODE == "gloo2":
+        both = [torch.empty_like(pa.cpu()) for _ in range(2)]
+        dist.all_gather(both, pa.cpu())
+        assert torch.equal(both[0], both[1])
+    print("DDP2OPT_BITEQ", rank, n_iter, tk_a, calls_a)
+# a second backward pass inside an armed step is refused
+m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+m.load_state_dict(pp); m.to(dev)
+OPT.ADAMW_IN_BACKWARD = True
+g = m.get_param_groups()
+opt = OPT.PolyWarmupAdamW(params=[{"params": g[i], "lr": 1e-3, "weight_decay": 0.01} for i in range(4)], lr=1e-3, weight_decay=0.01,
+                          betas=(0.9, 0.999), warmup_iter=2, max_iter=100, warmup_ratio=1e-2, power=0.9).bind(m.flat_storage)
+x, c, box, _ = batch(rank, 5000, 0)
+opt.zero_grad()
+l1, _ = trainer.compute_losses(m, par, x, c.to(dev), box, 5000, trainer.StepArgs(), c)
+l2, _ = trainer.compute_losses(m, par, x, c.to(dev), box, 5000, trainer.StepArgs(), c)
+assert opt.begin_step(m)
+l1.sum().backward()
+try:
+    l2.sum().backward()
+    raise SystemExit("second backward was accepted")
+except RuntimeError as e:
+    assert "backward pass" in str(e), e
+opt.zero_grad()
+assert getattr(opt, "_armed", None) is None
+dist.barrier()
+dist.destroy_process_group()
+print("DDP2OPT_OK", rank)
+""")
+    nr = 2 if mode == "gloo2" else 1
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DUPL_ROOT=ROOT, DUPL_TEST_MODE=mode)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nr}", "--master-addr", "127.0.0.1",
+           "--master-port", "29619" if mode == "gloo2" else "29621", str(script)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and out.count("DDP2OPT_OK") == nr and out.count("DDP2OPT_BITEQ") == 2 * nr, out[-5000:]
+
+
 def test_c_abi_from_plain_c(dev, tmp_path):
     """The drop-in boundary without Python or torch: tests/c/abi_smoke.c includes include/dupl_hip.h, allocates with the
     HIP runtime, and calls dupl_fill / dupl_gemm_f32 / dupl_layernorm_fwd / dupl_colsum through the C ABI."""
@@ -439,6 +562,11 @@ def test_bench_multi_rank_control_flow(dev):
     assert cm["allreduce_calls"] >= 16 and cm["comm_exposed_ms"] >= 0.0
     # the run validates its own exchange: bit-identical parameter buffers on all ranks after the steps, world == --gpus
     assert cm["params_identical_on_all_ranks"] is True and cm["world_matches_gpus"] is True and len(cm["param_checksum"]) == 2
+    # round 6: the update rides behind each piece's all-reduce at world > 1 too, and the line says who took part (here both ranks
+    # share cuda:0, so ONE distinct device behind a world of 2 -- on the 8-GPU node this must read N distinct devices)
+    assert cm["optimizer_in_exchange"] is True and cm["comm_stall_ms_in_backward"] >= 0.0
+    rs = cm["ranks_seen"]
+    assert rs["world"] == 2 and len(rs["devices"]) == 2 and rs["distinct_devices"] == 1, rs
     # second field: the configuration BASELINE.json lists for N = 2 (configs[2]: VOC, global batch 4 = 2 img/GPU)
     lc = d["listed_config"]
     assert lc is not None and lc["comm"]["world"] == 2 and lc["baseline_config"] == "configs[2]" and lc["img_per_gpu"] == 2
