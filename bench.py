@@ -365,7 +365,7 @@ class GemmTimer:
             return timer._timed_family("attention_bwd", lambda: timer._orig_ab(qkv16, out, dout, lse, B, N, H, hd, scale, *a, **kw),
                                        10.0 * B * H * N * N * hd)
 
-        def timed_wg(items):        # the grouped weight gradients of a transformer block: ONE launch of the same kernel family
+        def timed_wg(items, **kw):        # the grouped weight gradients of a transformer block: ONE launch of the same kernel family
             fl = by = 0.0
             for dy16, x16, out, _ in items:
                 m_, n_, k_ = dy16.cols, x16.cols, getattr(dy16, "valid_rows", dy16.rows)
@@ -374,7 +374,7 @@ class GemmTimer:
             s_ = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s_)
-            r = timer._orig_wg(items)
+            r = timer._orig_wg(items, **kw)
             e1.record(s_)
             timer.pairs["f16x3"].append((e0, e1))
             timer.flops["f16x3"] += fl

@@ -17,8 +17,24 @@ namespace {
 // addresses (seg-loss forward 55 -> 95 us); with 16 sets the reduction is off the kernel's critical path again.
 constexpr float Q28 = 268435456.f;
 constexpr int LOSS_SETS = 16;
+// finish (ABI 4): the last block also forms the loss VALUE from the four sums into sums[6] -- every operation with the rounding of
+// the torch expression it replaces (six or seven one-element ATen launches per loss on the step's critical path):
+//   1 PTC      0.5 * (1 - s0 / (s1 + 1)) + 0.5 * s2 / (s3 + 1)                     (losses.py:17-21)
+//   2 seg      0.5 * (s0 / (s1 + 1e-6) + s2 / (s3 + 1e-6))                         (losses.py:33-39)
+//   3 plain    (s0 + s2) / max(s1 + s3, 1)                                         (consistency loss, train_final_voc.py:430-436)
+__device__ __forceinline__ float loss_finish(const int mode, const float s0, const float s1, const float s2, const float s3) {
+    if (mode == 1) {
+        const float pos = __fmul_rn(0.5f, __fsub_rn(1.f, __fdiv_rn(s0, __fadd_rn(s1, 1.f))));
+        const float neg = __fdiv_rn(__fmul_rn(0.5f, s2), __fadd_rn(s3, 1.f));
+        return __fadd_rn(pos, neg);
+    }
+    if (mode == 2)
+        return __fmul_rn(0.5f, __fadd_rn(__fdiv_rn(s0, __fadd_rn(s1, 1e-6f)), __fdiv_rn(s2, __fadd_rn(s3, 1e-6f))));
+    return __fdiv_rn(__fadd_rn(s0, s2), fmaxf(__fadd_rn(s1, s3), 1.f));
+}
+
 __device__ __forceinline__ void loss_sums_commit(float* __restrict__ sums, float a, float b, float c, float d, unsigned block_id,
-                                                 unsigned nblocks) {
+                                                 unsigned nblocks, const int finish = 0) {
     unsigned* done = reinterpret_cast<unsigned*>(sums + 4);
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(sums + 8) + 4 * (block_id % LOSS_SETS);
     // Ordering without __threadfence(): on a multi-XCD part an agent-scope release fence writes the XCD's L2 back (buffer_wbl2) --
@@ -39,11 +55,14 @@ __device__ __forceinline__ void loss_sums_commit(float* __restrict__ sums, float
     if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1u) {
         const bool bad = __hip_atomic_load(done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         unsigned long long* all = reinterpret_cast<unsigned long long*>(sums + 8);
+        float r4[4];
         for (int i = 0; i < 4; ++i) {
             unsigned long long t = 0ull;
             for (int s = 0; s < LOSS_SETS; ++s) t += __hip_atomic_load(&all[4 * s + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sums[i] = bad ? __int_as_float(0x7fc00000) : (float)((double)t * (1.0 / 268435456.0));
+            r4[i] = bad ? __int_as_float(0x7fc00000) : (float)((double)t * (1.0 / 268435456.0));
+            sums[i] = r4[i];
         }
+        if (finish) sums[6] = loss_finish(finish, r4[0], r4[1], r4[2], r4[3]);
     }
 }
 
@@ -66,7 +85,7 @@ __device__ __forceinline__ int ptc_pair(const long long* lb, const long long* mk
 // division per element and chained two dependent label loads behind it: 76-109 us for 9.8 MB; now bound by the read).
 __global__ __launch_bounds__(256) void ptc_reduce_kernel(const float* __restrict__ cosm, const long long* __restrict__ label,
                                                          const long long* __restrict__ mask, int ignore,
-                                                         float* __restrict__ sums, int hw) {
+                                                         float* __restrict__ sums, int hw, int finish) {
     __shared__ float red[16];
     const int b = blockIdx.y;
     const long long* lb = label ? label + (long)b * hw : nullptr;
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(256) void ptc_reduce_kernel(const float* __restrict
         }
     }
     sp = block_sum(sp, red); np = block_sum(np, red); sn = block_sum(sn, red); nn = block_sum(nn, red);
-    if (threadIdx.x == 0) loss_sums_commit(sums, sp, np, sn, nn, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    if (threadIdx.x == 0) loss_sums_commit(sums, sp, np, sn, nn, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, finish);
 }
 
 // in place: cos_signed -> d loss / d cos_signed  (g = upstream scalar gradient gscale[0])
@@ -212,7 +231,8 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     if (!BWD) {
         ce_bg = block_sum(ce_bg, red); n_bg = block_sum(n_bg, red); ce_fg = block_sum(ce_fg, red); n_fg = block_sum(n_fg, red);
         if (threadIdx.x == 0)
-            loss_sums_commit(sums, ce_bg, n_bg, ce_fg, n_fg, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+            loss_sums_commit(sums, ce_bg, n_bg, ce_fg, n_fg, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z,
+                             MODE == 0 ? balanced : 0);      // (MODE 0: `balanced` carries the finish mode, dupl_seg_loss_fwd)
     } else {
         // d loss/d z_c = coef * (softmax_c - [c==lab]); scatter to the 4 low-res cells.  All lanes of a wave (4 rows x 16
         // px of the shifted tile) share the same 2x2 cells, so reduce over the wave first: 4*C1 atomics per wave.
@@ -468,14 +488,69 @@ inline int ew_grid(long n) {
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// ----------------------------------------------------------------------------------------------- weighted total of the step's losses
+// total = ((w_0 G_0 + w_1 G_1) + w_2 G_2) + ...,  G_g = ((v_a + v_b) + ...) over the terms of group g in list order, v_i = add_i + *term_i
+// (add_i = 0: the term as it is) -- the loss assembly of train_final_voc.py:210-216,247-254,451-456 with every rounding of the torch
+// expressions it replaces, in ONE launch instead of ~20 one-element ATen kernels (and as many again in their autograd).
+// total[0], gsums[g] = G_g.   Backward: gterm[i] = g[0] * w_group(i).
+struct loss_total_args {
+    const float* term[DUPL_LOSS_TERMS_MAX];
+    float add[DUPL_LOSS_TERMS_MAX];
+    int group[DUPL_LOSS_TERMS_MAX];
+    float weight[DUPL_LOSS_TERMS_MAX];
+    int n, ng;
+};
+__global__ void loss_total_kernel(const loss_total_args a, float* __restrict__ tot, float* __restrict__ gsums) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+    for (int g = 0; g < a.ng; ++g) {
+        float G = 0.f;
+        bool first = true;
+        for (int i = 0; i < a.n; ++i) {
+            if (a.group[i] != g) continue;
+            float v = *a.term[i];
+            if (a.add[i] != 0.f) v = __fadd_rn(a.add[i], v);
+            G = first ? v : __fadd_rn(G, v);
+            first = false;
+        }
+        if (gsums) gsums[g] = G;
+        const float wg = __fmul_rn(a.weight[g], G);
+        total = g == 0 ? wg : __fadd_rn(total, wg);
+    }
+    tot[0] = total;
+}
+__global__ void loss_total_bwd_kernel(const loss_total_args a, const float* __restrict__ g, float* __restrict__ gterm) {
+    const int i = threadIdx.x;
+    if (i < a.n) gterm[i] = __fmul_rn(g[0], a.weight[a.group[i]]);
+}
+
 }  // namespace
 
+extern "C" int dupl_loss_total(const float* const* terms, const float* add, const int32_t* group, int32_t n_terms,
+                               const float* weight, int32_t n_groups, float* total, float* gsums, const float* g, float* gterm,
+                               dupl_stream_t s) {
+    if (!terms || !group || !weight || n_terms < 1 || n_terms > DUPL_LOSS_TERMS_MAX || n_groups < 1 || n_groups > DUPL_LOSS_TERMS_MAX)
+        return DUPL_ERR_ARG;
+    if ((total == nullptr) == (gterm == nullptr) || (gterm && !g)) return DUPL_ERR_ARG;      // forward (total) XOR backward (g, gterm)
+    loss_total_args a;
+    a.n = n_terms; a.ng = n_groups;
+    for (int i = 0; i < DUPL_LOSS_TERMS_MAX; ++i) { a.term[i] = nullptr; a.add[i] = 0.f; a.group[i] = 0; a.weight[i] = 0.f; }
+    for (int i = 0; i < n_terms; ++i) {
+        if (!terms[i] || group[i] < 0 || group[i] >= n_groups) return DUPL_ERR_ARG;
+        a.term[i] = terms[i]; a.add[i] = add ? add[i] : 0.f; a.group[i] = group[i];
+    }
+    for (int g_ = 0; g_ < n_groups; ++g_) a.weight[g_] = weight[g_];
+    if (total) DUPL_LAUNCH(loss_total_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a, total, gsums);
+    else DUPL_LAUNCH(loss_total_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a, g, gterm);
+    return dupl_launch_status();
+}
+
 extern "C" int dupl_ptc_reduce(const float* cosm, const int64_t* label, const int64_t* mask, int32_t ignore_index, float* sums,
-                               int32_t b, int32_t hw, dupl_stream_t s) {
-    if (!cosm || (!label && !mask) || !sums || b <= 0 || hw <= 0) return DUPL_ERR_ARG;
+                               int32_t b, int32_t hw, int32_t finish, dupl_stream_t s) {
+    if (!cosm || (!label && !mask) || !sums || b <= 0 || hw <= 0 || (finish != 0 && finish != 1)) return DUPL_ERR_ARG;
     int gx = hw < 96 ? hw : 96;              // rows of the (hw, hw) matrix per image are dealt to the blocks (~8 rows each at 28 x 28)
     DUPL_LAUNCH(ptc_reduce_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)s, cosm, (const long long*)label,
-                       (const long long*)mask, ignore_index, sums, hw);
+                       (const long long*)mask, ignore_index, sums, hw, finish);
     return dupl_launch_status();
 }
 
@@ -508,11 +583,12 @@ extern "C" int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const
 
 extern "C" int dupl_seg_loss_fwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* sums,
                                  int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip,
-                                 dupl_stream_t s) {
+                                 int32_t finish, dupl_stream_t s) {
     if (!logits || !label || !sums || b <= 0 || C1 <= 0 || h <= 0 || w <= 0 || H < h || W < w) return DUPL_ERR_ARG;
+    if (finish != 0 && finish != 2 && finish != 3) return DUPL_ERR_ARG;
     dim3 grid((W + (W / w) / 2 + 15) / 16 + 1, (H + (H / h) / 2 + 15) / 16 + 1, b);
     DUPL_LAUNCH(seg_loss_kernel<0>, grid, dim3(256), 0, (hipStream_t)s, logits, label, is_i64, ignore_index, sums,
-                       (const float*)nullptr, (float*)nullptr, C1, h, w, H, W, flip, 1);
+                       (const float*)nullptr, (float*)nullptr, C1, h, w, H, W, flip, finish);
     return dupl_launch_status();
 }
 

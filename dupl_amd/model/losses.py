@@ -29,8 +29,10 @@ class _PTC(torch.autograd.Function):
         ops.gemm_raw(xh.data_ptr(), xh.data_ptr(), cos.data_ptr(), hw, hw, c, c, c, hw, batch=b, zdiv=1,
                      sA=(hw * c, 0), sB=(hw * c, 0), sC=(hw * hw, 0))
         sums = ops.zeros((ops.LOSS_SUMS_FLOATS,), x.device)     # [0..3] results, rest = the order-independent reduction's state
-        L().dupl_ptc_reduce(cos.data_ptr(), _p(label), _p(mask), ignore_index, sums.data_ptr(), b, hw, _stream())
-        loss = 0.5 * (1 - sums[0] / (sums[1] + 1)) + 0.5 * sums[2] / (sums[3] + 1)
+        # finish 1: the kernel's last block forms 0.5 * (1 - s0 / (s1 + 1)) + 0.5 * s2 / (s3 + 1) itself (sums[6]; the roundings of the
+        # seven one-element torch launches this line used to be)
+        L().dupl_ptc_reduce(cos.data_ptr(), _p(label), _p(mask), ignore_index, sums.data_ptr(), b, hw, 1, _stream())
+        loss = sums[6].clone()
         ctx.save_for_backward(xh, nrm, cos, sums, label if label is not None else mask)
         ctx.meta = (b, c, h, w, ignore_index, label is not None)
         return loss
@@ -82,12 +84,11 @@ class _SegLoss(torch.autograd.Function):
             label = label.float()
         label = label.contiguous()
         sums = ops.zeros((ops.LOSS_SUMS_FLOATS,), seg.device)
+        # finish: 2 = 0.5 * (s0 / (s1 + 1e-6) + s2 / (s3 + 1e-6)); 3 = (s0 + s2) / max(s1 + s3, 1) (no valid pixel -> 0; reference:
+        # seg_loss * 0) -- formed by the kernel's last block (sums[6])
         L().dupl_seg_loss_fwd(logits.data_ptr(), label.data_ptr(), is_i64, ignore_index, sums.data_ptr(), b, C1, h, w, H, W,
-                              int(flip), _stream())
-        if balanced:
-            loss = 0.5 * (sums[0] / (sums[1] + 1e-6) + sums[2] / (sums[3] + 1e-6))
-        else:
-            loss = (sums[0] + sums[2]) / (sums[1] + sums[3]).clamp_min(1.0)   # no valid pixel -> 0 (reference: seg_loss * 0)
+                              int(flip), 2 if balanced else 3, _stream())
+        loss = sums[6].clone()
         ctx.save_for_backward(logits, label, sums)
         ctx.meta = (b, C1, h, w, H, W, ignore_index, is_i64, int(flip), int(balanced))
         return loss
@@ -250,6 +251,58 @@ class _CosSim(torch.autograd.Function):
 def sim_loss(fmap_1, fmap_2):
     """Discrepancy loss (train_final_voc.py:247-254): 2 + mean cos(f1.detach(), f2) + mean cos(f2.detach(), f1)."""
     return (1 + _CosSim.apply(fmap_1.detach(), fmap_2)) + (1 + _CosSim.apply(fmap_2.detach(), fmap_1))
+
+
+def sim_loss_terms(fmap_1, fmap_2):
+    """The two cosine means of sim_loss, un-assembled: weighted_total adds the 1s and sums them in its one launch."""
+    return _CosSim.apply(fmap_1.detach(), fmap_2), _CosSim.apply(fmap_2.detach(), fmap_1)
+
+
+class _Total(torch.autograd.Function):
+    """total = sum_g weight_g * (sum of the group's terms, each add_i + term_i) over device scalars, in ONE launch with the
+    roundings of the torch expression (csrc/loss.hip::loss_total_kernel); its backward hands every term g * weight_group from one
+    launch too.  forward(meta, *terms) -> (total 0-dim, group sums [n_groups], not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, meta, *terms):
+        import ctypes
+        add, group, weight = meta
+        n, ng = len(terms), len(weight)
+        dev = terms[0].device
+        ts = [t.reshape(1) if t.dim() == 0 else t for t in terms]
+        assert all(t.numel() == 1 and t.dtype == torch.float32 and t.device == dev for t in ts)
+        c = ((ctypes.c_void_p * n)(*[t.data_ptr() for t in ts]), (ctypes.c_float * n)(*add), (ctypes.c_int32 * n)(*group),
+             (ctypes.c_float * ng)(*weight))
+        total = torch.empty((), device=dev, dtype=torch.float32)
+        gsums = torch.empty(ng, device=dev, dtype=torch.float32)
+        L().dupl_loss_total(c[0], c[1], c[2], n, c[3], ng, total.data_ptr(), gsums.data_ptr(), None, None, _stream())
+        ctx.c, ctx.n, ctx.ng, ctx.dev = c, n, ng, dev
+        ctx.keep = ts                       # (the pointer array refers to them)
+        ctx.mark_non_differentiable(gsums)
+        return total, gsums
+
+    @staticmethod
+    def backward(ctx, g, _g_groups):
+        c = ctx.c
+        g = g.reshape(1).contiguous().float()
+        gt = torch.empty(ctx.n, device=ctx.dev, dtype=torch.float32)
+        L().dupl_loss_total(c[0], c[1], c[2], ctx.n, c[3], ctx.ng, None, None, g.data_ptr(), gt.data_ptr(), _stream())
+        return (None,) + tuple(gt[i] for i in range(ctx.n))
+
+
+def weighted_total(groups):
+    """groups: [(weight, [term | (add, term), ...]), ...] -> (total, [group sums]).  total = ((w0 G0 + w1 G1) + w2 G2) + ..., G = its
+    terms (add + term where given) summed left to right: train_final_voc.py:451-456 and the sums that feed it, one launch."""
+    add, group, weight, terms = [], [], [], []
+    for gi, (w, ts) in enumerate(groups):
+        weight.append(float(w))
+        for t in ts:
+            a, t = t if isinstance(t, tuple) else (0.0, t)
+            add.append(float(a))
+            group.append(gi)
+            terms.append(t)
+    total, gsums = _Total.apply((add, group, weight), *terms)
+    return total, [gsums[g] for g in range(len(groups))]
 
 
 class _MSM(torch.autograd.Function):

@@ -109,13 +109,15 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     cls_2, segs_2, fmap_2, cls_aux_2 = res["branch2"]
 
     msm = LS.multilabel_soft_margin_loss
-    cls_loss = msm(cls_1, cls_label) + msm(cls_aux_1, cls_label) + msm(cls_2, cls_label) + msm(cls_aux_2, cls_label)
+    # the scalar arithmetic of the loss assembly (train_final_voc.py:210-216,247-254,451-456) is ONE launch at the end of this function
+    # (LS.weighted_total: the same fp32 operations in the same order); here only the terms are collected
+    cls_terms = [msm(cls_1, cls_label), msm(cls_aux_1, cls_label), msm(cls_2, cls_label), msm(cls_aux_2, cls_label)]
 
     fh, fw = fmap_1.shape[2:]
     out = {"cams_1": cams_1, "cams_2": cams_2, "cams_aux_1": cams_aux_1, "cams_aux_2": cams_aux_2}
     high = None
     if phase_a and coco:
-        ptc_loss = torch.ones(1, device=inputs.device)     # train_final_coco.py:216: no PTC in phase A
+        ptc_terms = [torch.ones(1, device=inputs.device)]     # train_final_coco.py:216: no PTC in phase A
     else:
         if phase_a:
             high = args.high_thre
@@ -133,10 +135,11 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
         (l1, p1), (l2, p2) = core.per_student(lambda: aux_label_and_ptc(cams_aux_1, fmap_1),
                                               lambda: aux_label_and_ptc(cams_aux_2, fmap_2))
         labels = [l1, l2]
-        ptc_loss = p1 + p2
+        ptc_terms = [p1, p2]
         out["pseudo_label_aux_1"], out["pseudo_label_aux_2"] = labels
+    reg_terms = None
     if phase_a:
-        seg_loss = torch.ones(1, device=inputs.device)
+        seg_terms = [torch.ones(1, device=inputs.device)]
     else:
         # the reference passes cams * cls_label_rep (train_final_voc.py:336); refine only reads the channels of
         # PRESENT classes (label == 1), for which that product is the identity, so the (b,C,H,W) multiply is skipped
@@ -171,7 +174,7 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
         # cross supervision: student 1 learns from student 2's labels and vice versa (train_final_voc.py:351-352)
         sl1, sl2 = core.per_student(lambda: LS.get_seg_loss_lowres(segs_1, r2, (h, w), args.ignore_index),
                                     lambda: LS.get_seg_loss_lowres(segs_2, r1, (h, w), args.ignore_index))
-        seg_loss = sl1 + sl2
+        seg_terms = [sl1, sl2]
         out["refined_1"], out["refined_2"] = r1, r2
         if phase_c:
             # consistency regularisation on the 0.75x strong-aug branch (:407-436)
@@ -180,24 +183,28 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
                 return ps, n, LS.get_reg_loss(aug_k, ps, (h, w), args.ignore_index)
             (ps1, n1, g1), (ps2, n2, g2) = core.per_student(lambda: pseudo_and_reg(segs_1, r2, res["branch1_aug"]),
                                                             lambda: pseudo_and_reg(segs_2, r1, res["branch2_aug"]))
-            reg_loss = g1 + g2
-            out.update(pseudo_seg_1=ps1, pseudo_seg_2=ps2, n_uncertain=(n1, n2), reg_loss=reg_loss)
-    sim = LS.sim_loss(fmap_1, fmap_2)
+            reg_terms = [g1, g2]
+            out.update(pseudo_seg_1=ps1, pseudo_seg_2=ps2, n_uncertain=(n1, n2))
+    c1, c2 = LS.sim_loss_terms(fmap_1, fmap_2)
+    sim_terms = [(1.0, c1), (1.0, c2)]           # sim_loss = (1 + cos_1) + (1 + cos_2), train_final_voc.py:251-254
     if coco:    # hard-coded weights, train_final_coco.py:441-448
         if n_iter <= 8000:
-            loss = 1.0 * cls_loss + 0.0 * ptc_loss + 0.0 * seg_loss + 0.0 * sim
+            w = (1.0, 0.0, 0.0, 0.0)
         elif n_iter <= args.coco_switch_iter:
-            loss = 1.0 * cls_loss + 0.0 * ptc_loss + 0.2 * seg_loss + 0.05 * sim
+            w = (1.0, 0.0, 0.2, 0.05)
         else:
-            loss = 1.0 * cls_loss + 0.2 * ptc_loss + 0.2 * seg_loss + 0.05 * sim
-            if phase_c:
-                loss = loss + 0.05 * out["reg_loss"]
+            w = (1.0, 0.2, 0.2, 0.05)
     elif n_iter <= args.cam_iters:
-        loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + 0.0 * seg_loss + 0.1 * sim
-    elif n_iter <= args.gmm_iters:
-        loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + args.w_seg * seg_loss + 0.1 * sim
+        w = (1.0, args.w_ptc, 0.0, 0.1)
     else:
-        loss = 1.0 * cls_loss + args.w_ptc * ptc_loss + args.w_seg * seg_loss + 0.1 * sim + 0.05 * out["reg_loss"]
+        w = (1.0, args.w_ptc, args.w_seg, 0.1)
+    groups = [(w[0], cls_terms), (w[1], ptc_terms), (w[2], seg_terms), (w[3], sim_terms)]
+    if reg_terms is not None and (n_iter > args.gmm_iters or (coco and n_iter > args.coco_switch_iter)):
+        groups.append((0.05, reg_terms))         # ... + 0.05 * reg_loss (train_final_voc.py:456, train_final_coco.py:446-448)
+    loss, gs = LS.weighted_total(groups)
+    cls_loss, ptc_loss, seg_loss, sim = gs[:4]
+    if reg_terms is not None:
+        out["reg_loss"] = gs[4] if len(gs) > 4 else reg_terms[0] + reg_terms[1]
     out.update(loss=loss, cls_loss=cls_loss, ptc_loss=ptc_loss, seg_loss=seg_loss, sim_loss=sim, cls_1=cls_1, segs_1=segs_1,
                fmap_1=fmap_1, cls_aux_1=cls_aux_1, cls_2=cls_2, segs_2=segs_2, fmap_2=fmap_2, cls_aux_2=cls_aux_2)
     return loss, out
@@ -209,7 +216,7 @@ def train_step(model, optim, par, inputs, cls_label, img_box, n_iter: int, args:
     optim.zero_grad()
     loss, out = compute_losses(model, par, inputs, cls_label, img_box, n_iter, args, cls_label_host, inputs_aug)
     if hasattr(optim, "begin_step"):
-        optim.begin_step(model)       # world 1: the update of each gradient range is issued as the backward pass finalises it
-    loss.sum().backward()
+        optim.begin_step(model)       # the update of each gradient range is issued as the backward pass (+ exchange) finalises it
+    (loss if loss.numel() == 1 and loss.dim() == 0 else loss.sum()).backward()
     optim.step()
     return out

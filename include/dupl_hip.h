@@ -354,9 +354,11 @@ int dupl_refine_merge(const float* lab_h, const float* lab_l, float* out, float 
  * when mask != NULL.
  * sums: DUPL_LOSS_SUMS_FLOATS (136) floats, zero-filled by the caller; after the launch sums[0..3] = {sum_pos |cos|, n_pos,
  * sum_neg |cos|, n_neg}.  The rest is the reduction's own state (ABI 3): the blocks accumulate in 64-bit fixed point, so the
- * four results do not depend on the order the blocks retire in -- bit-reproducible in every mode. */
+ * four results do not depend on the order the blocks retire in -- bit-reproducible in every mode.
+ * finish (ABI 4): 1 = the last block to retire also writes the loss VALUE 0.5 (1 - s0 / (s1 + 1)) + 0.5 s2 / (s3 + 1) (losses.py:17-21,
+ * every operation rounded as the torch expression rounds it) to sums[6]; 0 = sums only. */
 int dupl_ptc_reduce(const float* cos, const int64_t* label, const int64_t* mask, int32_t ignore_index, float* sums,
-                    int32_t b, int32_t hw, dupl_stream_t s);
+                    int32_t b, int32_t hw, int32_t finish, dupl_stream_t s);
 /* backward of get_masked_ptc_loss (autograd of losses.py:6-21), in place: cos_signed -> d loss/d cos_signed = sign(cos) * (pos ? -0.5*g/(n_pos+1) : neg ? 0.5*g/(n_neg+1) : 0), g = gscale[0] */
 int dupl_ptc_bwd_mask(float* cos_signed, const int64_t* label, const int64_t* mask, int32_t ignore_index,
                       const float* sums, const float* gscale, int32_t b, int32_t hw, dupl_stream_t s);
@@ -373,7 +375,10 @@ int dupl_l2norm_rows_bwd(const float* dxhat, const float* xhat, const float* nor
  * or int64 (is_i64).  sums: DUPL_LOSS_SUMS_FLOATS zero-filled floats, sums[0..3] = {ce_bg, n_bg, ce_fg, n_fg} after the
  * launch (order-independent fixed-point reduction, see dupl_ptc_reduce). */
 int dupl_seg_loss_fwd(const float* logits, const void* label, int32_t is_i64, int32_t ignore_index, float* sums,
-                      int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip, dupl_stream_t s);
+                      int32_t b, int32_t C1, int32_t h, int32_t w, int32_t H, int32_t W, int32_t flip, int32_t finish,
+                      dupl_stream_t s);
+/* ^ finish (ABI 4): the last block also writes the loss value to sums[6]: 2 = get_seg_loss' 0.5 (s0 / (s1 + 1e-6) + s2 / (s3 + 1e-6))
+ * (losses.py:33-39), 3 = the plain mean (s0 + s2) / max(s1 + s3, 1) of the consistency loss (train_final_voc.py:430-436), 0 = sums only */
 /* same fused upsample + CE, but the per-pixel value ce_map (b,H,W) (0 where label == ignore): the detached
  * ce_criterion(segs, refined_label) maps the GMM noise filter is fitted on (train_final_voc.py:360-361).
  * flip != 0 reads the low-res logits w-flipped (torch.flip(segs_aug, dims=[3]), :407-408). */
@@ -417,6 +422,16 @@ int dupl_cos_sim_fwd(const float* a, const float* b, float* out, float* stats, i
 /* autograd of train_final_voc.py:251-252 -- gradient wrt b only (a is detached): db (+)= g[0]*gmul * d cos / d b */
 int dupl_cos_sim_bwd(const float* a, const float* b, const float* stats, const float* g, float gmul, float* db, int32_t B,
                      int32_t n, int32_t c, int64_t ld, int64_t img_stride, float eps, int32_t accumulate, dupl_stream_t s);
+/* The loss assembly of an iteration (train_final_voc.py:210-216,247-254,451-456: cls = l1 + l2 + l3 + l4, sim = (1 + c1) + (1 + c2),
+ * loss = 1.0 cls + w_ptc ptc + w_seg seg + 0.1 sim [+ 0.05 reg]) as ONE launch over device scalars (ABI 4):
+ *   v_i = add[i] + *terms[i]  (add[i] == 0: the term as it is);   G_g = the v_i with group[i] == g, summed left to right in list order;
+ *   total = ((weight[0] G_0 + weight[1] G_1) + weight[2] G_2) + ...   -- every operation one fp32 rounding, like the torch expression.
+ * Forward (total != NULL, gterm == NULL): total[0], gsums[g] = G_g (gsums may be NULL).   Backward (total == NULL): gterm[i] = g[0] *
+ * weight[group[i]].  terms / add / group / weight are HOST arrays (n_terms, n_groups <= DUPL_LOSS_TERMS_MAX); *terms[i], total, gsums, g,
+ * gterm device memory. */
+#define DUPL_LOSS_TERMS_MAX 16
+int dupl_loss_total(const float* const* terms, const float* add, const int32_t* group, int32_t n_terms, const float* weight,
+                    int32_t n_groups, float* total, float* gsums, const float* g, float* gterm, dupl_stream_t s);
 /* the .mean() of train_final_voc.py:251-252: loss[0] += mul * sum(x[0..n)) */
 int dupl_mean_accum(const float* x, float* loss, int64_t n, float mul, dupl_stream_t s);
 /* F.multilabel_soft_margin_loss (train_final_voc.py:210-216; mean over classes then batch): loss[0] += value (if loss != NULL);

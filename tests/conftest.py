@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host-side oracle work per case; skipped unless DUPL_RUN_SLOW=1 "
+                                       "(tools/gate.sh runs them)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("DUPL_RUN_SLOW", "0") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow case: set DUPL_RUN_SLOW=1 (tools/gate.sh does)")
+    for it in items:
+        if "slow" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -543,7 +543,8 @@ def test_single_student_gradients_vs_oracle_autograd(dev, S, second):
 
 @pytest.mark.parametrize("gemm_mode,case", [("f16x3", "voc_B"), ("f16x3", "coco_B2"), ("f16x3", "voc_C"), ("f16x3", "voc_B_bs4"),
                                             ("f16x3", "voc_B_bs2"), ("f16x3", "coco_B2_bs2_vit21k"), ("f16x3", "voc_B_pretrained_like"),
-                                            ("f32", "voc_B"), ("f32", "voc_B_bs4")],
+                                            ("f32", "voc_B"), ("f32", "voc_B_bs4"),
+                                            pytest.param("f16x3", "coco_B2_bs8", marks=pytest.mark.slow)],
                          indirect=["gemm_mode"])
 def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     """BASELINE configs at FULL size: dual-student ViT-B/16, 448^2 -- the whole step (ms-CAM at three scales, dual
@@ -571,8 +572,9 @@ def test_full_size_vitb_step_vs_oracle(dev, case, gemm_mode):
     coco = case.startswith("coco")
     NC = 81 if coco else 21
     n_iter = {"voc_B": 5000, "coco_B2": 20000, "voc_C": 9000, "voc_B_bs4": 5000, "voc_B_bs2": 5000, "coco_B2_bs2_vit21k": 20000,
-              "voc_B_pretrained_like": 5000}[case]
-    nimg = {"voc_B_bs4": 4, "voc_B_bs2": 2, "coco_B2_bs2_vit21k": 2}.get(case, 1)
+              "voc_B_pretrained_like": 5000, "coco_B2_bs8": 20000}[case]
+    # coco_B2_bs8 (slow: DUPL_RUN_SLOW=1, tools/gate.sh): the metric's "COCO bs = 8" point itself -- 8 images, 81 classes, on one GPU
+    nimg = {"voc_B_bs4": 4, "voc_B_bs2": 2, "coco_B2_bs2_vit21k": 2, "coco_B2_bs8": 8}.get(case, 1)
     backbone = "vit_base_patch16_224" if case.endswith("vit21k") else "deit_base_patch16_224"
     targs = trainer.coco_step_args() if coco else trainer.StepArgs()
     oargs = O.coco_step_args() if coco else O.StepArgs()
@@ -1310,3 +1312,42 @@ def test_merged_pass_survives_a_range_verdict_that_flips_at_this_step(dev):
     finally:
         engine.MERGED_PASS = prev
         ops.set_deterministic(0)
+
+
+def test_coco_eight_images_per_gpu_equal_the_same_images_two_at_a_time(dev):
+    """the metric's second half ("COCO bs = 8") runs 8 images on one GPU -- the largest grids the launchers see
+    (12 560- and 31 392-row GEMMs with the row split, C = 80 CAM fusion / normalisation, 8-image PAR batches) -- while the oracle-
+    verified cases stop at 2 images.  Nothing in the label path mixes images, and no forward kernel's per-element arithmetic depends
+    on the row count, so the 8-image step must reproduce, image by image and BIT FOR BIT, what the same images give two at a time
+    (the batch size `coco_B2_bs2_vit21k` checks against the oracle): both CAMs, the aux pseudo-labels, the PAR-refined label maps of
+    both students.  (Losses and gradients are batch means: the slow case `coco_B2_bs8` of test_full_size_vitb_step_vs_oracle checks
+    those against the oracle.)"""
+    from dupl_amd.model.model_dupl import siamese_network
+    from dupl_amd.model.PAR import PAR
+    from dupl_amd import trainer
+    from oracle import dupl_oracle as O
+    NC = 81
+    pp = O.make_siamese_params(O.VIT_BASE, NC, seed=3)
+    inputs, cls_label, img_box = O.synthetic_batch(8, NC - 1, 448, seed=100)
+    model = siamese_network("deit_base_patch16_224", num_classes=NC, pretrained=False, aux_layer=-3)
+    model.load_state_dict(pp, strict=True)
+    model.to(dev)
+    model.enable_dual_stream(True)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]).to(dev)
+    targs = trainer.coco_step_args()
+    keys = ("cams_1", "cams_2", "cams_aux_1", "cams_aux_2", "pseudo_label_aux_1", "pseudo_label_aux_2", "refined_1", "refined_2")
+
+    def run(sl):
+        box = img_box[sl] if torch.is_tensor(img_box) else [img_box[i] for i in range(*sl.indices(8))]
+        # (grad mode: the step's own route -- shared scale-1.0 pass with activation saving, merged pass at 2 images, row-split at 8)
+        _, out = trainer.compute_losses(model, par, inputs[sl].to(dev), cls_label[sl].to(dev), box, 20000, targs,
+                                        cls_label_host=cls_label[sl])
+        model.flat_storage.wait_streams()
+        torch.cuda.synchronize()
+        return {k: out[k].detach().clone() for k in keys}
+    whole = run(slice(0, 8))
+    assert float(whole["cams_1"].max()) > 0.5 and int((whole["refined_1"] != 255).sum()) > 0
+    for p0 in range(0, 8, 2):
+        part = run(slice(p0, p0 + 2))
+        for k in keys:
+            assert torch.equal(whole[k][p0:p0 + 2], part[k]), (k, p0)

@@ -1278,6 +1278,46 @@ def test_gemm_f16x3_format1_is_fp32_equivalent(dev, M, N, K, tile):
         ops.linear16(xs, ops.split16(W), b)
 
 
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (3072, 768), (768, 3072)])
+@pytest.mark.parametrize("M", [12560, 28240, 31392])
+def test_gemm_f16x3_format1_at_the_coco8_row_counts(dev, M, N, K):
+    """the forward GEMMs at the row counts of the metric's second half ("COCO bs = 8": 8 images per GPU) --
+    12 560 = the saved scale-1.0 pass [x ; flip x], 28 240 = the 1.5x scale alone, 31 392 = the merged no-grad pass -- on the
+    launcher's own choice (256 x 256 tiles with the row split into a 256 x 128 remainder launch where the last round would be
+    nearly empty), with the epilogues of the step (bias + GELU + stored pre-activation for the first c_rows rows + format 1 result
+    planes; bias + residual): error vs fp64 <= 2x the exact-f32 MFMA kernel's + 1e-7, every row written exactly once (the split
+    launches meet at a row boundary: a sentinel in the outputs would survive a gap)."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    xs, Ws = ops.split16(x, exp=ops.EXP_ACT), ops.split16(W, exp=ops.EXP_W)
+    ref = x.double() @ W.double().t() + b.double()
+    # fc1-like: GELU, pre-activation and fp32 rows for the saved prefix only, planes for all rows
+    crow = M // 2
+    pre = torch.full((crow, N), float("nan"), device=dev)
+    y16 = ops.split16_empty(M, N, dev, ops.EXP_ACT)
+    y16.planes.fill_(float("nan"))
+    yc, _ = ops.linear16(xs, Ws, b, gelu=True, store_pre=pre, out16=y16, c_rows=crow)
+    # proj / fc2-like: residual, fp32 for all rows
+    yr = torch.full((M, N), float("nan"), device=dev)
+    ops.linear16(xs, Ws, b, res=res, out=yr)
+    y32 = ops.linear(x, W, b, res=res)
+    want_r = ref + res.double()
+    sc = float(want_r.abs().max())
+    e16, e32 = float((yr.double() - want_r).abs().max()) / sc, float((y32.double() - want_r).abs().max()) / sc
+    print(f"{M}x{N}x{K}: format 1 {e16:.2e}  f32 {e32:.2e}")
+    assert e16 <= 2.0 * e32 + 1e-7          # (NaN sentinels left anywhere fail this too)
+    assert float((pre.double() - ref[:crow]).abs().max()) / float(ref.abs().max()) <= 2.0 * e32 + 1e-7
+    want_g = F.gelu(ref)
+    scg = float(want_g.abs().max())
+    assert yc.shape[0] == crow and float((yc.double() - want_g[:crow]).abs().max()) / scg <= 2.0 * e32 + 2e-7
+    rec = (y16.planes[0].float() + y16.planes[1].float()) / 2.0 ** ops.EXP_ACT
+    assert float((rec.double() - want_g).abs().max()) / scg <= 2.0 * e32 + 2.0 ** -21
+
+
 def test_format1_planes_from_layernorm_and_attention(dev):
     """dupl_layernorm_fwd16 / dupl_attention_fwd16 write their output planes in format 1 on request: the same values as the
     fp32 output, to the format's precision."""
@@ -1304,7 +1344,9 @@ def test_format1_planes_from_layernorm_and_attention(dev):
 
 
 @pytest.mark.parametrize("tokens,n_out,n_in", [(3140, 768, 3072), (3140, 2304, 768), (1570, 768, 768), (130, 96, 288), (34, 288, 96),
-                                               (300, 224, 104)])
+                                               (300, 224, 104),
+                                               # 8 images of 785 tokens -- the metric's "COCO bs = 8" point
+                                               (6280, 768, 3072), (6280, 3072, 768), (6280, 2304, 768), (6280, 768, 768)])
 @pytest.mark.parametrize("x_rows", ["exact", "more"])
 def test_kmajor_backward_gemms_are_fp32_equivalent(dev, tokens, n_out, n_in, x_rows):
     """gemm_f16x3_km_kernel (dupl_gemm16_desc.a_layout / b_layout): the backward GEMMs of y = x W^T on the forward's own format 1

@@ -14,6 +14,10 @@ SHA=$(python -c "from dupl_amd.build import source_digest; print(source_digest()
   echo "# git_head: ${GIT_HEAD:-unknown}"; echo "# csrc_sha256: $SHA"; echo "# date: $(date -u +%FT%TZ)"; } > $OUT
 timeout 1500 python -m pytest tests/ -x -q -m gpu >> $OUT 2>&1
 echo "# pytest rc: $?" >> $OUT
+# the slow cases (minutes of host-side oracle work each; skipped by the plain run above): the 8-image COCO step vs the oracle
+echo "# slow: DUPL_RUN_SLOW=1 python -m pytest tests/ -x -q -m 'gpu and slow'" >> $OUT
+DUPL_RUN_SLOW=1 timeout 1200 python -m pytest tests/ -x -q -m "gpu and slow" >> $OUT 2>&1
+echo "# pytest slow rc: $?" >> $OUT
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("__SMOKE_OK__")' >> $OUT 2>&1
 echo "# smoke rc: $?" >> $OUT
 tail -8 $OUT
