@@ -1743,6 +1743,11 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         // format 1 operands: one accumulator set.  256 x 256 on 8 waves (wave tile 128 x 64, two LDS stages of 64 KB; tile 8) where
         // the grid fills the chip, 256 x 128 (the ring kernel's tile with half the accumulators; 12) below.  One block per tile: the
         // persistent form of 256 x 128 (14) measures the same or 1-3 % less, that of 256 x 256 spills (228 vs 353 TF/s-eq)
+        // (round 6, measured and dropped: the same 256 x 256 tile on FOUR waves of 128 x 128 -- one wave per SIMD in the 512-register
+        // file, 252 VGPRs + 256 accumulation registers, no spill, 16 instead of 24 fragment reads per 48 MFMAs -- is 8-20 % SLOWER on
+        // every forward shape, alone and next to a second stream (15 696 x 3 072 x 768 bias + GELU -> planes: 247 vs 300 TF/s-eq,
+        // 15 696 x 768 x 3 072 bias + residual: 295 vs 328; profiles/r06_tile16.txt): with one wave per SIMD nothing covers a wave's
+        // own waits, the result tile 7 gave in round 3)
         const int nb22 = ((d->M + 255) / 256) * ((d->N + 255) / 256), nb21 = ((d->M + 255) / 256) * ((d->N + 127) / 128);
         int t = (g16_tile == 8 || g16_tile == 12 || g16_tile == 14) ? g16_tile : (nb22 >= g16_f1_big_from ? 8 : 12);
         if (d->K / TBK < 3 && t == 14) t = 12;

@@ -172,6 +172,7 @@ class FlatStorage:
         # sticky "this segment has received a gradient at least once" flags == torch's `p.grad is None` skip
         self.seg_has_grad = [[False] * 5 for _ in range(n_students)]
         self.streams: List = []     # side streams the students run on (siamese_network.enable_dual_stream)
+        self.version_anchor = None  # a Parameter that shares the version counter of every student Parameter (_param_key)
         # launch tuning of this model's split GEMMs (dupl_gemm16_desc.tile / concurrency / persist_blocks / group / sk_slices): the
         # model's own copy of the caller-side defaults -- enable_dual_stream of one model does not retune another
         self.gemm16_tuning = dict(ops.GEMM16_TUNING)
@@ -216,7 +217,14 @@ class FlatStorage:
             self.rewrites += 1
 
     def _param_key(self):
-        return (self.data._version, self.dirty, self.data.data_ptr(), self.rewrites)
+        # torch-visible writes, counted where torch counts them.  The students' Parameters were created as views of the ORIGINAL flat
+        # buffer and keep that buffer's version counter for life -- `p.data = view_of_the_moved_buffer` (network._rebind after .to() /
+        # .cuda()) re-points their storage, not their counter -- so after a move `self.data._version` no longer sees `p.copy_()`,
+        # `p[i] = v` or a load_state_dict (round 6: on the GPU a rewritten parameter left the operand planes AND the range verdicts
+        # stale; on the CPU, where the buffer never moves, the two counters are one and the tests never noticed).  version_anchor is
+        # one of those Parameters (network._build_modules): its counter covers every Parameter of every student.
+        a = self.version_anchor
+        return (self.data._version + (a._version if a is not None else 0), self.dirty, self.data.data_ptr(), self.rewrites)
 
     # ---- the optimiser writes the planes of the parameters it updates (dupl_adamw p_hi / p_lo): utils/optimizer.py
     def planes_current(self, student: int) -> bool:

@@ -231,6 +231,8 @@ class network(nn.Module):
         self.aux_classifier = _Holder()
         self.aux_classifier.register_parameter("weight", params["aux_classifier.weight"])
         self._params_by_key = params
+        if st.version_anchor is None:
+            st.version_anchor = next(iter(params.values()))     # (FlatStorage._param_key: the Parameters' shared version counter)
         self._P = StudentParams(st, s)
 
     def _rebind(self):

@@ -13,7 +13,7 @@ import torch
 import os
 
 from .. import ops
-from ..engine import FlatStorage, SEG_BACKBONE
+from ..engine import FlatStorage, SEG_BACKBONE, SEG_NORM
 
 # the AdamW launches of a step ride in its backward pass (PolyWarmupAdamW.begin_step; world 1): DUPL_ADAMW_IN_BWD=0 = all in step()
 ADAMW_IN_BACKWARD = os.environ.get("DUPL_ADAMW_IN_BWD", "1") != "0"

@@ -362,3 +362,70 @@ def test_library_carries_the_digest_of_its_sources_and_a_stale_one_is_refused(mo
     monkeypatch.setattr(build, "source_digest", lambda: "0" * 64)
     with pytest.raises(ImportError, match="rebuild"):
         _lib._Lib()
+
+
+def test_no_module_uses_a_name_it_never_binds():
+    """Round 6: `optimizer._on_bucket_reduced` used SEG_NORM without importing it -- a path that only runs at world > 1, so the
+    single-GPU gate never reached it and every multi-rank run would have died in its first backward pass.  A static scan (what
+    pyflakes' undefined-name check does; pyflakes is not in the image): every name LOADED anywhere in a product / tool module must be
+    bound somewhere in that module (import, def, class, assignment, argument, comprehension / except / with target) or be a builtin."""
+    import ast
+    import builtins
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, f) for f in ("bench.py", "__graft_entry__.py", "train_final_voc.py", "train_final_coco.py")]
+    for top in ("dupl_amd", "tools", "oracle"):
+        for dp, _, fn in os.walk(os.path.join(root, top)):
+            if any(p in dp for p in ("_obj", "__pycache__", "_ref", "tmp", "abl")):
+                continue
+            files += [os.path.join(dp, f) for f in fn if f.endswith(".py")]
+    bad = []
+    for path in files:
+        tree = ast.parse(open(path).read(), filename=path)
+        bound = set(dir(builtins)) | {"__file__", "__name__", "__doc__", "__spec__", "__package__"}
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                bound.update((a.asname or a.name).split(".")[0] for a in node.names)
+            elif isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                bound.add(node.name)
+            elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+                bound.add(node.id)
+            elif isinstance(node, ast.arg):
+                bound.add(node.arg)
+            elif isinstance(node, ast.ExceptHandler) and node.name:
+                bound.add(node.name)
+            elif isinstance(node, (ast.Global, ast.Nonlocal)):
+                bound.update(node.names)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Name) and isinstance(node.ctx, ast.Load) and node.id not in bound:
+                bad.append(f"{os.path.relpath(path, root)}:{node.lineno}: {node.id}")
+    assert not bad, bad
+
+
+def test_parameter_rewrites_are_seen_after_the_flat_buffer_moved():
+    """Round 6 (found on the GPU by tests/test_engine_gpu.py::test_merged_pass_survives_a_range_verdict_that_flips_at_this_step): the
+    operand planes and the range guard's verdicts are refreshed when FlatStorage._param_key changes.  The key used to read the flat
+    buffer's own torch version counter -- which stops counting writes made THROUGH the Parameters once the buffer has been moved
+    (.to() / .cuda() replace the buffer; `p.data = new_view` re-points a Parameter's storage but not its version counter), so after
+    `model.to(dev)` a `p.copy_()`, `p[i] = v` or `load_state_dict` left stale planes behind.  Emulated here without a GPU: the same
+    FlatStorage.apply + _rebind that .to() runs, with a cloning `fn`."""
+    from dupl_amd.model.model_dupl import siamese_network, network
+    for make in (lambda: siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3),
+                 lambda: network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)):
+        m = make()
+        st = m.flat_storage if hasattr(m, "flat_storage") else m._store
+        m._apply(lambda t: t.clone())                      # what nn.Module.to() calls: a NEW flat buffer, Parameters re-pointed
+        assert st.data._version == 0
+        first = (m.branch2 if hasattr(m, "branch2") else m).encoder.blocks[1].norm1.weight
+        assert first.data_ptr() - st.data.data_ptr() >= 0 and first._version > 0      # a view of the new buffer, the old counter
+        keys = [st._param_key()]
+        with torch.no_grad():
+            first[3] = 7.0
+        keys.append(st._param_key())
+        with torch.no_grad():
+            (m.branch1 if hasattr(m, "branch1") else m).classifier.weight.mul_(2.0)
+        keys.append(st._param_key())
+        m.load_state_dict(m.state_dict())
+        keys.append(st._param_key())
+        st.data.add_(0.0)                                  # a write through the flat buffer itself (a broadcast, a raw copy_)
+        keys.append(st._param_key())
+        assert all(b[0] > a[0] for a, b in zip(keys, keys[1:])), keys
