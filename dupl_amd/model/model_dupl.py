@@ -415,8 +415,10 @@ class siamese_network(nn.Module):
             dev = self._store.data.device
             if dev not in _STREAM_PAIRS:
                 spec = os.environ.get("DUPL_CU_MASK", "")
+                # DUPL_STREAM_PRIO = "a,b" (experiment knob): HIP stream priorities of the two student streams (lower = served first)
+                prio = [int(v) for v in os.environ.get("DUPL_STREAM_PRIO", "0,0").split(",")]
                 _STREAM_PAIRS[dev] = (_cu_masked_streams(dev, spec) if spec else
-                                      [torch.cuda.Stream(device=dev) for _ in range(2)])
+                                      [torch.cuda.Stream(device=dev, priority=prio[i]) for i in range(2)])
             self._store.streams = list(_STREAM_PAIRS[dev])
         tn = self._store.gemm16_tuning       # THIS model's launch tuning (engine.FlatStorage.gemm16_tuning): nothing process-wide
         if not on:

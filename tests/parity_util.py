@@ -53,7 +53,22 @@ def decoder_relu_flips(model, pp, pc, x_dev):
             if res[-1]:
                 worst = max(worst, float(pre.abs()[f].max() / pre.abs().max()))
         out[br] = (res[0], res[1], worst)
+        # the product's global-max-pool decisions of this student, in the order the oracle pools (aux map first, model_dupl.py:100-104)
+        pools = getattr(decoder_relu_flips, "last_pools", None)
+        if pools is not None:
+            pools += [sv.pooled_aux_idx.long().cpu(), sv.pooled_idx.long().cpu()]
     return out, masks
+
+
+def head_decisions(model, pp, pc, x_dev):
+    """decoder_relu_flips + the product's pooling decisions: (relu flips, relu masks, [pool indices (B, D) per oracle pooling call:
+    student 1 aux, x4, student 2 aux, x4])."""
+    decoder_relu_flips.last_pools = []
+    try:
+        flips, masks = decoder_relu_flips(model, pp, pc, x_dev)
+        return flips, masks, decoder_relu_flips.last_pools
+    finally:
+        decoder_relu_flips.last_pools = None
 
 
 import contextlib
@@ -79,3 +94,43 @@ def oracle_relu_masks(masks):
         yield used
     finally:
         F.relu = orig
+
+
+@contextlib.contextmanager
+def oracle_pool_decisions(pools, hw):
+    """Run the oracle with the PRODUCT's global-max-pool decisions imposed (the GMP argmax in front of both classifiers,
+    model_dupl.py:100-104, is a DECISION like a ReLU or a label argmax: where two tokens of a channel tie at round-off level -- the
+    8-image COCO step has one with a relative top-2 gap of 3.5e-8 -- two fp32 implementations may send that channel's whole gradient
+    to different tokens, and the difference is O(1) in one row of every weight gradient below).  Inside the block
+    F.adaptive_max_pool2d(x, (1, 1)) on a (B, D, h, w) input whose (B, D) and h * w match the next entry of `pools` returns x at the
+    product's token per (image, channel) -- differentiable, the gradient goes where the product sent it -- and records, for every
+    (image, channel) where the oracle's own argmax differs, the oracle's margin (its maximum minus its value at the product's token,
+    relative to the map's max-abs).  Other calls (the CAM normalisation pools over class maps) pass through.
+    Yields {"used": calls imposed, "flips": n, "worst_margin": largest relative margin among the flips}."""
+    import torch.nn.functional as F
+    st, orig = {"used": 0, "flips": 0, "worst_margin": 0.0}, F.adaptive_max_pool2d
+
+    def pool(x, output_size, *a, **kw):
+        i = st["used"]
+        one = output_size in (1, (1, 1), [1, 1])
+        if one and i < len(pools) and x.dim() == 4 and tuple(x.shape[:2]) == tuple(pools[i].shape) and x.shape[2] * x.shape[3] == hw:
+            st["used"] += 1
+            flat = x.flatten(2)
+            idx = pools[i].to(flat.device).unsqueeze(-1)
+            got = flat.gather(2, idx)
+            with torch.no_grad():
+                own_v, own_i = flat.max(dim=2, keepdim=True)
+                diff = own_i != idx
+                n = int(diff.sum())
+                if n:
+                    st["flips"] += n
+                    rel = (own_v - got)[diff] / flat.abs().amax()
+                    st["worst_margin"] = max(st["worst_margin"], float(rel.max()))
+            return got.view(x.shape[0], x.shape[1], 1, 1)
+        return orig(x, output_size, *a, **kw)
+
+    F.adaptive_max_pool2d = pool
+    try:
+        yield st
+    finally:
+        F.adaptive_max_pool2d = orig

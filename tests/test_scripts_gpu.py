@@ -493,9 +493,11 @@ opt = OPT.PolyWarmupAdamW(params=[{"params": g[i], "lr": 1e-3, "weight_decay": 0
 x, c, box, _ = batch(rank, 5000, 0)
 opt.zero_grad()
 l1, _ = trainer.compute_losses(m, par, x, c.to(dev), box, 5000, trainer.StepArgs(), c)
-l2, _ = trainer.compute_losses(m, par, x, c.to(dev), box, 5000, trainer.StepArgs(), c)
 assert opt.begin_step(m)
 l1.sum().backward()
+# (the gradient-ready events of a student fire in its LAST pending backward pass -- phase C has two forwards per student -- so the
+# second pass is a whole forward + backward after the first one has finished, without a step() in between: gradient accumulation)
+l2, _ = trainer.compute_losses(m, par, x, c.to(dev), box, 5000, trainer.StepArgs(), c)
 try:
     l2.sum().backward()
     raise SystemExit("second backward was accepted")
