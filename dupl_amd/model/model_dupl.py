@@ -415,10 +415,11 @@ class siamese_network(nn.Module):
             dev = self._store.data.device
             if dev not in _STREAM_PAIRS:
                 spec = os.environ.get("DUPL_CU_MASK", "")
-                # DUPL_STREAM_PRIO = "a,b" (experiment knob): HIP stream priorities of the two student streams (lower = served first)
-                prio = [int(v) for v in os.environ.get("DUPL_STREAM_PRIO", "0,0").split(",")]
+                # (round 6, measured and dropped: HIP stream priorities -- student 1 ahead of student 2, so that its light CAM / label
+                # section would run under the other's forward: 51.80 / 51.86 ms per step vs 51.71 / 51.71 on the same box; both
+                # streams at high priority 51.58 = noise.  profiles/r06_stream_priority.txt)
                 _STREAM_PAIRS[dev] = (_cu_masked_streams(dev, spec) if spec else
-                                      [torch.cuda.Stream(device=dev, priority=prio[i]) for i in range(2)])
+                                      [torch.cuda.Stream(device=dev) for _ in range(2)])
             self._store.streams = list(_STREAM_PAIRS[dev])
         tn = self._store.gemm16_tuning       # THIS model's launch tuning (engine.FlatStorage.gemm16_tuning): nothing process-wide
         if not on:
