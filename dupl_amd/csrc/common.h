@@ -111,17 +111,15 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // 1 + erf cancellation of the textbook formula.  Measured against float64 over [-12, 12] and 2 M normal samples: GELU max abs
 // error 3.9e-7 (0.5 x (1 + erff) with a correctly rounded erff: 4.5e-7), max relative error for x > -3 1.6e-6 (1.1e-5);
 // GELU' max abs error 1.3e-7 (1.4e-7).  |x| is clamped at 5.65 (t = 4): beyond, Phi stays at Phi(-5.65) = 8e-9 resp. 1 - 8e-9.
+constexpr float GELU_CLAMP = 5.65f;
+constexpr float GELU_Q[9] = {-5.128725888425834e-07f, 9.56037638388807e-06f, -7.497461774619296e-05f, 0.00028434989508241415f,
+                             -1.4994513549027033e-05f, -0.006931116338819265f, 0.0524347648024559f, 0.4592214524745941f,
+                             1.151104211807251f};          // q = c8 u^8 + ... + c0, highest power first
 __device__ __forceinline__ float gelu_phi(float x) {
-    const float u = fminf(fabsf(x), 5.65f);
-    float q = -5.128725888425834e-07f;
-    q = fmaf(q, u, 9.56037638388807e-06f);
-    q = fmaf(q, u, -7.497461774619296e-05f);
-    q = fmaf(q, u, 0.00028434989508241415f);
-    q = fmaf(q, u, -1.4994513549027033e-05f);
-    q = fmaf(q, u, -0.006931116338819265f);
-    q = fmaf(q, u, 0.0524347648024559f);
-    q = fmaf(q, u, 0.4592214524745941f);
-    q = fmaf(q, u, 1.151104211807251f);
+    const float u = fminf(fabsf(x), GELU_CLAMP);
+    float q = GELU_Q[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) q = fmaf(q, u, GELU_Q[k]);
     const float he = 0.5f * __builtin_amdgcn_exp2f(-(q * u));
     return x >= 0.f ? 1.f - he : he;
 }
@@ -129,6 +127,43 @@ __device__ __forceinline__ float gelu_f(float x) { return x * gelu_phi(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
     return fmaf(x, pdf, gelu_phi(x));
+}
+// The same two functions on PAIRS (round 6): the Horner chain, the products and the final combination as packed fp32 operations
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two elements per issue slot) -- the scalar form compiled to one v_fmaak_f32 per
+// coefficient and element, ~15 VALU instructions per GELU, ~10 now.  Every operation is the IEEE operation of the scalar form on the
+// same operands in the same order, so the results are the scalar form's (tests/test_kernels_gpu.py::test_gelu_epilogues_follow_the_header_formula).
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f32x2 gelu_phi2(const gelu_f32x2 x) {
+    const gelu_f32x2 u = {fminf(fabsf(x[0]), GELU_CLAMP), fminf(fabsf(x[1]), GELU_CLAMP)};
+    gelu_f32x2 q = {GELU_Q[0], GELU_Q[0]};
+#pragma unroll
+    for (int k = 1; k < 9; ++k) q = __builtin_elementwise_fma(q, u, gelu_f32x2{GELU_Q[k], GELU_Q[k]});
+    const gelu_f32x2 t = q * u;
+    const gelu_f32x2 he = gelu_f32x2{0.5f, 0.5f} * gelu_f32x2{__builtin_amdgcn_exp2f(-t[0]), __builtin_amdgcn_exp2f(-t[1])};
+    const gelu_f32x2 om = gelu_f32x2{1.f, 1.f} - he;
+    return gelu_f32x2{x[0] >= 0.f ? om[0] : he[0], x[1] >= 0.f ? om[1] : he[1]};
+}
+__device__ __forceinline__ void gelu4(float (&v)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+        const gelu_f32x2 x = {v[c], v[c + 1]};
+        const gelu_f32x2 y = x * gelu_phi2(x);
+        v[c] = y[0];
+        v[c + 1] = y[1];
+    }
+}
+// v[c] *= gelu'(a[c])
+__device__ __forceinline__ void gelu_grad_mul4(float (&v)[4], const float (&a)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+        const gelu_f32x2 x = {a[c], a[c + 1]};
+        const gelu_f32x2 e = (gelu_f32x2{-0.72134752044448170368f, -0.72134752044448170368f} * x) * x;
+        const gelu_f32x2 pdf = gelu_f32x2{0.39894228040143267794f, 0.39894228040143267794f} *
+                               gelu_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        const gelu_f32x2 g = __builtin_elementwise_fma(x, pdf, gelu_phi2(x));
+        v[c] *= g[0];
+        v[c + 1] *= g[1];
+    }
 }
 
 // float atomic max via CAS-free integer trick (valid for any finite floats)

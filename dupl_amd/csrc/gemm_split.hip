@@ -233,10 +233,7 @@ __device__ __forceinline__ void gemm16_epilogue_lds(const dupl_gemm16_desc& p, f
                 {
 _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) auxp[c] = v[c]; }
         }
-        if (f_gelu) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
-        }
+        if (f_gelu) gelu4(v);
         if (f_relu) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -248,10 +245,8 @@ _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) auxp[c] = v[c]; }
             } else
                 {
 _Pragma("unroll") for (int c = 0; c < 4; ++c) if (c < nv) a[c] = auxp[c]; }
-            if (f_dgelu) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] *= gelu_grad_f(a[c]);
-            } else {
+            if (f_dgelu) gelu_grad_mul4(v, a);
+            else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = a[c] > 0.f ? v[c] : 0.f;
             }
@@ -338,10 +333,7 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
             for (int c = 0; c < 4; ++c) if (c < nv) auxp[c] = v[c];
         }
     }
-    if (E.f_gelu) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
-    }
+    if (E.f_gelu) gelu4(v);
     if (E.f_relu) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -355,10 +347,8 @@ __device__ __forceinline__ void epi16_quad(const dupl_gemm16_desc& p, const Epi1
 #pragma unroll
             for (int c = 0; c < 4; ++c) if (c < nv) a[c] = auxp[c];
         }
-        if (E.f_dgelu) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] *= gelu_grad_f(a[c]);
-        } else {
+        if (E.f_dgelu) gelu_grad_mul4(v, a);
+        else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = a[c] > 0.f ? v[c] : 0.f;
         }

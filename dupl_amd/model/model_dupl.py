@@ -478,6 +478,10 @@ class siamese_network(nn.Module):
         with torch.cuda.stream(s1):
             r1 = fn1()
         with torch.cuda.stream(s2):
+            # (round 6, measured and dropped: starting student 2 late -- a spin of 0.3 / 1.4 / 4.9 ms in front of its forward, so that
+            # one student's light kernels would meet the other's GEMMs -- only adds the delay: 51.0 / 52.3 / 55.8 vs 50.9 ms per step,
+            # profiles/r06_stream_offset.txt.  The students are not in lock-step to begin with: the host issues student 1's whole
+            # forward before student 2's first launch.)
             r2 = fn2()
         main.wait_stream(s1)
         main.wait_stream(s2)

@@ -1,6 +1,7 @@
 """-m gpu: every HIP kernel against a plain PyTorch reference of the same op (float64 on the host
 for the MFMA kernels), called through the C ABI (dupl_amd.ops -> ctypes -> libdupl_hip.so)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1316,6 +1317,61 @@ def test_gemm_f16x3_format1_at_the_coco8_row_counts(dev, M, N, K):
     assert yc.shape[0] == crow and float((yc.double() - want_g[:crow]).abs().max()) / scg <= 2.0 * e32 + 2e-7
     rec = (y16.planes[0].float() + y16.planes[1].float()) / 2.0 ** ops.EXP_ACT
     assert float((rec.double() - want_g).abs().max()) / scg <= 2.0 * e32 + 2.0 ** -21
+
+
+def test_gelu_epilogues_follow_the_header_formula(dev):
+    """Round 6: the GELU / GELU' of the split-GEMM epilogues run on PAIRS (csrc/common.h::gelu_phi2: packed fp32 FMAs, two elements per
+    issue slot).  Same IEEE operations in the same order as the scalar gelu_phi, so the stored outputs must be x * Phi(x) of the stored
+    pre-activations as the header's formula gives it in fp32 (coefficients parsed from the header; the Horner chain with one rounding
+    per fused multiply-add, exp2 in double then rounded -- v_exp_f32 is within 1 ulp of that) -- and likewise dy * gelu'(pre) for the
+    data-gradient epilogue.  Covers both epilogue forms (LDS walk of the one-block-per-tile kernels, side buffer of the persistent ones)."""
+    import re
+    from dupl_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "dupl_amd", "csrc", "common.h")).read()
+    body = src[src.index("constexpr float GELU_CLAMP"):src.index("float gelu_f(float x)")]
+    nums = [float(v) for v in re.findall(r"(-?\d+\.\d+(?:e-?\d+)?)f", body)]
+    clamp, coef = nums[0], nums[1:10]
+    f32 = np.float32
+
+    def phi(x):
+        u = np.minimum(np.abs(x), f32(clamp)).astype(f32)
+        q = np.full_like(u, f32(coef[0]))
+        for c in coef[1:]:
+            q = (q.astype(np.float64) * u + f32(c)).astype(f32)
+        he = (f32(0.5) * np.exp2(-(q * u).astype(f32).astype(np.float64)).astype(f32)).astype(f32)
+        return np.where(x >= 0, (f32(1.0) - he).astype(f32), he)
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 1000, 768, 256
+    x = (torch.randn(M, K, generator=g) * 1.5).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.08).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    for fmt1 in (True, False):           # format 1: the LDS-walk epilogue of the single-accumulator tiles; format 0: the 128 x 128 kernel
+        xs, Ws = (ops.split16(x, exp=ops.EXP_ACT), ops.split16(W, exp=ops.EXP_W)) if fmt1 else (ops.split16(x), ops.split16(W))
+        pre = torch.empty(M, N, device=dev)
+        y, _ = ops.linear16(xs, Ws, b, gelu=True, store_pre=pre)
+        p_ = pre.cpu().numpy()
+        want = (p_ * phi(p_)).astype(f32)
+        err = np.abs(y.cpu().numpy().astype(np.float64) - want.astype(np.float64))
+        tol = 2.0 ** -22 * np.maximum(np.abs(want), 2.0 ** -20)          # 2 ulp (exp2 in hardware vs double-rounded)
+        assert (err <= tol).all(), (fmt1, float((err / tol).max()))
+    # the data-gradient epilogue dx = (dy W) * gelu'(pre) on the persistent k-major kernel (side-buffer epilogue)
+    tokens, n_out, n_in = 640, 256, 512
+    dy = (torch.randn(tokens, n_out, generator=g) * 1e-3).to(dev)
+    W2 = (torch.randn(n_out, n_in, generator=g) * 0.05).to(dev)
+    pre2 = (torch.randn(tokens, n_in, generator=g) * 1.5).to(dev)
+    dy16, _, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False, fmt1=True, rm_rows=tokens)
+    W16 = ops.split16(W2, exp=ops.EXP_W)
+    dx_lin, _ = ops.linear16(dy16.rows_slice(0, tokens), W16, alpha=alpha, b_kmajor=True)
+    dx, _ = ops.linear16(dy16.rows_slice(0, tokens), W16, alpha=alpha, dgelu_of=pre2, b_kmajor=True)
+    p2 = pre2.cpu().numpy()
+    e = ((f32(-0.72134752044448170368) * p2).astype(f32) * p2).astype(f32)
+    pdf = (f32(0.39894228040143267794) * np.exp2(e.astype(np.float64)).astype(f32)).astype(f32)
+    grad = (p2.astype(np.float64) * pdf + phi(p2)).astype(f32)                  # fmaf(x, pdf, Phi)
+    want = (dx_lin.cpu().numpy() * grad).astype(f32)
+    err = np.abs(dx.cpu().numpy().astype(np.float64) - want.astype(np.float64))
+    tol = 2.0 ** -21 * np.maximum(np.abs(want), float(np.abs(want).max()) * 2.0 ** -12)
+    assert (err <= tol).all(), float((err / tol).max())
 
 
 def test_format1_planes_from_layernorm_and_attention(dev):

@@ -439,9 +439,9 @@ def test_gelu_phi_coefficients():
     from scipy.special import erf, erfc
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "dupl_amd", "csrc", "common.h")).read()
-    body = src[src.index("float gelu_phi(float x)"):src.index("float gelu_f(float x)")]
+    body = src[src.index("constexpr float GELU_CLAMP"):src.index("float gelu_f(float x)")]
     nums = [float(v) for v in re.findall(r"(-?\d+\.\d+(?:e-?\d+)?)f", body)]
-    clamp, coef = nums[0], nums[1:10]            # 5.65f, then q = c8; fmaf(q, u, c7) ... fmaf(q, u, c0)
+    clamp, coef = nums[0], nums[1:10]            # GELU_CLAMP = 5.65f, then GELU_Q = {c8 ... c0}: q = c8; fmaf(q, u, c7) ... fmaf(q, u, c0)
     assert clamp == 5.65 and len(coef) == 9 and nums[10] == 0.5
     f32 = np.float32
     x = np.concatenate([np.linspace(-12, 12, 1000001), np.random.RandomState(0).randn(500000) * 1.5]).astype(f32)

@@ -34,7 +34,7 @@ def main():
         w.step(i)
     torch.cuda.synchronize()
 
-    rec = []          # (key, flops, e0, e1) in issue order
+    rec = []          # (key, flops, e0, e1, stream) in issue order
 
     def ev(key, flops, fn):
         s = torch.cuda.current_stream()
@@ -42,7 +42,7 @@ def main():
         e0.record(s)
         r = fn()
         e1.record(s)
-        rec.append((key, flops, e0, e1))
+        rec.append((key, flops, e0, e1, s.cuda_stream))
         return r
 
     o16, oaf, oab, oafs, owg = ops.linear16, ops.attention_fwd16, ops.attention_bwd16, ops.attention_fwd16_segs, ops.wgrad16_group
@@ -78,11 +78,28 @@ def main():
 
     ops.linear16, ops.attention_fwd16, ops.attention_bwd16, ops.attention_fwd16_segs, ops.wgrad16_group = t16, taf, tab, tafs, twg
     per_step = []
+    occupancy = []
     for i in range(a.steps):
         rec.clear()
+        base = torch.cuda.Event(enable_timing=True)
+        base.record(torch.cuda.current_stream())
+        t_host = __import__("time").perf_counter()
         w.step(10 + i)
         torch.cuda.synchronize()
-        per_step.append([(k, f, e0.elapsed_time(e1)) for k, f, e0, e1 in rec])
+        wall = (__import__("time").perf_counter() - t_host) * 1e3
+        per_step.append([(k, f, e0.elapsed_time(e1)) for k, f, e0, e1, _ in rec])
+        # the step's timeline of the recorded (MFMA-heavy) launches: how long 0 / 1 / 2 of them were in flight
+        iv = sorted((base.elapsed_time(e0), base.elapsed_time(e1), st) for _, _, e0, e1, st in rec)
+        pts = sorted([(a_, 1) for a_, _, _ in iv] + [(b_, -1) for _, b_, _ in iv])
+        depth, last, t_depth = 0, 0.0, {0: 0.0, 1: 0.0, 2: 0.0}
+        for t_, d_ in pts:
+            t_depth[min(depth, 2)] += t_ - last
+            last, depth = t_, depth + d_
+        t_depth[0] += max(0.0, wall - last)
+        per_stream = {}
+        for a_, b_, st in iv:
+            per_stream[st] = per_stream.get(st, 0.0) + (b_ - a_)
+        occupancy.append((wall, t_depth[0], t_depth[1], t_depth[2], sorted(per_stream.values())))
     n = len(per_step[0])
     assert all(len(p) == n for p in per_step)
     rows = OrderedDict()
@@ -95,6 +112,9 @@ def main():
         r[2] += f
     tot = sum(r[1] for r in rows.values())
     print(f"# {a.dataset} {a.batch} img/GPU {a.backbone}, {'two streams' if a.dual else 'one stream'}; {n} launches, {tot:.2f} ms per step")
+    for wall, t0, t1, t2, ps in occupancy:
+        print(f"# step wall {wall:.2f} ms: no recorded launch in flight {t0:.2f} ms, one {t1:.2f} ms, two or more {t2:.2f} ms; "
+              f"per stream sum of intervals {[round(v, 2) for v in ps]}")
     print(f"{'family':14s} {'M':>22s} {'N':>6s} {'K':>6s} {'n':>4s} {'us/launch':>10s} {'ms/step':>8s} {'TF/s-eq':>8s} {'frac':>6s}  epilogue")
     for k, (c, ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
         tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -152,7 +152,30 @@ def gaps(path, tail_frac=0.5, min_us=150.0, top=60):
         print(f"{g:9.1f} {at:9.2f}  {a[:60]} -> {b[:60]}")
 
 
+def sequence(path, tail_frac=0.2):
+    """The kernels of the last `tail_frac` of the trace in start order: start (us from the window's first kernel), duration, idle gap
+    since the previous kernel ended, name -- to read a step's serial sections (what runs between the forward and the backward pass)
+    launch by launch.  python tools/rocpd_stats.py --sequence x.db [frac]"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {namecol}, start, end from kernels order by start").fetchall()
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    lo = t1 - (t1 - t0) * tail_frac
+    rows = [r for r in rows if r[1] >= lo]
+    base, prev_end = rows[0][1], rows[0][1]
+    print(f"# {len(rows)} kernels of the last {tail_frac:.2f} of {path}")
+    print(f"{'start_us':>10s} {'dur_us':>8s} {'gap_us':>8s}  kernel")
+    for n, s_, e in rows:
+        print(f"{(s_ - base) / 1e3:10.1f} {(e - s_) / 1e3:8.1f} {max(0, s_ - prev_end) / 1e3:8.1f}  {short(n)[:70]}")
+        prev_end = max(prev_end, e)
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--sequence":
+        sequence(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.2)
+        sys.exit(0)
     if sys.argv[1] == "--gaps":
         gaps(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.5, float(sys.argv[4]) if len(sys.argv) > 4 else 150.0)
         sys.exit(0)
