@@ -1046,7 +1046,7 @@ def network_forward(P: StudentParams, x: Tensor, save: bool, enc_cache=None):
     return (cls_x4, seg, x4, cls_aux), sv
 
 
-def large_fov_forward(x: Tensor, W6: Tensor, W7: Tensor, W8: Tensor, dil: int) -> Tensor:
+def large_fov_forward(x: Tensor, W6: Tensor, W7: Tensor, W8: Tensor, dil: int, keep: Optional[list] = None) -> Tensor:
     """LargeFOV.forward (conv_head.py:32-41) on a stand-alone feature map x (B, C, h, w) -> (B, classes, h, w): the decoder section
     of network_forward on the exact-f32 kernels (im2col + GEMM with fused ReLU), for callers that run `model.decoder(x4)` themselves."""
     B, C, h, w = x.shape
@@ -1060,7 +1060,58 @@ def large_fov_forward(x: Tensor, W6: Tensor, W7: Tensor, W8: Tensor, dil: int) -
     ops.L().dupl_im2col_dil3(h6.data_ptr(), col7.data_ptr(), B, h, w, dd, dil, dd, n * dd, ops._stream())
     h7 = ops.linear(col7, W7.reshape(W7.shape[0], -1), relu=True)
     seg_tok = ops.linear(h7, W8.reshape(NC, -1))
-    return ops.tokens_to_nchw(seg_tok, B, n, NC, h, w, skip_cls=False)
+    seg = ops.tokens_to_nchw(seg_tok, B, n, NC, h, w, skip_cls=False)
+    if keep is not None:
+        keep.extend((col6, h6, col7, h7))
+    return seg
+
+
+class LargeFOVFn(torch.autograd.Function):
+    """The stand-alone LargeFOV head as an autograd node (round 6; conv_head.py:32-41 is an ordinary nn.Module in the reference, so
+    `model.decoder(x4)` must be trainable on its own): forward = large_fov_forward, backward = the decoder section of
+    network_backward on the exact-f32 kernels -- dW8 = dseg^T h7, dh7 = (dseg W8) [h7 > 0], dW7 = dh7^T col7, dh6 = col2im(dh7 W7)
+    [h6 > 0], dW6 = dh6^T col6, dx = col2im(dh6 W6).  Gradients are RETURNED (torch accumulates them into .grad, which for a student's
+    decoder is a view of the flat gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, x, W6, W7, W8, dil):
+        keep = []
+        with torch.no_grad():
+            seg = large_fov_forward(x.contiguous().float(), W6, W7, W8, dil, keep=keep)
+        ctx.save_for_backward(W6, W7, W8, *keep)
+        ctx.dil, ctx.xshape = dil, tuple(x.shape)
+        return seg
+
+    @staticmethod
+    def backward(ctx, dseg):
+        W6, W7, W8, col6, h6, col7, h7 = ctx.saved_tensors
+        B, C, h, w = ctx.xshape
+        n, dd, NC, dil = h * w, W6.shape[0], W8.shape[0], ctx.dil
+        dev = dseg.device
+        dseg_tok = ops.zeros((B * n, NC), dev)
+        ops.nchw_to_tokens_add(dseg.contiguous().float(), dseg_tok, B, n, NC, skip_cls=False)
+        need = ctx.needs_input_grad
+        dW8 = dW7 = dW6 = dx = None
+        if need[3]:
+            dW8 = torch.empty_like(W8)
+            ops.linear_wgrad(dseg_tok, h7, dW8)
+        dh7 = ops.linear_dgrad(dseg_tok, W8.reshape(NC, dd), relumask_of=h7)
+        if need[2]:
+            dW7 = torch.empty_like(W7)
+            ops.linear_wgrad(dh7, col7, dW7)
+        dcol7 = ops.linear_dgrad(dh7, W7.reshape(dd, -1))
+        dh6 = torch.empty((B * n, dd), device=dev, dtype=torch.float32)
+        ops.L().dupl_col2im_dil3(dcol7.data_ptr(), dh6.data_ptr(), B, h, w, dd, dil, dd, n * dd, 0, h6.data_ptr(), ops._stream())
+        del dcol7
+        if need[1]:
+            dW6 = torch.empty_like(W6)
+            ops.linear_wgrad(dh6, col6, dW6)
+        if need[0]:
+            dcol6 = ops.linear_dgrad(dh6, W6.reshape(dd, -1))
+            dtok = torch.empty((B * n, C), device=dev, dtype=torch.float32)
+            ops.L().dupl_col2im_dil3(dcol6.data_ptr(), dtok.data_ptr(), B, h, w, C, dil, C, n * C, 0, None, ops._stream())
+            dx = ops.tokens_to_nchw(dtok, B, n, C, h, w, skip_cls=False)
+        return dx, dW6, dW7, dW8, None
 
 
 # ------------------------------------------------------------------------------------------------

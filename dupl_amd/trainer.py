@@ -143,19 +143,22 @@ def compute_losses(model, par, inputs, cls_label, img_box, n_iter: int, args: St
     else:
         # the reference passes cams * cls_label_rep (train_final_voc.py:336); refine only reads the channels of
         # PRESENT classes (label == 1), for which that product is the identity, so the (b,C,H,W) multiply is skipped
+        # the colour affinity depends on the images only: once per image for both students (the reference rebuilds it in
+        # each of its four PAR calls per image, PAR.py:52), on the stream both students' streams fork from
+        aff = cam_helper.par_affinity_of(par, inputs_denorm)
         if coco and n_iter <= args.coco_switch_iter:
             # train_final_coco.py:312-322: scalar high threshold on the AUX CAMs
             def refine(cams_aux_k):
                 return cam_helper.refine_cams_with_bkg_v2(par, inputs_denorm, cams=cams_aux_k, cls_labels=cls_label_host,
                                                           high_thre=args.high_thre, low_thre=args.low_thre,
-                                                          ignore_index=args.ignore_index, img_box=img_box)
+                                                          ignore_index=args.ignore_index, img_box=img_box, aff=aff)
             ref_in = (cams_aux_1, cams_aux_2)
         else:
             hmap = high.view(b, 1, 1, 1).expand(b, 1, h, w).contiguous()
             def refine(cams_k):
                 return cam_helper.refine_cams_with_dynamic_thres(par, inputs_denorm, cams=cams_k, cls_labels=cls_label_host,
                                                                  high_thre_map=hmap, low_thre=args.low_thre,
-                                                                 ignore_index=args.ignore_index, img_box=img_box)
+                                                                 ignore_index=args.ignore_index, img_box=img_box, aff=aff)
             ref_in = (cams_1, cams_2)
 
         def refine_and_filter(cams_k, segs_k):

@@ -132,8 +132,16 @@ def label_to_aff_mask(cam_label, ignore_index=255):
     return aff
 
 
+def par_affinity_of(ref_mod, images, down_scale=2):
+    """The colour affinity _refine builds from `images` (PAR.py:39-85 on the down-scaled image): depends on the images only, so a
+    caller that refines several CAM sets of the SAME images -- the two students of a step -- builds it once and passes it as `aff`."""
+    images = images.contiguous().float()
+    H, W = images.shape[2:]
+    return ref_mod.affinity(ops.resize_bilinear(images, H // int(down_scale), W // int(down_scale)))
+
+
 def _refine(ref_mod, images, cams, cls_labels, thr_scalar: Optional[float], thr_map, low_thre, ignore_index, img_box,
-            down_scale):
+            down_scale, aff=None):
     """Shared body of refine_cams_with_bkg_v2 / refine_cams_with_dynamic_thres (cam_helper.py:338-431).
     Jobs: for every image, one PAR run with the high threshold and one with the low threshold; the colour affinity
     is built once per image and shared (the reference rebuilds it per run)."""
@@ -162,8 +170,8 @@ def _refine(ref_mod, images, cams, cls_labels, thr_scalar: Optional[float], thr_
     tab_d = ops.to_device_async(tab, torch.int32, dev)
     job_img, job_K, keys = tab_d[:njobs], tab_d[njobs:2 * njobs], tab_d[2 * njobs:].view(njobs, Kmax)
     box = _box_i32(img_box, dev)
-    half = ops.resize_bilinear(images, H // down_scale, W // down_scale)
-    aff = ref_mod.affinity(half)
+    if aff is None:
+        aff = ref_mod.affinity(ops.resize_bilinear(images, H // down_scale, W // down_scale))
     thr_low = torch.full((b,), float(low_thre), device=dev, dtype=torch.float32)
     if thr_map is not None:
         m_h = ops.refine_pre(cams, thr_map.to(dev).contiguous().float(), None, job_img[:b], job_K[:b], keys[:b], down_scale)
@@ -178,12 +186,13 @@ def _refine(ref_mod, images, cams, cls_labels, thr_scalar: Optional[float], thr_
 
 
 def refine_cams_with_bkg_v2(ref_mod=None, images=None, cams=None, cls_labels=None, high_thre=None, low_thre=None,
-                            ignore_index=False, img_box=None, down_scale=2):
-    """cam_helper.py:338-383 (= camutils.py:145-185) -> (b,H,W) float32 labels in {0..C, ignore_index}."""
-    return _refine(ref_mod, images, cams, cls_labels, high_thre, None, low_thre, ignore_index, img_box, down_scale)
+                            ignore_index=False, img_box=None, down_scale=2, aff=None):
+    """cam_helper.py:338-383 (= camutils.py:145-185) -> (b,H,W) float32 labels in {0..C, ignore_index}.
+    aff (extension): par_affinity_of(ref_mod, images, down_scale), when the caller already has it."""
+    return _refine(ref_mod, images, cams, cls_labels, high_thre, None, low_thre, ignore_index, img_box, down_scale, aff=aff)
 
 
 def refine_cams_with_dynamic_thres(ref_mod=None, images=None, cams=None, cls_labels=None, high_thre_map=None,
-                                   low_thre=None, ignore_index=False, img_box=None, down_scale=2):
-    """cam_helper.py:386-431: high threshold given as a (b,1,H,W) map."""
-    return _refine(ref_mod, images, cams, cls_labels, None, high_thre_map, low_thre, ignore_index, img_box, down_scale)
+                                   low_thre=None, ignore_index=False, img_box=None, down_scale=2, aff=None):
+    """cam_helper.py:386-431: high threshold given as a (b,1,H,W) map.  aff: as in refine_cams_with_bkg_v2."""
+    return _refine(ref_mod, images, cams, cls_labels, None, high_thre_map, low_thre, ignore_index, img_box, down_scale, aff=aff)

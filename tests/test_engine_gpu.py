@@ -505,6 +505,42 @@ def test_decoder_is_callable_on_its_own(dev, tiny_student):
     assert tuple(seg2.shape) == tuple(seg.shape) and relerr(seg2, seg) < 1e-5
 
 
+def test_decoder_on_its_own_is_differentiable(dev):
+    """VERDICT r5 missing 4 / ADVICE r5: the reference's LargeFOV (conv_head.py:32-41) is an ordinary nn.Module -- `model.decoder(x4)`
+    called on its own trains the head.  engine.LargeFOVFn: the gradients of an arbitrary functional w.r.t. the feature map and the
+    three conv weights against torch autograd through the same two dilated convolutions on the host (fp64); the weights' .grad are
+    the views of the flat gradient buffer (accumulated into, like every other gradient of the student)."""
+    from dupl_amd.model.model_dupl import network
+    from oracle import dupl_oracle as O
+    cfg, NC = O.VIT_TINY, 21
+    sp = O.make_student_params(cfg, NC, seed=1)
+    net = network("tiny_test", num_classes=NC, pretrained=False, aux_layer=-3)
+    net.load_state_dict(sp)
+    net.to(dev)
+    net._store.grad.zero_()
+    x4 = O.hash_normal("x4dec", (2, cfg.embed_dim, 7, 5), seed=9)
+    R = O.hash_normal("rdec", (2, NC, 7, 5), seed=10)
+    xg = x4.to(dev).requires_grad_(True)
+    seg = net.decoder(xg)
+    assert seg.requires_grad and tuple(seg.shape) == (2, NC, 7, 5)
+    ((seg * R.to(dev)).sum() + 0.5 * (seg ** 2).sum()).backward()
+    w = {k: sp["decoder." + k + ".weight"].double().requires_grad_(True) for k in ("conv6", "conv7", "conv8")}
+    xr = x4.double().requires_grad_(True)
+    d = net.decoder.dilation          # (5: conv_head.py:17)
+    ref = F.conv2d(F.relu(F.conv2d(F.relu(F.conv2d(xr, w["conv6"], padding=d, dilation=d)), w["conv7"], padding=d, dilation=d)), w["conv8"])
+    assert relerr(seg, ref) < 1e-5
+    ((ref * R.double()).sum() + 0.5 * (ref ** 2).sum()).backward()
+    assert relerr(xg.grad, xr.grad) < 2e-5
+    for k in ("conv6", "conv7", "conv8"):
+        got = net._store.view(0, "decoder." + k + ".weight", grad=True)
+        assert relerr(got, w[k].grad) < 2e-5, k
+        assert getattr(net.decoder, k).weight.grad.data_ptr() == got.data_ptr()
+    # nothing else of the student received a gradient; a no-grad call still takes the plain forward
+    assert float(net._store.view(0, "encoder.blocks.0.attn.qkv.weight", grad=True).abs().max()) == 0.0
+    with torch.no_grad():
+        assert not net.decoder(x4.to(dev)).requires_grad
+
+
 @pytest.mark.parametrize("S,second", [(96, None), (128, None), (96, 128)])
 def test_single_student_gradients_vs_oracle_autograd(dev, S, second):
     """Single `network` (config-1 style), arbitrary linear functional of all four outputs: every parameter gradient of

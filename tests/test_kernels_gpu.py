@@ -1368,9 +1368,12 @@ def test_gelu_epilogues_follow_the_header_formula(dev):
     e = ((f32(-0.72134752044448170368) * p2).astype(f32) * p2).astype(f32)
     pdf = (f32(0.39894228040143267794) * np.exp2(e.astype(np.float64)).astype(f32)).astype(f32)
     grad = (p2.astype(np.float64) * pdf + phi(p2)).astype(f32)                  # fmaf(x, pdf, Phi)
-    want = (dx_lin.cpu().numpy() * grad).astype(f32)
+    lin = dx_lin.cpu().numpy()
+    want = (lin * grad).astype(f32)
     err = np.abs(dx.cpu().numpy().astype(np.float64) - want.astype(np.float64))
-    tol = 2.0 ** -21 * np.maximum(np.abs(want), float(np.abs(want).max()) * 2.0 ** -12)
+    # gelu' = x pdf + Phi cancels near its zero (x ~ -0.75): the bar is ABSOLUTE in gelu' (|gelu'| <= 1.13, a few ulp of 1 from the two
+    # hardware exp2), i.e. relative to the un-gated gradient
+    tol = 2.0 ** -20 * np.abs(lin) + 1e-30
     assert (err <= tol).all(), float((err / tol).max())
 
 
