@@ -475,16 +475,21 @@ class siamese_network(nn.Module):
         s1, s2 = self._store.streams
         s1.wait_stream(main)
         s2.wait_stream(main)
+        # (round 6, measured and dropped: starting student 2 late -- a spin of 0.3 / 1.4 / 4.9 ms in front of its forward, so that
+        # one student's light kernels would meet the other's GEMMs -- only adds the delay: 51.0 / 52.3 / 55.8 vs 50.9 ms per step,
+        # profiles/r06_stream_offset.txt.  The students are not in lock-step to begin with: the host issues student 1's whole
+        # forward (~4 ms of host time) before student 2's first launch.  Removing THAT skew does not pay either: the two launch
+        # sequences issued from two host threads 51.96 / 52.07 vs 51.90 / 51.88 ms (2 img/GPU: 29.06 / 29.36 vs 28.99 / 28.97);
+        # and a third / fourth stream -- each student's no-grad pass of the other scales next to its saved scale-1.0 pass --
+        # 53.65 / 53.61 ms (2 img/GPU: 29.01 / 28.97).  profiles/r06_issue_order.txt: the step is bound by what its MFMA-heavy
+        # kernels cost in total, not by how they are interleaved.)
         with torch.cuda.stream(s1):
             r1 = fn1()
         with torch.cuda.stream(s2):
-            # (round 6, measured and dropped: starting student 2 late -- a spin of 0.3 / 1.4 / 4.9 ms in front of its forward, so that
-            # one student's light kernels would meet the other's GEMMs -- only adds the delay: 51.0 / 52.3 / 55.8 vs 50.9 ms per step,
-            # profiles/r06_stream_offset.txt.  The students are not in lock-step to begin with: the host issues student 1's whole
-            # forward before student 2's first launch.)
             r2 = fn2()
         main.wait_stream(s1)
         main.wait_stream(s2)
+
         def rec(r):
             if torch.is_tensor(r):
                 r.record_stream(main)
