@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the second measurement of the same workload on the exact-f32 MFMA kernels (f16x3 runs only)")
-    ap.add_argument("--pmc-profile", default=os.environ.get("DUPL_PMC_PROFILE", "profiles/r05_final_pmc_hbm.txt"),
+    ap.add_argument("--pmc-profile", default=os.environ.get("DUPL_PMC_PROFILE", "profiles/r06_final_pmc_hbm.txt"),
                     help="PMC summary (tools/profile_round.sh) roofline.traffic is read from; ignored (traffic = null) "
                          "unless its '# csrc_sha256:' header matches the kernel sources of THIS build")
     ap.add_argument("--no-share-encoder", action="store_true",

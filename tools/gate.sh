@@ -2,10 +2,10 @@
 # The round's gate: the FULL GPU suite with -x on a fresh lease, exactly as the driver runs it at round
 # end, plus smoke() -- and the log kept under profiles/.  Run through gpurun from the repo root AFTER the last kernel / default-flag
 # commit of the round:
-#   gpurun --timeout 1700 -- "GIT_HEAD=$(git rev-parse HEAD) bash tools/gate.sh r05"
+#   gpurun --timeout 1700 -- "GIT_HEAD=$(git rev-parse HEAD) bash tools/gate.sh r06"
 # then `cp gpurun_out/<tag>_gate.txt profiles/<tag>_gate.txt` and commit it.  No kernel or default-flag commit after it.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${TAG}_gate.txt
 cd $R

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Chip-occupancy timeline of the timed (two-stream) configuration at a given per-GPU batch (run through gpurun):
-#   gpurun --timeout 900 -- 'bash tools/timeline.sh r05 2'      -> gpurun_out/<tag>_timeline_b<batch>.txt
+#   gpurun --timeout 900 -- 'bash tools/timeline.sh r06 2'      -> gpurun_out/<tag>_timeline_b<batch>.txt
 # rocprofv3 --kernel-trace of `bench.py --batch B`, then tools/rocpd_stats.py --timeline over the last half of the trace.
-TAG=${1:-r05}; BATCH=${2:-4}
+TAG=${1:-r06}; BATCH=${2:-4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${TAG}_timeline_b${BATCH}.txt
 cd /tmp && export TMPDIR=/tmp
