@@ -160,7 +160,7 @@ def setup_seed(seed):
     random.seed(seed)
 
 
-_RESUME_FILES = ("optimizer.pth", "checkpoint.pth", "checkpoint.n_iter")
+_RESUME_FILES = ("optimizer.n_iter", "optimizer.pth", "checkpoint.pth", "checkpoint.n_iter")
 
 
 def _prev(name):
@@ -168,12 +168,19 @@ def _prev(name):
     return f"{stem}.prev{ext}"
 
 
-def _read_generation(resume_dir, prev=False):
+def _read_generation(resume_dir, prev=False, cheap=False):
     """(optimiser payload, n_iter) of the current (or previous) generation if it is COMPLETE -- its iteration tag, written last, equals
     the n_iter inside its optimizer file, written first -- else (None, reason)."""
-    opt, ck, tag = (os.path.join(resume_dir, _prev(n) if prev else n) for n in _RESUME_FILES)
+    begun, opt, ck, tag = (os.path.join(resume_dir, _prev(n) if prev else n) for n in _RESUME_FILES)
     if not (os.path.exists(opt) and os.path.exists(ck)):
         return None, "files missing"
+    if cheap and os.path.exists(begun) and os.path.exists(tag):
+        # the SAVE path only needs "is the current generation complete?" (ADVICE r5: it used to torch.load both students' moment
+        # buffers for that): optimizer.n_iter is written BEFORE optimizer.pth is replaced and the tag after everything, so the two
+        # agree exactly when no later save has begun to replace the files
+        with open(begun) as f, open(tag) as g:
+            a, b = int(f.read().strip()), int(g.read().strip())
+        return (True, b) if a == b else (None, f"a save at n_iter {a} was begun after the last completed one at {b}")
     ost = torch.load(opt, map_location="cpu")
     if not os.path.exists(tag):
         return None, f"no iteration tag (a save was interrupted after its optimizer file reached n_iter {int(ost['n_iter'])})"
@@ -186,22 +193,24 @@ def _read_generation(resume_dir, prev=False):
 
 
 def _save_resume_state(ckpt_dir, wrapped, model, optim, n_iter):
-    """checkpoint.pth (keys prefixed `module.`, train_final_voc.py:519) + optimizer.pth + checkpoint.n_iter, each written to a
-    temporary file and renamed into place, in THIS order: optimizer.pth (it carries n_iter) first, then checkpoint.pth, then the
-    iteration tag -- a job killed between any two renames leaves a tag that differs from optimizer.pth's n_iter, which
+    """checkpoint.pth (keys prefixed `module.`, train_final_voc.py:519) + optimizer.pth + checkpoint.n_iter (+ the small
+    optimizer.n_iter marker), each written to a temporary file and renamed into place, in THIS order: the marker, optimizer.pth (it
+    carries n_iter), then checkpoint.pth, then the iteration tag -- a job killed between any two renames leaves a tag that differs from optimizer.pth's n_iter, which
     `_load_resume_state` recognises as an incomplete generation.  So that one complete generation ALWAYS exists (an
     interrupted save used to leave a directory that could not be resumed at all), the current generation -- if complete -- is
     first kept as *.prev (hard links: no copy; its tag linked last), and the loader falls back to it."""
     os.makedirs(ckpt_dir, exist_ok=True)
     sd = wrapped.state_dict() if wrapped is not None else {"module." + k: v for k, v in model.state_dict().items()}
 
-    if _read_generation(ckpt_dir)[0] is not None:
+    if _read_generation(ckpt_dir, cheap=True)[0] is not None:
         for name in _RESUME_FILES:                       # tag last: an interrupted rotation leaves an incomplete .prev, never a mixed one
             dst = os.path.join(ckpt_dir, _prev(name))
             if os.path.exists(dst):
                 os.remove(dst)
         for name in _RESUME_FILES:
             src, dst = os.path.join(ckpt_dir, name), os.path.join(ckpt_dir, _prev(name))
+            if not os.path.exists(src):                  # (a directory written before the marker existed)
+                continue
             try:
                 os.link(src, dst)
             except OSError:                              # a filesystem without hard links
@@ -213,6 +222,10 @@ def _save_resume_state(ckpt_dir, wrapped, model, optim, n_iter):
         torch.save(obj, tmp)
         os.replace(tmp, os.path.join(ckpt_dir, name))
 
+    tmp = os.path.join(ckpt_dir, "optimizer.n_iter.tmp")
+    with open(tmp, "w") as f:
+        f.write(str(n_iter))
+    os.replace(tmp, os.path.join(ckpt_dir, "optimizer.n_iter"))       # "a save at n_iter has begun": before any payload is replaced
     put({"n_iter": n_iter, "optimizer": optim.state_dict()}, "optimizer.pth")
     put(sd, "checkpoint.pth")
     tmp = os.path.join(ckpt_dir, "checkpoint.n_iter.tmp")

@@ -275,10 +275,12 @@ def test_command_line_flags_match_the_reference(golden_dir):
 
 def test_interrupted_resume_save_falls_back_to_the_previous_generation(tmp_path, monkeypatch):
     """ADVICE r3 + r4: a job killed between any two renames of _save_resume_state must never resume from mixed state -- and must
-    still be resumable.  The save at n_iter 200 is cut after 0 .. 3 of its three os.replace calls: the uncut save (3) resumes at 200;
+    still be resumable.  The save at n_iter 200 is cut after 0 .. 4 of its four os.replace calls (the `optimizer.n_iter` marker, optimizer.pth,
+    checkpoint.pth, the tag): the uncut save (4) resumes at 200;
     every cut one resumes from the last COMPLETE generation, 100 (cut 0: nothing was renamed, the current files are still it; cut
-    1 / 2: optimizer.pth -- and checkpoint.pth -- are already new, the tag is not: the loader takes the *.prev generation every
-    save keeps).  With neither generation complete the loader refuses."""
+    1: only the marker is new -- the payload files are still the complete generation 100; cut 2 / 3: optimizer.pth -- and checkpoint.pth -- are
+    already new, the tag is not: the loader takes the *.prev generation every save keeps).  The save path itself decides "is the current
+    generation complete?" from the marker and the tag alone (no torch.load of the moment buffers: ADVICE r5).  With neither generation complete the loader refuses."""
     from dupl_amd import train_main as TM
 
     class Obj:
@@ -293,7 +295,7 @@ def test_interrupted_resume_save_falls_back_to_the_previous_generation(tmp_path,
     sd, opt, at = TM._load_resume_state(d)
     assert at == 100 and float(sd["w"][0]) == 1 and float(opt["w"][0]) == 10
     real = os.replace
-    for cut in (0, 1, 2, 3):
+    for cut in (0, 1, 2, 3, 4):
         n = {"k": 0}
 
         def flaky(a, b, _n=n, _cut=cut):
@@ -309,7 +311,7 @@ def test_interrupted_resume_save_falls_back_to_the_previous_generation(tmp_path,
             pass
         monkeypatch.setattr(TM.os, "replace", real)
         sd, opt, at = TM._load_resume_state(d)
-        want = (200, 2, 20) if cut == 3 else (100, 1, 10)
+        want = (200, 2, 20) if cut == 4 else (100, 1, 10)
         assert (at, float(sd["w"][0]), float(opt["w"][0])) == want, cut
         # restore a clean state at 100 for the next cut (its own .prev is then whatever complete generation was current)
         TM._save_resume_state(d, None, Obj(1), Obj(10), 100)
