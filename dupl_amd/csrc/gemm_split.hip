@@ -1700,6 +1700,11 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
         if (accum) {
             const int ntf = d->K / TBK;
             auto per = [&](int s_) { return (ntf + s_ - 1) / s_; };
+            auto fits = [&](int s_) { return s_ > 0 && (long)nb21 * s_ <= g16_persist_blocks && per(s_) >= 3 && ntf - (s_ - 1) * per(s_) >= 3; };
+            // an explicit slice count that does not fit THIS shape (more units than blocks, a slice shorter than the prologue) falls back
+            // to the library's choice instead of failing the launch: the value is a per-model tuning default that meets every shape of
+            // the step, including the launches that never look at it (deterministic mode, one block per tile) -- ADVICE r5
+            if (dsk.sk_slices > 0 && !fits(dsk.sk_slices)) dsk.sk_slices = 0;
             if (dsk.sk_slices == 0) {
                 // more tiles than blocks: the equal-run cut (a block's run then spans several tiles); otherwise as many slices as
                 // there are blocks for.  Measured (profiles/r05_sk_slices.txt): stand-alone 3140 x 768 x 3072 244 vs 211 TF/s-eq, 1570 x
@@ -1710,9 +1715,7 @@ extern "C" int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream) 
                 while (S > 1 && (per(S) < 3 || ntf - (S - 1) * per(S) < 3)) --S;
                 dsk.sk_slices = S;
             }
-            if (dsk.sk_slices > 0 && ((long)nb21 * dsk.sk_slices > g16_persist_blocks || per(dsk.sk_slices) < 3 ||
-                                      ntf - (dsk.sk_slices - 1) * per(dsk.sk_slices) < 3))
-                return DUPL_ERR_ARG;      // one unit per block, every slice at least the prologue's 3 k-steps
+            if (dsk.sk_slices > 0 && !fits(dsk.sk_slices)) dsk.sk_slices = -1;      // (cannot happen for the choice above: kept as a guard -> equal runs)
         }
         if (accum && !d->a_layout) {
             // a data gradient with a LINEAR epilogue (dx = alpha dy . W, nothing else) into a zero-filled dx: stream-K pieces meet in

@@ -132,7 +132,8 @@ typedef struct dupl_gemm16_desc {
     int32_t group;                        /* row tiles per group of the block -> tile order */
     int32_t sk_slices;                    /* stream-K forms of the k-major kernels (DUPL_GEMM_ACCUM, not deterministic): n > 0 = every tile's k axis
                                              in n aligned slices, one (tile, slice) unit per block, units dealt slice-major to the XCDs (operands
-                                             shared in L2); 0 = the library picks n from the grid; < 0 = equal runs of (tile, k-step) pairs */
+                                             shared in L2; an n that does not fit a launch's shape -- more units than blocks, a slice under 3 k-steps -- is
+                                             replaced by the library's choice); 0 = the library picks n from the grid; < 0 = equal runs of (tile, k-step) pairs */
     int32_t reserved1;
 } dupl_gemm16_desc;
 int dupl_gemm_f16x3(const dupl_gemm16_desc* d, dupl_stream_t stream);

@@ -1319,6 +1319,31 @@ def test_gemm_f16x3_format1_at_the_coco8_row_counts(dev, M, N, K):
     assert float((rec.double() - want_g).abs().max()) / scg <= 2.0 * e32 + 2.0 ** -21
 
 
+def test_an_explicit_slice_count_that_does_not_fit_falls_back(dev):
+    """`dupl_gemm16_desc.sk_slices` is a per-model tuning default that meets EVERY accumulating k-major launch of a step.  A
+    value that suits one shape (4 slices of fc1's data gradient at 4 images) used to make other launches return DUPL_ERR_ARG -- more
+    (tile, slice) units than blocks, or a slice shorter than the 3-k-step prologue -- and the step aborted.  It now falls back to the
+    library's own choice: the results are the ones of the default."""
+    from dupl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    tokens, n_out, n_in = 1570, 2304, 768
+    dy = (torch.randn(tokens, n_out, generator=g) * 1e-4).to(dev)
+    x = torch.randn(tokens, n_in, generator=g).to(dev)
+    W = (torch.randn(n_out, n_in, generator=g) * 0.03).to(dev)
+    x16, W16 = ops.split16(x, exp=ops.EXP_ACT), ops.split16(W, exp=ops.EXP_W)
+    Kp = (tokens + 31) // 32 * 32
+    dy16, _, alpha = ops.split_prepare(dy, scaled=True, want_rm=True, want_T=False, fmt1=True, rm_rows=Kp)
+    want_dx, want_dw = dy.double() @ W.double(), dy.double().t() @ x.double()
+    for slices in (0, 64, 7):          # 64: 42 tiles x 64 units > 256 blocks; 7 slices of 72 k-steps is fine for dx, 50 k-steps / 7 for dW too
+        tn = dict(ops.GEMM16_TUNING, sk_slices=slices)
+        dx = ops.zeros((tokens, n_in), dev)
+        ops.linear16(dy16.rows_slice(0, tokens), W16, out=dx, accumulate=True, alpha=alpha, b_kmajor=True, tuning=tn)
+        dw = ops.zeros((n_out, n_in), dev)
+        ops.linear16(dy16, x16, out=dw, accumulate=True, alpha=alpha, a_kmajor=True, b_kmajor=True, k_pad=Kp, tuning=tn)
+        assert float((dx.double() - want_dx).abs().max() / want_dx.abs().max()) < 3e-6, slices
+        assert float((dw.double() - want_dw).abs().max() / want_dw.abs().max()) < 3e-6, slices
+
+
 def test_gelu_epilogues_follow_the_header_formula(dev):
     """Round 6: the GELU / GELU' of the split-GEMM epilogues run on PAIRS (csrc/common.h::gelu_phi2: packed fp32 FMAs, two elements per
     issue slot).  Same IEEE operations in the same order as the scalar gelu_phi, so the stored outputs must be x * Phi(x) of the stored
