@@ -173,6 +173,21 @@ class _CamGradFn(torch.autograd.Function):
         return dx4, None
 
 
+def _rebuild_model(kind: str, ctor, state, device, dual: bool):
+    """copy.deepcopy / pickle of a dupl_amd model: the Parameters are views of ONE flat buffer (and the encoder holds a
+    weak reference to its network), so a member-wise copy would detach them from the storage the engine computes on.  A copy is a NEW
+    model of the same configuration with the state loaded into its own flat buffer, on the same device, with the same stream mode."""
+    backbone, num_classes, aux_layer = ctor
+    cls = siamese_network if kind == "siamese" else network
+    m = cls(backbone, num_classes=num_classes, pretrained=False, aux_layer=aux_layer)
+    m.load_state_dict(state, strict=True)
+    if device is not None and torch.device(device).type != "cpu":
+        m.to(device)
+    if dual and kind == "siamese":
+        m.enable_dual_stream(True)
+    return m
+
+
 class network(nn.Module):
     def __init__(self, backbone, num_classes=None, pretrained=None, aux_layer=None, add_mlp=False,
                  _store: Optional[FlatStorage] = None, _student: int = 0):
@@ -183,6 +198,7 @@ class network(nn.Module):
         self.add_mlp = add_mlp
         cfg = encoder_config(backbone, aux_layer)
         self._cfg = cfg
+        self._ctor = (backbone, num_classes, aux_layer)
         self._owns_store = _store is None
         self._store = FlatStorage(cfg, num_classes, 1) if _store is None else _store
         self._student = _student
@@ -258,6 +274,18 @@ class network(nn.Module):
         assert self._store.data.dtype == torch.float32, "dupl_amd is an fp32-storage engine"
         self._rebind()
         return self
+
+    def _copy_args(self):
+        if not self._owns_store:
+            raise RuntimeError("a student of a siamese_network shares the pair's flat storage: copy / pickle the siamese_network")
+        sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items()}
+        return ("single", self._ctor, sd, str(self._store.data.device), False)
+
+    def __deepcopy__(self, memo):
+        return _rebuild_model(*self._copy_args())
+
+    def __reduce_ex__(self, protocol):
+        return _rebuild_model, self._copy_args()
 
     # ---- reference API ------------------------------------------------------------------------
     def get_param_groups(self):
@@ -374,6 +402,7 @@ class siamese_network(nn.Module):
     def __init__(self, backbone, num_classes=None, pretrained=None, aux_layer=None):
         super().__init__()
         cfg = encoder_config(backbone, aux_layer)
+        self._ctor = (backbone, num_classes, aux_layer)
         self._store = FlatStorage(cfg, num_classes, 2)
         self.branch1 = network(backbone, num_classes=num_classes, pretrained=None, aux_layer=aux_layer,
                                _store=self._store, _student=0)
@@ -397,6 +426,16 @@ class siamese_network(nn.Module):
         assert self._store.data.dtype == torch.float32, "dupl_amd is an fp32-storage engine"
         self._rebind()
         return self
+
+    def __deepcopy__(self, memo):
+        return _rebuild_model(*self._copy_args())
+
+    def __reduce_ex__(self, protocol):
+        return _rebuild_model, self._copy_args()
+
+    def _copy_args(self):
+        sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items()}
+        return ("siamese", self._ctor, sd, str(self._store.data.device), bool(getattr(self, "_dual", False) and self._store.streams))
 
     @property
     def flat_storage(self) -> FlatStorage:

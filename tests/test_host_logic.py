@@ -431,3 +431,32 @@ def test_parameter_rewrites_are_seen_after_the_flat_buffer_moved():
         st.data.add_(0.0)                                  # a write through the flat buffer itself (a broadcast, a raw copy_)
         keys.append(st._param_key())
         assert all(b[0] > a[0] for a, b in zip(keys, keys[1:])), keys
+
+
+def test_models_copy_and_pickle_by_reconstruction():
+    """`copy.deepcopy(model)` / `torch.save(model)` used to fail on the encoder's weak reference -- and a member-wise copy
+    would have been worse than a failure: the Parameters are views of ONE flat buffer, a copied Parameter is not.  A copy / an
+    unpickled model is a new model of the same configuration with the state loaded into its OWN flat buffer (same values, independent
+    storage, Parameters that are views of it); a single student of a pair refuses (its storage is the pair's)."""
+    import copy
+    import io
+    from dupl_amd.model.model_dupl import siamese_network, network
+    m = siamese_network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    m2 = copy.deepcopy(m)
+    assert m2.flat_storage is not m.flat_storage and torch.equal(m2.flat_storage.data, m.flat_storage.data)
+    with torch.no_grad():
+        m2.branch1.classifier.weight.add_(1.0)
+    assert not torch.equal(m2.flat_storage.data, m.flat_storage.data)                 # independent storage ...
+    lo = m2.flat_storage.data.data_ptr()
+    for p in m2.parameters():
+        assert lo <= p.data_ptr() < lo + 4 * m2.flat_storage.data.numel()             # ... that its Parameters are views of
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert torch.equal(m3.flat_storage.data, m.flat_storage.data) and sorted(m3.state_dict()) == sorted(m.state_dict())
+    n = network("tiny_test", num_classes=21, pretrained=False, aux_layer=-3)
+    n2 = copy.deepcopy(n)
+    assert n2._store is not n._store and torch.equal(n2._store.data, n._store.data)
+    with pytest.raises(RuntimeError, match="siamese_network"):
+        copy.deepcopy(m.branch1)
